@@ -1,0 +1,468 @@
+/* experiment.c -- OnlineLearningExperiment loop with TD agents over hashed
+ * tile-coded linear representations, restated (TEST INFRASTRUCTURE, see oracle.h).
+ *
+ * Each function cites the reference lines it follows.  Scalar, single thread,
+ * IEEE double, no contraction.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_internal.h"
+
+/* ---------------------------------------------------------------- spec -- */
+void orc_spec_pendulum_sarsa(orc_spec *s)
+{ /* values of the reference's tests/pendulum-sarsa-tc.yaml */
+  memset(s, 0, sizeof(*s));
+  s->test_interval = 10;
+  s->env = ORC_ENV_PENDULUM;
+  s->control_step = 0.03;
+  s->integration_steps = 5;
+  s->timeout = 2.99;
+  s->randomization = 0;
+  s->action_min = -3;            /* task/pendulum/swingup action_min/max, pendulum.cpp:89-90 */
+  s->action_max = 3;
+  s->action_steps = 3;
+  s->agent = ORC_AGENT_SARSA;
+  s->projector.tilings = 16;
+  s->projector.memory = 8388608;
+  s->projector.dims = 3;
+  s->projector.resolution[0] = 0.31415;
+  s->projector.resolution[1] = 3.1415;
+  s->projector.resolution[2] = 3;
+  s->projector.wrapping[0] = 6.283;
+  s->representation.init_min = 0;
+  s->representation.init_max = 1;
+  s->representation.output_min = -DBL_MAX;   /* linear.cpp:86-96: empty => +-DBL_MAX */
+  s->representation.output_max = DBL_MAX;
+  s->representation.limit = 1;               /* linear.h:46-49 */
+  s->epsilon = 0.05;
+  s->decay_rate = 1;                         /* greedy.h:75 */
+  s->decay_min = 0;
+  s->alpha = 0.2;
+  s->gamma = 0.97;
+  s->lambda = 0.65;
+  s->trace = ORC_TRACE_REPLACING;
+  s->ac_step_limit = -1;
+  s->math = ORC_MATH_LIBM;
+}
+
+/* ------------------------------------------------------- representation -- */
+static double lin_read(orc_exp *e, int table, const orc_linear_spec *ls, const orc_proj *p)
+{ /* linear.cpp:136-184, IndexProjection with empty weights */
+  const double *w = e->w[table];
+  double r = 0;
+  for (int i = 0; i < p->n; ++i)
+    r += w[p->idx[i]];
+  r /= p->n;
+  r = fmin(fmax(r, ls->output_min), ls->output_max);
+  e->stats.weight_reads += (uint64_t)p->n;
+  return r;
+}
+
+static void lin_update(orc_exp *e, int table, const orc_linear_spec *ls, const orc_proj *p, double delta)
+{ /* linear.cpp:198-216: every valid index, duplicates applied twice */
+  double *w = e->w[table];
+  for (int i = 0; i < p->n; ++i)
+    if (p->idx[i] != ORC_INVALID)
+    {
+      if (ls->limit)
+        w[p->idx[i]] = fmin(fmax(w[p->idx[i]] + delta, ls->output_min), ls->output_max);
+      else
+        w[p->idx[i]] = w[p->idx[i]] + delta;
+      e->stats.weight_rmws++;
+    }
+}
+
+static void lin_write(orc_exp *e, int table, const orc_linear_spec *ls, const orc_proj *p, double target, double alpha)
+{ /* linear.cpp:186-196 */
+  double value = lin_read(e, table, ls, p);
+  double delta = alpha * (target - value);
+  lin_update(e, table, ls, p, delta);
+}
+
+/* ---------------------------------------------------------------- trace -- */
+static void trace_clear(orc_trace *t)
+{ /* trace.h:200-204 */
+  t->len = 0;
+  t->total_decay = 1.;
+}
+
+static void proj_ssub(orc_proj *a, const orc_proj *b)
+{ /* projection.h:94-104 */
+  for (int i = 0; i < a->n; ++i)
+    for (int j = 0; j < b->n; ++j)
+      if (a->idx[i] == b->idx[j])
+        a->idx[i] = ORC_INVALID;
+}
+
+static void trace_pop_front(orc_trace *t)
+{
+  memmove(&t->p[0], &t->p[1], sizeof(orc_proj) * (size_t)(t->len - 1));
+  memmove(&t->decay[0], &t->decay[1], sizeof(double) * (size_t)(t->len - 1));
+  t->len--;
+}
+
+static void trace_add(orc_trace *t, int kind, const orc_proj *p, double decay)
+{
+  double cut = (kind == ORC_TRACE_REPLACING) ? 0.01 : 0.0001;   /* trace.h:218, :249 */
+  if (decay < cut)
+    trace_clear(t);
+  if (kind == ORC_TRACE_REPLACING)                              /* trace.h:221-222 */
+    for (int i = 0; i < t->len; ++i)
+      proj_ssub(&t->p[i], p);
+  if (t->len >= ORC_MAX_TRACE)
+  {
+    fprintf(stderr, "oracle: trace overflow\n");
+    abort();
+  }
+  t->p[t->len] = *p;                                            /* :224-225 / :254-255 */
+  t->decay[t->len] = decay;
+  t->len++;
+  t->total_decay *= decay;
+  while (t->total_decay < cut && t->len > 1)                    /* :227-231 / :257-261 */
+  {
+    t->total_decay /= t->decay[0];
+    trace_pop_front(t);
+  }
+}
+
+static void lin_update_trace(orc_exp *e, int table, const orc_linear_spec *ls, const orc_trace *t, double delta, double ee)
+{ /* representation.h:79-83 with the iterator of trace.h:150-178: newest first,
+   * weight 1, multiplied by the decay of the entry being left */
+  double weight = 1.;
+  for (int k = 0; k < t->len && weight > 0.001; ++k)
+  {
+    int at = t->len - k - 1;
+    lin_update(e, table, ls, &t->p[at], weight * delta * ee);
+    weight *= t->decay[at];
+  }
+}
+
+/* ------------------------------------------------------------ projector -- */
+static void project_sa(orc_exp *e, const double *obs, double action, orc_proj *p)
+{ /* tile_coding.h:67-73: _project(extend(base, variant)) */
+  const orc_tile_spec *ts = &e->spec.projector;
+  double in[ORC_MAX_DIMS];
+  uint32_t out[ORC_MAX_TILINGS];
+  int D = ts->dims - 1;
+  for (int i = 0; i < D; ++i) in[i] = obs[i];
+  in[D] = action;
+  if (orc_tile_project(ts, in, out) != 0)
+  {
+    fprintf(stderr, "oracle: invalid tile coding spec\n");
+    abort();
+  }
+  p->n = ts->tilings;
+  for (int j = 0; j < p->n; ++j) p->idx[j] = out[j];
+}
+
+/* -------------------------------------------------------------- sampler -- */
+static void findmax(const double *v, int n, int *mai, int *man)
+{ /* greedy.cpp:47-61 */
+  *mai = 0;
+  *man = 1;
+  for (int i = 1; i < n; ++i)
+  {
+    if (v[i] > v[*mai]) { *mai = i; *man = 1; }
+    else if (v[i] == v[*mai]) (*man)++;
+  }
+}
+
+static int tie_break(orc_exp *e, const double *v, int mai, int man)
+{ /* greedy.cpp:77-85 / :206-214; getInteger uses the GLOBAL lrand48 (utils.h:127-130) */
+  int ii = mai;
+  e->stats.ties++;
+  for (int jj = (int)(orc_lrand48(&e->G) % (uint32_t)man); jj >= 0; ++ii)
+    if (v[ii] == v[mai])
+      --jj;
+  return ii - 1;
+}
+
+static int sample_greedy(orc_exp *e, const double *v, int n)
+{ /* greedy.cpp:63-86 */
+  int mai, man;
+  findmax(v, n, &mai, &man);
+  if (man > 1)
+    return tie_break(e, v, mai, man);
+  return mai;
+}
+
+static int sample_eps_greedy(orc_exp *e, double time, const double *v, int n)
+{ /* greedy.cpp:144-218, scalar epsilon */
+  int mai, man;
+  if (time == 0.)
+    e->eps_decay = fmax(e->eps_decay * e->spec.decay_rate, e->spec.decay_min);
+  findmax(v, n, &mai, &man);
+  double r = orc_drand48(&e->S1);
+  if (r < e->eps_decay * e->spec.epsilon)
+  {
+    e->stats.explorations++;
+    return (int)(orc_lrand48(&e->G) % (uint32_t)n);
+  }
+  if (man > 1)
+    return tie_break(e, v, mai, man);
+  return mai;
+}
+
+/* --------------------------------------------------------------- policy -- */
+static void q_values(orc_exp *e, const double *obs, double *q)
+{ /* q.cpp:94-107 */
+  orc_proj p;
+  for (int a = 0; a < e->A; ++a)
+  {
+    project_sa(e, obs, e->actions[a], &p);
+    q[a] = lin_read(e, 0, &e->spec.representation, &p);
+  }
+}
+
+/* ------------------------------------------------------------ predictor -- */
+static double sarsa_update(orc_exp *e, const double *prev_obs, double prev_action, double tau,
+                           double reward, const double *obs, int has_action, double action, orc_proj *pout)
+{ /* sarsa.cpp:98-124 (criticize with an empty `action` argument, predictor.h:75-78) */
+  const orc_spec *s = &e->spec;
+  orc_proj p, pn;
+  project_sa(e, prev_obs, prev_action, &p);
+  double target = reward;
+  if (has_action)
+  {
+    project_sa(e, obs, action, &pn);
+    target += orc_m_powtau(s, s->gamma, tau) * lin_read(e, 0, &s->representation, &pn);
+  }
+  double delta = target - lin_read(e, 0, &s->representation, &p);
+  lin_write(e, 0, &s->representation, &p, target, s->alpha);
+  if (s->trace != ORC_TRACE_NONE)
+  {
+    double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
+    lin_update_trace(e, 0, &s->representation, &e->trace, s->alpha * delta, ee);
+    trace_add(&e->trace, s->trace, &p, ee);
+  }
+  *pout = p;
+  return delta;
+}
+
+static double q_update(orc_exp *e, const double *prev_obs, double prev_action, double tau,
+                       double reward, const double *obs, int has_action, orc_proj *pout)
+{ /* advantage.cpp:71-110 (QPredictor::criticize).  parity unpinned by reference tests. */
+  const orc_spec *s = &e->spec;
+  orc_proj p, pa;
+  project_sa(e, prev_obs, prev_action, &p);
+  double target = reward;
+  if (has_action)
+  {
+    double v = -INFINITY;
+    for (int kk = 0; kk < e->A; ++kk)
+    {
+      project_sa(e, obs, e->actions[kk], &pa);
+      v = fmax(v, lin_read(e, 0, &s->representation, &pa));
+    }
+    target += orc_m_powtau(s, s->gamma, tau) * v;
+  }
+  double delta = target - lin_read(e, 0, &s->representation, &p);
+  lin_write(e, 0, &s->representation, &p, target, s->alpha);
+  if (s->trace != ORC_TRACE_NONE)
+  {
+    double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
+    lin_update_trace(e, 0, &s->representation, &e->trace, s->alpha * delta, ee);
+    trace_add(&e->trace, s->trace, &p, ee);
+  }
+  *pout = p;
+  return delta;
+}
+
+/* ---------------------------------------------------------------- agent -- */
+typedef struct { double value; int index; double q[ORC_MAX_ACTIONS]; } act_t;
+
+static void policy_act(orc_exp *e, int test, double time, const double *obs, act_t *out)
+{ /* q.cpp:143-155 (QPolicy::act with time) */
+  q_values(e, obs, out->q);
+  if (test)
+    out->index = sample_greedy(e, out->q, e->A);
+  else
+    out->index = sample_eps_greedy(e, time, out->q, e->A);
+  out->value = e->actions[out->index];        /* discretizer_->at(index), uniform.cpp:140-151 */
+}
+
+/* --------------------------------------------------------------- create -- */
+static double *table_alloc_init(orc_exp *e, const orc_tile_spec *ts, const orc_linear_spec *ls)
+{ /* linear.cpp:110-121: memory*outputs uniforms from the thread-local RandGen */
+  size_t n = (size_t)ts->memory;
+  double *w = (double *)malloc(n * sizeof(double));
+  if (!w) return NULL;
+  for (size_t i = 0; i < n; ++i)
+    w[i] = ls->init_min + orc_drand48(&e->TL) * (ls->init_max - ls->init_min);   /* utils.h:110-113 */
+  return w;
+}
+
+orc_exp *orc_create(const orc_spec *spec, long seed)
+{
+  if (spec->env != ORC_ENV_PENDULUM) return NULL;                 /* others: later sections */
+  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q) return NULL;
+  if (spec->action_steps < 1 || spec->action_steps > ORC_MAX_ACTIONS) return NULL;
+  if (spec->projector.tilings > ORC_MAX_TILINGS) return NULL;
+
+  orc_exp *e = (orc_exp *)calloc(1, sizeof(*e));
+  if (!e) return NULL;
+  e->spec = *spec;
+
+  /* deployer.cpp:70-74 */
+  orc_srand48(&e->G, seed);
+
+  /* uniform.cpp:60-95: values = min + delta*k, delta = (max-min)/(steps-1), NaN -> 0 */
+  e->A = spec->action_steps;
+  {
+    double range = spec->action_max - spec->action_min;
+    double delta = range / ((double)spec->action_steps - 1);
+    if (isnan(delta)) delta = 0.;
+    for (int k = 0; k < e->A; ++k)
+      e->actions[k] = spec->action_min + delta * k;
+  }
+
+  /* Instantiate order of the yaml (configurable.cpp:627-654): the representation's
+   * configure()->reset() is the first RandGen::instance() call => `new Rand()`
+   * seeds the thread-local stream from the global lrand48() (utils.h:90-93,160-171),
+   * then draws memory*outputs uniforms. */
+  orc_srand48(&e->TL, (long)orc_lrand48(&e->G));
+  e->w[0] = table_alloc_init(e, &spec->projector, &spec->representation);
+  if (!e->w[0]) { free(e); return NULL; }
+  /* learning policy's sampler/epsilon_greedy, then the test policy's
+   * sampler/greedy: each `new Rand()` (greedy.cpp:38-41) */
+  orc_srand48(&e->S1, (long)orc_lrand48(&e->G));
+  orc_srand48(&e->S2, (long)orc_lrand48(&e->G));
+
+  e->eps_decay = 1;
+  trace_clear(&e->trace);
+  return e;
+}
+
+void orc_destroy(orc_exp *e)
+{
+  if (!e) return;
+  free(e->w[0]);
+  free(e->w[1]);
+  free(e);
+}
+
+/* ------------------------------------------------------------------ run -- */
+int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
+            orc_tap *tap, int tap_cap, int *tap_n)
+{ /* online_learning.cpp:154-280 */
+  const orc_spec *s = &e->spec;
+  int nrows = 0, ntap = 0;
+  int D = orc_env_obs_dims(s->env);
+
+  for (int t = 0; t < n_trials; ++t, ++e->tt)
+  {
+    int ti = s->test_interval;
+    int test = (ti >= 0 && e->tt % (ti + 1) == ti);           /* :160 */
+    double obs[ORC_MAX_DIMS], reward, total_reward = 0;
+    int terminal;
+    act_t act;
+
+    /* environment_->start, modeled.cpp:132-158 */
+    orc_env_start(s, e, test, e->state);
+    orc_env_observe(s, e->state, obs);
+
+    /* agent->start */
+    if (test)
+    { /* fixed.cpp:47-51 */
+      e->test_time = 0.;
+      policy_act(e, 1, e->test_time, obs, &act);
+    }
+    else
+    { /* td.cpp:50-61 */
+      trace_clear(&e->trace);                                  /* predictor_->finalize(), sarsa.cpp:126-132 */
+      e->time = 0;
+      policy_act(e, 0, e->time, obs, &act);
+      memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
+      e->prev_action = act.value;
+      e->prev_action_index = act.index;
+    }
+
+    do
+    {
+      double tau = orc_env_step(s, e->state, act.value, obs, &reward, &terminal);   /* :196 */
+      total_reward += reward;                                                      /* :202 */
+      double delta = 0;
+      orc_proj p;
+      p.n = 0;
+
+      if (test)
+      { /* fixed.cpp:53-61 */
+        if (terminal != 2)
+        {
+          e->test_time += tau;
+          policy_act(e, 1, e->test_time, obs, &act);
+        }
+        e->stats.test_steps++;
+      }
+      else
+      {
+        if (terminal == 2)
+        { /* td.cpp:76-81: update with an empty next action */
+          if (s->agent == ORC_AGENT_SARSA)
+            delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
+          else
+            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
+        }
+        else
+        { /* td.cpp:63-74: act first, then update */
+          e->time += tau;
+          policy_act(e, 0, e->time, obs, &act);
+          e->stats.trace_entries_sum += (uint64_t)e->trace.len;
+          if (s->agent == ORC_AGENT_SARSA)
+            delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
+          else
+            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
+          memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
+          e->prev_action = act.value;
+          e->prev_action_index = act.index;
+        }
+        e->ss++;                                                /* :218 */
+        e->stats.learn_steps++;
+      }
+
+      if (tap && ntap < tap_cap)
+      {
+        orc_tap *tp = &tap[ntap++];
+        memset(tp, 0, sizeof(*tp));
+        tp->test = test;
+        tp->action_index = act.index;
+        memcpy(tp->obs, obs, sizeof(double) * (size_t)D);
+        tp->action = act.value;
+        tp->reward = reward;
+        tp->terminal = terminal;
+        tp->trace_len = e->trace.len;
+        for (int a = 0; a < e->A && a < 8; ++a) tp->q[a] = act.q[a];
+        tp->delta = delta;
+        for (int j = 0; j < p.n && j < 32; ++j) tp->p_idx[j] = (uint32_t)p.idx[j];
+      }
+    } while (!terminal);
+
+    if (ti >= 0 ? test : 1)
+    { /* :238-262 */
+      if (rows && nrows < max_rows)
+      {
+        rows[nrows].trial = (ti >= 0) ? (e->tt + 1 - (e->tt + 1) / (ti + 1)) : e->tt;
+        rows[nrows].steps = e->ss;
+        rows[nrows].reward = total_reward;
+        nrows++;
+      }
+    }
+  }
+  if (tap_n) *tap_n = ntap;
+  return nrows;
+}
+
+/* ------------------------------------------------------------ accessors -- */
+void orc_get_stats(const orc_exp *e, orc_stats *out) { *out = e->stats; }
+const double *orc_weights(const orc_exp *e, int table) { return (table == 0 || table == 1) ? e->w[table] : NULL; }
+void orc_get_state(const orc_exp *e, double *state) { memcpy(state, e->state, sizeof(double) * (size_t)orc_env_state_dims(e->spec.env)); }
+void orc_rng_states(const orc_exp *e, uint64_t out[4]) { out[0] = e->G.x; out[1] = e->TL.x; out[2] = e->S1.x; out[3] = e->S2.x; }
+
+int orc_format_row(const orc_row *r, char *buf, size_t cap)
+{ /* the golden file's layout: three setw(15) columns at the default ostream
+   * precision (6 significant digits, %g), tests/template/pendulum-sarsa-tc-0.txt */
+  return snprintf(buf, cap, "%15lld%15lld%15g\n", (long long)r->trial, (long long)r->steps, r->reward);
+}

@@ -1,0 +1,185 @@
+/* portable_math.c -- operation-by-operation specified sin/cos/log
+ * (TEST INFRASTRUCTURE; the HIP kernels restate the same specification in
+ * grl_amd/csrc/grlx_math.h and must agree with this file bit for bit).
+ *
+ * Why: the reference calls glibc's sin/cos/log (pendulum.cpp:62, cart_pole.cpp,
+ * acrobot.cpp, utils.h:120-125).  glibc's results are not specified bit-wise and
+ * are not available on the GPU, so the GPU path and the oracle's
+ * ORC_MATH_PORTABLE mode share this specification instead; ORC_MATH_LIBM keeps
+ * the libm calls to pin the reference's golden file.  tests/test_oracle_math.py
+ * measures how often the two differ (<= 1 ulp, a few percent of arguments).
+ *
+ * Specification (all operations IEEE-754 binary64, round-to-nearest-even;
+ * fma = correctly rounded fused multiply-add; no other contraction allowed --
+ * compile with -ffp-contract=off):
+ *
+ *  reduce(x): fn = rint(x*INVPIO2); r0 = fma(-fn,P1,x)  [exact for |x|<2^20]
+ *             p = fn*P2; pl = fma(fn,P2,-p); (r,e) = TwoSum(r0,-p)
+ *             t = (e-pl) - fn*P3; rh = r+t; rl = (r-rh)+t; quadrant = fn mod 4
+ *  ksin(r,rl): z=r*r; v=z*r; P = S2+z*(S3+...+z*S8) by fma-Horner;
+ *              c = fma(v, fma(z,P,S1), fma(-0.5*z, rl, rl)); result r+c
+ *  kcos(r,rl): z=r*r; hz=0.5*z; w=1-hz; tail=(1-w)-hz; Q = C1+z*(C2+...+z*C8);
+ *              c = fma(z*z, Q, fma(-r, rl, tail)); result w+c
+ *  Constants: tools/gen_math_constants.py (Taylor coefficients 1/k! and a
+ *  three-double split of pi/2, all correctly rounded from exact rationals).
+ *  Domain: |x| < 2^20 (NaN outside; the environments never get there).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "oracle.h"
+
+#define PM_PIO2_1  0x1.921fb54442d18p+0
+#define PM_PIO2_2  0x1.1a62633145c07p-54
+#define PM_PIO2_3  -0x1.f1976b7ed8fbcp-110
+#define PM_INVPIO2 0x1.45f306dc9c883p-1
+#define PM_S1      -0x1.5555555555555p-3
+#define PM_S2      0x1.1111111111111p-7
+#define PM_S3      -0x1.a01a01a01a01ap-13
+#define PM_S4      0x1.71de3a556c734p-19
+#define PM_S5      -0x1.ae64567f544e4p-26
+#define PM_S6      0x1.6124613a86d09p-33
+#define PM_S7      -0x1.ae7f3e733b81fp-41
+#define PM_S8      0x1.952c77030ad4ap-49
+#define PM_C1      0x1.5555555555555p-5
+#define PM_C2      -0x1.6c16c16c16c17p-10
+#define PM_C3      0x1.a01a01a01a01ap-16
+#define PM_C4      -0x1.27e4fb7789f5cp-22
+#define PM_C5      0x1.1eed8eff8d898p-29
+#define PM_C6      -0x1.93974a8c07c9dp-37
+#define PM_C7      0x1.ae7f3e733b81fp-45
+#define PM_C8      -0x1.6827863b97d97p-53
+#define PM_LN2_HI  0x1.62e4200000000p-1
+#define PM_LN2_LO  0x1.fdf473de6af28p-22
+#define PM_SQRT2   0x1.6a09e667f3bcdp+0
+#define PM_L1      0x1.5555555555555p-1
+#define PM_L2      0x1.999999999999ap-2
+#define PM_L3      0x1.2492492492492p-2
+#define PM_L4      0x1.c71c71c71c71cp-3
+#define PM_L5      0x1.745d1745d1746p-3
+#define PM_L6      0x1.3b13b13b13b14p-3
+#define PM_L7      0x1.1111111111111p-3
+#define PM_L8      0x1.e1e1e1e1e1e1ep-4
+#define PM_L9      0x1.af286bca1af28p-4
+#define PM_L10     0x1.8618618618618p-4
+#define PM_L11     0x1.642c8590b2164p-4
+
+static int reduce(double x, double *rh, double *rl)
+{
+  double fn = rint(x * PM_INVPIO2);
+  double r0 = fma(-fn, PM_PIO2_1, x);
+  double p  = fn * PM_PIO2_2;
+  double pl = fma(fn, PM_PIO2_2, -p);
+  double r  = r0 - p;
+  double bb = r - r0;
+  double e  = (r0 - (r - bb)) + (-p - bb);
+  double t  = (e - pl) - fn * PM_PIO2_3;
+  double h  = r + t;
+  *rh = h;
+  *rl = (r - h) + t;
+  return (int)((int64_t)fn & 3);
+}
+
+static double ksin(double r, double rl)
+{
+  double z = r * r, v = z * r;
+  double P = fma(z, PM_S8, PM_S7);
+  P = fma(z, P, PM_S6);
+  P = fma(z, P, PM_S5);
+  P = fma(z, P, PM_S4);
+  P = fma(z, P, PM_S3);
+  P = fma(z, P, PM_S2);
+  double c = fma(v, fma(z, P, PM_S1), fma(-0.5 * z, rl, rl));
+  return r + c;
+}
+
+static double kcos(double r, double rl)
+{
+  double z = r * r, hz = 0.5 * z;
+  double w = 1.0 - hz;
+  double tail = (1.0 - w) - hz;
+  double Q = fma(z, PM_C8, PM_C7);
+  Q = fma(z, Q, PM_C6);
+  Q = fma(z, Q, PM_C5);
+  Q = fma(z, Q, PM_C4);
+  Q = fma(z, Q, PM_C3);
+  Q = fma(z, Q, PM_C2);
+  Q = fma(z, Q, PM_C1);
+  double c = fma(z * z, Q, fma(-r, rl, tail));
+  return w + c;
+}
+
+double orc_psin(double x)
+{
+  double ax = fabs(x), rh, rl;
+  if (!(ax < 0x1p20)) return NAN;
+  if (ax < 0x1p-27) return x;
+  switch (reduce(x, &rh, &rl))
+  {
+    case 0:  return ksin(rh, rl);
+    case 1:  return kcos(rh, rl);
+    case 2:  return -ksin(rh, rl);
+    default: return -kcos(rh, rl);
+  }
+}
+
+double orc_pcos(double x)
+{
+  double ax = fabs(x), rh, rl;
+  if (!(ax < 0x1p20)) return NAN;
+  if (ax < 0x1p-27) return 1.0;
+  switch (reduce(x, &rh, &rl))
+  {
+    case 0:  return kcos(rh, rl);
+    case 1:  return -ksin(rh, rl);
+    case 2:  return -kcos(rh, rl);
+    default: return ksin(rh, rl);
+  }
+}
+
+/* plog(x), x > 0 finite:  x = m*2^k, m in [sqrt2/2, sqrt2);  f = m-1 (exact);
+ * d = f+2; s = f/d; sl = (fma(-s,d,f) - s*((2-(d-f)))) / d   [s+sl ~ f/(f+2)]
+ * z = s*s; R = L1+z*(L2+...+z*L11) by fma-Horner;
+ * lo = fma(k, LN2_LO, fma(s*z, R, 2*sl)); result = fma(k, LN2_HI, 2*s + lo)
+ * where the final sum is evaluated as (k*LN2_HI exact) + (2*s + lo).
+ * x == 0 -> -inf; x < 0 or NaN -> NaN; +inf -> +inf. */
+double orc_plog(double x)
+{
+  uint64_t b;
+  int k;
+  if (x != x || x < 0.0) return NAN;
+  if (x == 0.0) return -INFINITY;
+  if (x == INFINITY) return x;
+  memcpy(&b, &x, 8);
+  k = 0;
+  if ((b >> 52) == 0)
+  { /* subnormal: scale by 2^54 */
+    x *= 0x1p54;
+    memcpy(&b, &x, 8);
+    k = -54;
+  }
+  k += (int)(b >> 52) - 1023;
+  b = (b & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+  double m;
+  memcpy(&m, &b, 8);
+  if (m > PM_SQRT2) { m *= 0.5; k += 1; }
+  double f = m - 1.0;
+  double d = f + 2.0;
+  double dl = 2.0 - (d - f);
+  double s = f / d;
+  double sl = (fma(-s, d, f) - s * dl) / d;
+  double z = s * s;
+  double R = fma(z, PM_L11, PM_L10);
+  R = fma(z, R, PM_L9);
+  R = fma(z, R, PM_L8);
+  R = fma(z, R, PM_L7);
+  R = fma(z, R, PM_L6);
+  R = fma(z, R, PM_L5);
+  R = fma(z, R, PM_L4);
+  R = fma(z, R, PM_L3);
+  R = fma(z, R, PM_L2);
+  R = fma(z, R, PM_L1);
+  double dk = (double)k;
+  double lo = fma(dk, PM_LN2_LO, fma(s * z, R, 2.0 * sl));
+  return fma(dk, PM_LN2_HI, 2.0 * s + lo);
+}
