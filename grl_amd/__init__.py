@@ -1,0 +1,10 @@
+"""grl_amd -- MI355X-native runner for grl's OnlineLearningExperiment hot path.
+
+The product is the HIP library behind include/grlx.h (grl_amd/csrc); this
+package is its ctypes host.  Importing does not load the library; the first use
+does, and fails loudly when it has not been built (no CPU fallback).
+"""
+from . import capi, runner  # noqa: F401
+from .runner import Runner, pendulum_sarsa_config  # noqa: F401
+
+__all__ = ["capi", "runner", "Runner", "pendulum_sarsa_config"]

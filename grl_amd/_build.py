@@ -1,0 +1,46 @@
+"""Build the HIP extension (libgrlx.so) in-tree for gfx950.
+
+`hipcc` cross-compiles without a GPU, so this runs in the CPU container too.
+-ffp-contract=off is REQUIRED: the reference's arithmetic is unfused IEEE double
+(only grlx_math.h fuses, through explicit fma calls).
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgrlx.so")
+SOURCES = ["grlx_kernels.hip", "grlx_api.cpp"]
+HEADERS = ["grlx_internal.h", "grlx_math.h", os.path.join("..", "..", "include", "grlx.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libgrlx.so if missing or older than its sources; return its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build the HIP extension")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,118 @@
+"""ctypes binding of the C ABI in include/grlx.h (the drop-in boundary).
+
+The library is the product; there is no Python or CPU fallback.  If the shared
+object is missing, loading raises -- build it with `python -m grl_amd._build`
+(or __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+MAX_DIMS, MAX_STATE, MAX_ACTIONS = 8, 12, 8
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TABLE_FULL, ERR_DOMAIN, ERR_ROWS_FULL, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7
+ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER = 0, 1, 2, 3
+AGENT_SARSA, AGENT_Q, AGENT_AC = 0, 1, 2
+TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
+
+
+class TileSpec(C.Structure):
+    _fields_ = [("tilings", C.c_int32), ("memory", C.c_int32), ("dims", C.c_int32), ("reserved", C.c_int32),
+                ("resolution", C.c_double * MAX_DIMS), ("wrapping", C.c_double * MAX_DIMS)]
+
+
+class LinearSpec(C.Structure):
+    _fields_ = [("init_min", C.c_double), ("init_max", C.c_double), ("output_min", C.c_double),
+                ("output_max", C.c_double), ("limit", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_replicas", C.c_int32), ("test_interval", C.c_int32), ("env", C.c_int32),
+                ("control_step", C.c_double), ("integration_steps", C.c_int32), ("discrete_time", C.c_int32),
+                ("timeout", C.c_double), ("randomization", C.c_double),
+                ("action_min", C.c_double), ("action_max", C.c_double), ("action_steps", C.c_int32), ("agent", C.c_int32),
+                ("projector", TileSpec), ("representation", LinearSpec),
+                ("epsilon", C.c_double), ("decay_rate", C.c_double), ("decay_min", C.c_double),
+                ("alpha", C.c_double), ("gamma", C.c_double), ("lambda_", C.c_double),
+                ("trace", C.c_int32), ("reserved0", C.c_int32),
+                ("actor_projector", TileSpec), ("actor_representation", LinearSpec),
+                ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
+                ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double), ("ac_step_limit", C.c_double),
+                ("ac_update_method", C.c_int32),
+                ("table_log2_capacity", C.c_int32), ("max_rows", C.c_int32), ("tap_replica", C.c_int32),
+                ("tap_capacity", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class Tap(C.Structure):
+    _fields_ = [("test", C.c_int32), ("action_index", C.c_int32), ("terminal", C.c_int32), ("trace_len", C.c_int32),
+                ("obs", C.c_double * MAX_DIMS), ("action", C.c_double), ("reward", C.c_double), ("delta", C.c_double),
+                ("q", C.c_double * MAX_ACTIONS), ("p_idx", C.c_uint32 * 32)]
+
+
+class GrlxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"grlx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+_P = C.POINTER
+_SIGS = {
+    "grlx_last_error": (C.c_char_p, []),
+    "grlx_abi_version": (C.c_int, []),
+    "grlx_device_count": (C.c_int, []),
+    "grlx_config_pendulum_sarsa": (None, [_P(Config)]),
+    "grlx_create": (C.c_int, [_P(Config), _P(C.c_int64), _P(C.c_void_p)]),
+    "grlx_destroy": (C.c_int, [C.c_void_p]),
+    "grlx_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "grlx_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grlx_rows": (C.c_int, [C.c_void_p]),
+    "grlx_read_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64), _P(C.c_double)]),
+    "grlx_curve_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "grlx_step_counts": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
+    "grlx_get_env_state": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),
+    "grlx_get_rng": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint64)]),
+    "grlx_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double)]),
+    "grlx_table_load": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32)]),
+    "grlx_read_taps": (C.c_int, [C.c_void_p, _P(Tap), C.c_int, _P(C.c_int)]),
+    "grlx_project": (C.c_int, [_P(TileSpec), _P(C.c_double), C.c_int, _P(C.c_uint32)]),
+    "grlx_env_step": (C.c_int, [_P(Config), _P(C.c_double), _P(C.c_double), C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),
+    "grlx_env_dims": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
+    "grlx_read": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), _P(C.c_uint32), C.c_int, _P(C.c_double)]),
+    "grlx_write": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), _P(C.c_uint32), C.c_int, _P(C.c_double), C.c_double]),
+    "grlx_update": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), _P(C.c_uint32), C.c_int, _P(C.c_double)]),
+    "grlx_math": (C.c_int, [C.c_int, _P(C.c_double), _P(C.c_double), C.c_int, _P(C.c_double)]),
+    "grlx_rand48_at": (C.c_int, [C.c_int64, _P(C.c_uint64), C.c_int, _P(C.c_double)]),
+}
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load libgrlx.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build the HIP extension first (python -m grl_amd._build); "
+                          "grl_amd has no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.grlx_abi_version() != 1:
+        raise ImportError("libgrlx.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> int:
+    if code < 0:
+        raise GrlxError(code, load().grlx_last_error().decode())
+    return code

@@ -1,0 +1,594 @@
+// grlx_api.cpp -- the C ABI declared in include/grlx.h.
+//
+// Host-side logic only: validation (grl's bad_param conditions become
+// GRLX_ERR_INVALID with a message), the reference's instantiate-order RNG
+// seeding, device memory management and kernel launches.  No compute happens on
+// the host: without a HIP device every compute entry point fails.
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "grlx_internal.h"
+
+using namespace grlx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess)                                                              \
+      return fail(GRLX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+bool have_device()
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return n > 0;
+}
+
+// host copy of the drand48-family LCG (utils.h:84-137), used only to seed the replicas
+constexpr uint64_t kA = 0x5DEECE66DULL, kC = 0xBULL, kM = (1ULL << 48) - 1;
+inline uint64_t h_seed(long s) { return ((((uint64_t)s) & 0xFFFFFFFFULL) << 16) | 0x330EULL; }   // srand48
+inline uint64_t h_next(uint64_t x) { return (kA * x + kC) & kM; }
+inline uint64_t h_jump(uint64_t x, uint64_t n)
+{
+  uint64_t a = kA, c = kC;
+  while (n)
+  {
+    if (n & 1) x = (a * x + c) & kM;
+    c = ((a + 1) * c) & kM;
+    a = (a * a) & kM;
+    n >>= 1;
+  }
+  return x;
+}
+
+int env_dims(int env, int *S, int *D)
+{
+  switch (env)
+  {
+    case GRLX_ENV_PENDULUM: *S = 3; *D = 2; return GRLX_OK;
+    default: return GRLX_ERR_INVALID;
+  }
+}
+
+// TileCodingProjector::configure (tile_coding.cpp:45-80)
+int make_tile_params(const grlx_tile_spec &ts, TileParams *tp)
+{
+  if (ts.dims < 1 || ts.dims > GRLX_MAX_DIMS) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution (dims %d)", ts.dims);
+  if (ts.tilings < 1 || ts.tilings > 32) return fail(GRLX_ERR_INVALID, "projector/tile_coding:tilings (%d)", ts.tilings);
+  if (ts.memory < 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:memory");
+  memset(tp, 0, sizeof(*tp));
+  tp->T = ts.tilings;
+  tp->D = ts.dims;
+  tp->memory = ts.memory;
+  for (int i = 0; i < ts.dims; ++i)
+  {
+    if (!(ts.resolution[i] > 0)) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution[%d]", i);
+    tp->scaling[i] = ts.tilings / ts.resolution[i];
+    double w = ts.wrapping[i] * tp->scaling[i];
+    if (fabs(w - round(w)) > 0.001)
+      return fail(GRLX_ERR_INVALID, "projector/tile_coding:wrapping (scaled wrapping for dimension %d (%.5f) is not an integer)", i, w);
+    tp->wrap[i] = (int)round(w);
+  }
+  return GRLX_OK;
+}
+
+int make_linear_params(const grlx_linear_spec &ls, uint64_t draws_before, LinearParams *lp)
+{
+  lp->init_min = ls.init_min;
+  lp->init_range = ls.init_max - ls.init_min;     // utils.h:110-113: a + get()*(b-a)
+  lp->out_min = ls.output_min;
+  lp->out_max = ls.output_max;
+  lp->limit = ls.limit;
+  lp->draws_before = draws_before;
+  return GRLX_OK;
+}
+
+int make_params(const grlx_config &c, DevParams *P)
+{
+  memset(P, 0, sizeof(*P));
+  if (c.struct_size != sizeof(grlx_config)) return fail(GRLX_ERR_INVALID, "grlx_config.struct_size %u != %zu (ABI mismatch)", c.struct_size, sizeof(grlx_config));
+  int S, D;
+  if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
+  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+  if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");
+  if (!(c.control_step >= 0.00001)) return fail(GRLX_ERR_INVALID, "model/dynamical:control_step");
+  if (c.integration_steps < 1) return fail(GRLX_ERR_INVALID, "model/dynamical:integration_steps");
+  if (c.action_steps < 1 || c.action_steps > GRLX_MAX_ACTIONS) return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps (1..%d supported)", GRLX_MAX_ACTIONS);
+  if (c.trace != GRLX_TRACE_NONE && c.trace != GRLX_TRACE_REPLACING) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
+
+  P->test_interval = c.test_interval;
+  P->env = c.env;
+  P->agent = c.agent;
+  P->trace_kind = c.trace;
+  P->integration_steps = c.integration_steps;
+  P->h = c.control_step / (double)(size_t)c.integration_steps;      // modeled.cpp:257
+  P->timeout = c.timeout;
+  P->randomization = c.randomization;
+
+  // UniformDiscretizer::configure (uniform.cpp:60-95)
+  P->A = c.action_steps;
+  {
+    double range = c.action_max - c.action_min;
+    double delta = range / ((double)c.action_steps - 1);
+    if (std::isnan(delta)) delta = 0.;
+    for (int k = 0; k < c.action_steps; ++k)
+      P->actions[k] = c.action_min + delta * k;
+  }
+
+  int rc = make_tile_params(c.projector, &P->tile);
+  if (rc != GRLX_OK) return rc;
+  if (P->tile.T != kLanesPerReplica) return fail(GRLX_ERR_INVALID, "projector/tile_coding:tilings must be %d on the fused path", kLanesPerReplica);
+  if (P->tile.D != D + 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution must have %d entries (observation + action)", D + 1);
+  make_linear_params(c.representation, 0, &P->lin);
+
+  P->epsilon = c.epsilon;
+  P->decay_rate = c.decay_rate;
+  P->decay_min = c.decay_min;
+  P->alpha = c.alpha;
+  P->gamma = c.gamma;                     // pow(gamma, tau) with tau = 1
+  P->gl = c.gamma * c.lambda;             // pow(gamma*lambda, tau) with tau = 1
+  if (c.trace == GRLX_TRACE_REPLACING)
+  { // the register trace holds kMaxTrace entries: the reference pops while the total decay < 0.01 (trace.h:227-231)
+    if (!(P->gl > 0 && P->gl < 1)) return fail(GRLX_ERR_INVALID, "predictor: gamma*lambda must be in (0,1) with a trace");
+    double tot = 1;
+    int n = 0;
+    while (tot >= 0.01 && n <= kMaxTrace) { tot *= P->gl; n++; }
+    if (n > kMaxTrace) return fail(GRLX_ERR_INVALID, "predictor: gamma*lambda = %g needs a trace longer than %d entries", P->gl, kMaxTrace);
+  }
+  return GRLX_OK;
+}
+
+} // namespace
+
+struct grlx_ctx {
+  grlx_config cfg;
+  DevParams   P;
+  int         S, D;
+  Entry        *tables = nullptr;
+  ReplicaState *states = nullptr;
+  double       *row_reward = nullptr;
+  int64_t      *row_steps = nullptr, *row_trial = nullptr;
+  grlx_tap     *taps = nullptr;
+  uint32_t     *tap_count = nullptr;
+  uint64_t     *scratch = nullptr;        // 8 x u64
+  int64_t      trials_run = 0;
+};
+
+// small RAII helper for the copy-in / copy-out entry points
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename T> T *as() { return (T *)p; }
+};
+}
+
+extern "C" {
+
+const char *grlx_last_error(void) { return g_err.c_str(); }
+int grlx_abi_version(void) { return GRLX_ABI_VERSION; }
+
+int grlx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+void grlx_config_pendulum_sarsa(grlx_config *c)
+{ // the reference's tests/pendulum-sarsa-tc.yaml
+  memset(c, 0, sizeof(*c));
+  c->struct_size = sizeof(grlx_config);
+  c->n_replicas = 1;
+  c->test_interval = 10;
+  c->env = GRLX_ENV_PENDULUM;
+  c->control_step = 0.03;
+  c->integration_steps = 5;
+  c->discrete_time = 1;
+  c->timeout = 2.99;
+  c->randomization = 0;
+  c->action_min = -3;
+  c->action_max = 3;
+  c->action_steps = 3;
+  c->agent = GRLX_AGENT_SARSA;
+  c->projector.tilings = 16;
+  c->projector.memory = 8388608;
+  c->projector.dims = 3;
+  c->projector.resolution[0] = 0.31415;
+  c->projector.resolution[1] = 3.1415;
+  c->projector.resolution[2] = 3;
+  c->projector.wrapping[0] = 6.283;
+  c->representation.init_min = 0;
+  c->representation.init_max = 1;
+  c->representation.output_min = -DBL_MAX;
+  c->representation.output_max = DBL_MAX;
+  c->representation.limit = 1;
+  c->epsilon = 0.05;
+  c->decay_rate = 1;
+  c->decay_min = 0;
+  c->alpha = 0.2;
+  c->gamma = 0.97;
+  c->lambda = 0.65;
+  c->trace = GRLX_TRACE_REPLACING;
+  c->ac_step_limit = -1;
+  c->table_log2_capacity = 0;
+  c->max_rows = 256;
+  c->tap_replica = -1;
+  c->tap_capacity = 0;
+}
+
+int grlx_env_dims(int env, int *state_dims, int *obs_dims)
+{
+  int S, D;
+  if (env_dims(env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "unknown environment %d", env);
+  if (state_dims) *state_dims = S;
+  if (obs_dims) *obs_dims = D;
+  return GRLX_OK;
+}
+
+int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
+{
+  if (!cfg || !seeds || !out) return fail(GRLX_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->n_replicas < 1) return fail(GRLX_ERR_INVALID, "n_replicas must be >= 1");
+  if (cfg->max_rows < 1) return fail(GRLX_ERR_INVALID, "max_rows must be >= 1");
+  DevParams P;
+  int rc = make_params(*cfg, &P);
+  if (rc != GRLX_OK) return rc;
+  if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
+
+  grlx_ctx *ctx = new grlx_ctx();
+  ctx->cfg = *cfg;
+  env_dims(cfg->env, &ctx->S, &ctx->D);
+  const int N = cfg->n_replicas;
+  uint32_t logC = cfg->table_log2_capacity ? (uint32_t)cfg->table_log2_capacity : 16u;
+  if (logC < 8 || logC > 26) { delete ctx; return fail(GRLX_ERR_INVALID, "table_log2_capacity must be in 8..26"); }
+  P.n_replicas = N;
+  P.logC = logC;
+  P.max_rows = cfg->max_rows;
+  P.tap_replica = cfg->tap_replica;
+  P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
+
+  const size_t n_tables = 1;
+  const size_t table_bytes = ((size_t)N * n_tables * sizeof(Entry)) << logC;
+#define CTX_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      int code__ = (e__ == hipErrorOutOfMemory) ? GRLX_ERR_OOM : GRLX_ERR_HIP;               \
+      fail(code__, "%s failed: %s", #expr, hipGetErrorString(e__));                          \
+      grlx_destroy(ctx);                                                                     \
+      return code__;                                                                         \
+    }                                                                                        \
+  } while (0)
+  CTX_TRY(hipMalloc((void **)&ctx->tables, table_bytes));
+  CTX_TRY(hipMemset(ctx->tables, 0, table_bytes));
+  CTX_TRY(hipMalloc((void **)&ctx->states, sizeof(ReplicaState) * (size_t)N));
+  CTX_TRY(hipMalloc((void **)&ctx->row_reward, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMalloc((void **)&ctx->row_steps, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMalloc((void **)&ctx->row_trial, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMemset(ctx->row_reward, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
+  CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));
+  CTX_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
+  if (P.tap_capacity > 0)
+  {
+    CTX_TRY(hipMalloc((void **)&ctx->taps, sizeof(grlx_tap) * (size_t)P.tap_capacity));
+    CTX_TRY(hipMemset(ctx->taps, 0, sizeof(grlx_tap) * (size_t)P.tap_capacity));
+  }
+
+  // Seed every replica exactly as `grld -s seed` instantiates the yaml
+  // (deployer.cpp:70-74; configurable.cpp:627-654 instantiate order):
+  //   srand48(seed) -> representation reset: thread-local Rand seeded by global lrand48 #1,
+  //   memory*outputs uniforms drawn -> learning sampler Rand (global #2) -> test sampler Rand (global #3).
+  std::vector<ReplicaState> hs((size_t)N);
+  const uint64_t table_draws = (uint64_t)cfg->projector.memory;        // outputs = 1
+  for (int r = 0; r < N; ++r)
+  {
+    ReplicaState &s = hs[(size_t)r];
+    memset(&s, 0, sizeof(s));
+    uint64_t G = h_seed((long)seeds[r]);
+    G = h_next(G);
+    s.TL0 = h_seed((long)(G >> 17));
+    s.TL = h_jump(s.TL0, table_draws);
+    G = h_next(G);
+    s.S1 = h_seed((long)(G >> 17));
+    G = h_next(G);
+    s.S2 = h_seed((long)(G >> 17));
+    s.G = G;
+    s.eps_decay = 1;
+    s.ac_decay = 1;
+  }
+  CTX_TRY(hipMemcpy(ctx->states, hs.data(), sizeof(ReplicaState) * (size_t)N, hipMemcpyHostToDevice));
+#undef CTX_TRY
+
+  P.tables = ctx->tables;
+  P.states = ctx->states;
+  P.row_reward = ctx->row_reward;
+  P.row_steps = ctx->row_steps;
+  P.row_trial = ctx->row_trial;
+  P.taps = ctx->taps;
+  P.tap_count = ctx->tap_count;
+  ctx->P = P;
+  *out = ctx;
+  return GRLX_OK;
+}
+
+int grlx_destroy(grlx_ctx *ctx)
+{
+  if (!ctx) return GRLX_OK;
+  (void)hipFree(ctx->tables);
+  (void)hipFree(ctx->states);
+  (void)hipFree(ctx->row_reward);
+  (void)hipFree(ctx->row_steps);
+  (void)hipFree(ctx->row_trial);
+  (void)hipFree(ctx->taps);
+  (void)hipFree(ctx->tap_count);
+  (void)hipFree(ctx->scratch);
+  delete ctx;
+  return GRLX_OK;
+}
+
+int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
+{
+  if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (n_trials == 0) return GRLX_OK;
+  HIP_TRY(launch_rollout(ctx->P, n_trials, (hipStream_t)stream));
+  ctx->trials_run += n_trials;
+  return GRLX_OK;
+}
+
+static int status_to_error(uint64_t st)
+{
+  if (st & ST_TABLE_FULL) return fail(GRLX_ERR_TABLE_FULL, "a replica's sparse weight table overflowed: raise table_log2_capacity");
+  if (st & ST_TRACE_OVERFLOW) return fail(GRLX_ERR_INVALID, "register trace overflow");
+  if (st & ST_DOMAIN) return fail(GRLX_ERR_DOMAIN, "sin/cos argument outside |x| < 2^20");
+  if (st & ST_ROWS_FULL) return fail(GRLX_ERR_ROWS_FULL, "more test rows than max_rows");
+  return GRLX_OK;
+}
+
+int grlx_sync(grlx_ctx *ctx, void *stream)
+{
+  if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
+  uint64_t h[3];
+  HIP_TRY(launch_step_counts(ctx->P, ctx->scratch, (hipStream_t)stream));
+  HIP_TRY(hipMemcpyAsync(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return status_to_error(h[2]);
+}
+
+int grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps)
+{
+  if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
+  uint64_t h[3];
+  HIP_TRY(launch_step_counts(ctx->P, ctx->scratch, nullptr));
+  HIP_TRY(hipMemcpy(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost));
+  if (learn_steps) *learn_steps = h[0];
+  if (test_steps) *test_steps = h[1];
+  return GRLX_OK;
+}
+
+int grlx_rows(grlx_ctx *ctx)
+{
+  if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
+  ReplicaState s;
+  if (hipMemcpy(&s, ctx->states, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) return fail(GRLX_ERR_HIP, "hipMemcpy failed");
+  return (int)s.rows;
+}
+
+int grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count, int64_t *trial, int64_t *steps, double *reward)
+{
+  if (!ctx || replica < 0 || replica >= ctx->P.n_replicas || first < 0 || count < 0 || first + count > ctx->P.max_rows)
+    return fail(GRLX_ERR_INVALID, "bad argument");
+  const size_t N = (size_t)ctx->P.n_replicas;
+  for (int i = 0; i < count; ++i)
+  {
+    size_t at = (size_t)(first + i) * N + (size_t)replica;
+    if (reward) HIP_TRY(hipMemcpy(&reward[i], ctx->row_reward + at, sizeof(double), hipMemcpyDeviceToHost));
+    if (steps) HIP_TRY(hipMemcpy(&steps[i], ctx->row_steps + at, sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (trial) HIP_TRY(hipMemcpy(&trial[i], ctx->row_trial + at, sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
+  return GRLX_OK;
+}
+
+int grlx_curve_stats(grlx_ctx *ctx, int first, int count, double *out_dev, void *stream)
+{
+  if (!ctx || !out_dev || first < 0 || count < 0 || first + count > ctx->P.max_rows) return fail(GRLX_ERR_INVALID, "bad argument");
+  HIP_TRY(launch_curve_stats(ctx->P, first, count, out_dev, (hipStream_t)stream));
+  return GRLX_OK;
+}
+
+int grlx_get_env_state(grlx_ctx *ctx, int replica, double *state)
+{
+  if (!ctx || !state || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  ReplicaState s;
+  HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
+  memcpy(state, s.x, sizeof(double) * GRLX_MAX_STATE);
+  return GRLX_OK;
+}
+
+int grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4])
+{
+  if (!ctx || !out || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  ReplicaState s;
+  HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
+  out[0] = s.G; out[1] = s.TL; out[2] = s.S1; out[3] = s.S2;
+  return GRLX_OK;
+}
+
+int grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used)
+{
+  if (!ctx || !n_slots_used || table != 0 || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  ReplicaState s;
+  HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
+  *n_slots_used = s.n_slots[table];
+  return GRLX_OK;
+}
+
+int grlx_read_taps(grlx_ctx *ctx, grlx_tap *out, int cap, int *n)
+{
+  if (!ctx || !out || !n) return fail(GRLX_ERR_INVALID, "bad argument");
+  uint32_t cnt = 0;
+  HIP_TRY(hipMemcpy(&cnt, ctx->tap_count, sizeof(cnt), hipMemcpyDeviceToHost));
+  int m = (int)cnt < cap ? (int)cnt : cap;
+  if (m > ctx->P.tap_capacity) m = ctx->P.tap_capacity;
+  if (m > 0) HIP_TRY(hipMemcpy(out, ctx->taps, sizeof(grlx_tap) * (size_t)m, hipMemcpyDeviceToHost));
+  *n = m;
+  return GRLX_OK;
+}
+
+int grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out)
+{
+  if (!ctx || !slots || !out || n < 0 || table != 0 || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (n == 0) return GRLX_OK;
+  DevBuf ds, dout;
+  HIP_TRY(ds.alloc(sizeof(uint32_t) * (size_t)n));
+  HIP_TRY(dout.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(hipMemcpy(ds.p, slots, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(launch_get_weights(ctx->P, table, replica, ds.as<uint32_t>(), n, dout.as<double>(), nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_project(const grlx_tile_spec *spec, const double *in, int n, uint32_t *out)
+{
+  if (!spec || !in || !out || n < 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  TileParams tp;
+  int rc = make_tile_params(*spec, &tp);
+  if (rc != GRLX_OK) return rc;
+  if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
+  if (n == 0) return GRLX_OK;
+  DevBuf din, dout;
+  HIP_TRY(din.alloc(sizeof(double) * (size_t)n * (size_t)tp.D));
+  HIP_TRY(dout.alloc(sizeof(uint32_t) * (size_t)n * (size_t)tp.T));
+  HIP_TRY(hipMemcpy(din.p, in, sizeof(double) * (size_t)n * (size_t)tp.D, hipMemcpyHostToDevice));
+  HIP_TRY(launch_project(tp, din.as<double>(), n, dout.as<uint32_t>(), nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(uint32_t) * (size_t)n * (size_t)tp.T, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_env_step(const grlx_config *cfg, double *state, const double *action, int n, double *obs, double *reward, int32_t *terminal)
+{
+  if (!cfg || !state || !action || !obs || !reward || !terminal || n < 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  DevParams P;
+  int rc = make_params(*cfg, &P);
+  if (rc != GRLX_OK) return rc;
+  if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
+  if (n == 0) return GRLX_OK;
+  int S, D;
+  env_dims(cfg->env, &S, &D);
+  DevBuf ds, da, dobs, dr, dt, derr;
+  HIP_TRY(ds.alloc(sizeof(double) * (size_t)n * S));
+  HIP_TRY(da.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(dobs.alloc(sizeof(double) * (size_t)n * D));
+  HIP_TRY(dr.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(dt.alloc(sizeof(int32_t) * (size_t)n));
+  HIP_TRY(derr.alloc(sizeof(uint32_t)));
+  HIP_TRY(hipMemset(derr.p, 0, sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(ds.p, state, sizeof(double) * (size_t)n * S, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(da.p, action, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(launch_env_step(P, ds.as<double>(), da.as<double>(), n, dobs.as<double>(), dr.as<double>(), dt.as<int32_t>(), derr.as<uint32_t>(), nullptr));
+  HIP_TRY(hipMemcpy(state, ds.p, sizeof(double) * (size_t)n * S, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(obs, dobs.p, sizeof(double) * (size_t)n * D, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(reward, dr.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(terminal, dt.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, derr.p, sizeof(err), hipMemcpyDeviceToHost));
+  if (err & ST_DOMAIN) return fail(GRLX_ERR_DOMAIN, "environment state left the supported domain (NaN)");
+  return GRLX_OK;
+}
+
+static int table_op(grlx_ctx *ctx, int table, int op, const int32_t *replica, const uint32_t *idx, int n,
+                    const double *arg, double alpha, double *out)
+{
+  if (!ctx || !replica || !idx || n < 0 || table != 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (n == 0) return GRLX_OK;
+  for (int i = 0; i < n; ++i)
+    if (replica[i] < 0 || replica[i] >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "replica index out of range");
+  const int T = ctx->P.tile.T;
+  for (size_t i = 0; i < (size_t)n * (size_t)T; ++i)
+    if (idx[i] != 0xFFFFFFFFu && idx[i] >= (uint32_t)ctx->P.tile.memory) return fail(GRLX_ERR_INVALID, "slot index out of range");
+  DevBuf dr, di, da, dout;
+  HIP_TRY(dr.alloc(sizeof(int32_t) * (size_t)n));
+  HIP_TRY(di.alloc(sizeof(uint32_t) * (size_t)n * T));
+  HIP_TRY(da.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(dout.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(hipMemcpy(dr.p, replica, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(di.p, idx, sizeof(uint32_t) * (size_t)n * T, hipMemcpyHostToDevice));
+  if (arg) HIP_TRY(hipMemcpy(da.p, arg, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(launch_table_op(ctx->P, table, op, dr.as<int32_t>(), di.as<uint32_t>(), n, da.as<double>(), alpha, dout.as<double>(), nullptr));
+  if (out) HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipDeviceSynchronize());
+  return GRLX_OK;
+}
+
+int grlx_read(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n, double *out)
+{
+  if (!out) return fail(GRLX_ERR_INVALID, "bad argument");
+  return table_op(ctx, table, 0, replica, idx, n, nullptr, 0, out);
+}
+
+int grlx_write(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n, const double *target, double alpha)
+{
+  if (!target) return fail(GRLX_ERR_INVALID, "bad argument");
+  return table_op(ctx, table, 1, replica, idx, n, target, alpha, nullptr);
+}
+
+int grlx_update(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n, const double *delta)
+{
+  if (!delta) return fail(GRLX_ERR_INVALID, "bad argument");
+  return table_op(ctx, table, 2, replica, idx, n, delta, 0, nullptr);
+}
+
+int grlx_math(int op, const double *x, const double *y, int n, double *out)
+{
+  if (!x || !out || n < 0 || op < 0 || op > 4 || (op == 3 && !y)) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
+  if (n == 0) return GRLX_OK;
+  DevBuf dx, dy, dout;
+  HIP_TRY(dx.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(dy.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(dout.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(hipMemcpy(dx.p, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  if (y) HIP_TRY(hipMemcpy(dy.p, y, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(launch_math(op, dx.as<double>(), dy.as<double>(), n, dout.as<double>(), nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_rand48_at(int64_t seed, const uint64_t *skip, int n, double *out)
+{
+  if (!skip || !out || n < 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
+  if (n == 0) return GRLX_OK;
+  DevBuf ds, dout;
+  HIP_TRY(ds.alloc(sizeof(uint64_t) * (size_t)n));
+  HIP_TRY(dout.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(hipMemcpy(ds.p, skip, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(launch_rand48_at(h_seed((long)seed), ds.as<uint64_t>(), n, dout.as<double>(), nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,96 @@
+// grlx_internal.h -- structures shared by the HIP kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grlx.h"
+
+namespace grlx {
+
+constexpr int kLanesPerReplica = 16;     // one lane per tiling
+constexpr int kReplicasPerWave = 4;
+constexpr int kMaxTrace = 10;            // replacing trace: (gamma*lambda)^n < 0.01 must hold for n <= 10
+constexpr int kMaxActions = GRLX_MAX_ACTIONS;
+constexpr uint32_t kInvalidPos = 0xFFFFFFFFu;
+constexpr int kMaxProbe = 2048;
+
+// status bits (sticky, per replica)
+enum : uint32_t { ST_TABLE_FULL = 1u, ST_DOMAIN = 2u, ST_ROWS_FULL = 4u, ST_TRACE_OVERFLOW = 8u };
+
+// One slot of a replica's sparse weight table.  The reference's table is a
+// dense double[memory] (linear.cpp:86) of which a run touches ~0.2 %; here a
+// slot exists only once touched and starts at the value the reference's dense
+// initialisation would have given it (lazy_weight()).
+struct __attribute__((aligned(16))) Entry {
+  uint32_t key;      // reference slot index + 1; 0 = empty
+  uint32_t aux;      // reserved (bit mask of tilings that touched the slot)
+  double   val;
+};
+
+// Persistent per-replica state between launches (one cloned experiment of
+// experiment/multi, multi.cpp:49-59).
+struct __attribute__((aligned(16))) ReplicaState {
+  double   x[GRLX_MAX_STATE];   // environment state (ModeledEnvironment::state_)
+  uint64_t G;                   // global srand48 stream              (deployer.cpp:70-74)
+  uint64_t TL;                  // thread-local RandGen stream        (utils.h:160-171)
+  uint64_t S1, S2;              // samplers' private Rand             (greedy.cpp:38-41)
+  uint64_t TL0;                 // TL state right after seeding: base of lazy weight init
+  double   eps_decay;           // EpsilonGreedySampler::decay_
+  double   ac_decay, ac_noise;  // ActionPolicy::decay_, n_
+  int64_t  tt, ss;              // trial counter, cumulative learning steps
+  uint64_t test_steps;
+  uint32_t n_slots[2];          // occupied table slots
+  uint32_t status;
+  uint32_t rows;                // test rows written
+};
+
+struct TileParams {
+  int32_t  T, D, memory;
+  double   scaling[GRLX_MAX_DIMS];
+  int32_t  wrap[GRLX_MAX_DIMS];
+};
+
+struct LinearParams {
+  double   init_min, init_range, out_min, out_max;
+  int32_t  limit;
+  uint64_t draws_before;        // TL draws consumed before this table's initialisation
+};
+
+struct DevParams {
+  int32_t  n_replicas, test_interval, env, agent, trace_kind;
+  int32_t  integration_steps;
+  double   h;                   // control_step / integration_steps (modeled.cpp:257)
+  double   timeout, randomization;
+  int32_t  A;
+  double   actions[kMaxActions];
+  TileParams   tile;
+  LinearParams lin;
+  double   epsilon, decay_rate, decay_min, alpha, gamma, gl;   // gl = gamma*lambda
+  // sparse tables: table t of replica r starts at tables + ((t*n_replicas + r) << logC)
+  Entry   *tables;
+  uint32_t logC;
+  ReplicaState *states;
+  // rows: [row][replica]
+  double  *row_reward;
+  int64_t *row_steps, *row_trial;
+  int32_t  max_rows;
+  // taps
+  grlx_tap *taps;
+  int32_t  tap_replica, tap_capacity;
+  uint32_t *tap_count;
+};
+
+// ---------------------------------------------------------------------------
+// launchers implemented in grlx_kernels.hip
+hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream);
+hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
+hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
+                           double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);
+hipError_t launch_table_op(const DevParams &P, int table, int op, const int32_t *replica_dev, const uint32_t *idx_dev, int n,
+                           const double *arg_dev, double alpha, double *out_dev, hipStream_t stream);
+hipError_t launch_get_weights(const DevParams &P, int table, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
+hipError_t launch_math(int op, const double *x, const double *y, int n, double *out, hipStream_t stream);
+hipError_t launch_rand48_at(uint64_t x0, const uint64_t *skip, int n, double *out, hipStream_t stream);
+hipError_t launch_curve_stats(const DevParams &P, int first, int count, double *out_dev, hipStream_t stream);
+hipError_t launch_step_counts(const DevParams &P, uint64_t *out_dev /*[3]: learn, test, status-or*/, hipStream_t stream);
+
+} // namespace grlx

@@ -1,0 +1,182 @@
+// grlx_math.h -- device transcendental functions with a bit-exact specification.
+//
+// The reference calls glibc's sin/cos/log from its dynamics and noise code
+// (base/src/environments/pendulum.cpp:62, cart_pole.cpp:64-65, acrobot.cpp,
+// base/include/grl/utils.h:120-125).  Those results are not specified bit-wise,
+// so this path defines its own routines out of IEEE-754 binary64 +,-,*,/, fma
+// and rint only; every operation below is a single correctly rounded
+// instruction on gfx950 (v_fma_f64, v_mul_f64, v_add_f64, v_rndne_f64).  The
+// translation unit MUST be compiled with -ffp-contract=off so that nothing but
+// the explicit __builtin_fma calls is fused.
+//
+// Specification (checked bit for bit against an independent CPU restatement in
+// tests/test_gpu_math.py):
+//   reduce(x): fn = rint(x*INVPIO2); r0 = fma(-fn,P1,x)  (exact for |x| < 2^20)
+//              p = fn*P2; pl = fma(fn,P2,-p); (r,e) = TwoSum(r0,-p)
+//              t = (e-pl) - fn*P3; rh = r+t; rl = (r-rh)+t; quadrant = fn mod 4
+//   ksin(r,rl): z=r*r; v=z*r; P = S2+z*(S3+..+z*S8) (fma Horner);
+//               c = fma(v, fma(z,P,S1), fma(-0.5*z, rl, rl)); r+c
+//   kcos(r,rl): z=r*r; hz=0.5*z; w=1-hz; tail=(1-w)-hz; Q = C1+z*(C2+..+z*C8);
+//               c = fma(z*z, Q, fma(-r, rl, tail)); w+c
+// Constants are Taylor coefficients 1/k! and a three-double split of pi/2, all
+// correctly rounded from exact rationals (tools/gen_math_constants.py).
+// Accuracy: <= 1 ulp from glibc on 3 % of arguments, identical elsewhere.
+// Domain: |x| < 2^20, NaN outside (callers raise GRLX_ERR_DOMAIN).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace grlx {
+
+#define GRLX_PIO2_1  0x1.921fb54442d18p+0
+#define GRLX_PIO2_2  0x1.1a62633145c07p-54
+#define GRLX_PIO2_3  -0x1.f1976b7ed8fbcp-110
+#define GRLX_INVPIO2 0x1.45f306dc9c883p-1
+#define GRLX_PI      0x1.921fb54442d18p+1
+#define GRLX_2PI     0x1.921fb54442d18p+2
+
+__device__ __forceinline__ int math_reduce(double x, double &rh, double &rl)
+{
+  double fn = __builtin_rint(x * GRLX_INVPIO2);
+  double r0 = __builtin_fma(-fn, GRLX_PIO2_1, x);
+  double p  = fn * GRLX_PIO2_2;
+  double pl = __builtin_fma(fn, GRLX_PIO2_2, -p);
+  double r  = r0 - p;
+  double bb = r - r0;
+  double e  = (r0 - (r - bb)) + (-p - bb);
+  double t  = (e - pl) - fn * GRLX_PIO2_3;
+  double h  = r + t;
+  rh = h;
+  rl = (r - h) + t;
+  return (int)((long long)fn & 3);
+}
+
+__device__ __forceinline__ double math_ksin(double r, double rl)
+{
+  double z = r * r, v = z * r;
+  double P = __builtin_fma(z, 0x1.952c77030ad4ap-49, -0x1.ae7f3e733b81fp-41);
+  P = __builtin_fma(z, P, 0x1.6124613a86d09p-33);
+  P = __builtin_fma(z, P, -0x1.ae64567f544e4p-26);
+  P = __builtin_fma(z, P, 0x1.71de3a556c734p-19);
+  P = __builtin_fma(z, P, -0x1.a01a01a01a01ap-13);
+  P = __builtin_fma(z, P, 0x1.1111111111111p-7);
+  double c = __builtin_fma(v, __builtin_fma(z, P, -0x1.5555555555555p-3), __builtin_fma(-0.5 * z, rl, rl));
+  return r + c;
+}
+
+__device__ __forceinline__ double math_kcos(double r, double rl)
+{
+  double z = r * r, hz = 0.5 * z;
+  double w = 1.0 - hz;
+  double tail = (1.0 - w) - hz;
+  double Q = __builtin_fma(z, -0x1.6827863b97d97p-53, 0x1.ae7f3e733b81fp-45);
+  Q = __builtin_fma(z, Q, -0x1.93974a8c07c9dp-37);
+  Q = __builtin_fma(z, Q, 0x1.1eed8eff8d898p-29);
+  Q = __builtin_fma(z, Q, -0x1.27e4fb7789f5cp-22);
+  Q = __builtin_fma(z, Q, 0x1.a01a01a01a01ap-16);
+  Q = __builtin_fma(z, Q, -0x1.6c16c16c16c17p-10);
+  Q = __builtin_fma(z, Q, 0x1.5555555555555p-5);
+  double c = __builtin_fma(z * z, Q, __builtin_fma(-r, rl, tail));
+  return w + c;
+}
+
+__device__ __forceinline__ double psin(double x)
+{
+  double ax = __builtin_fabs(x), rh, rl;
+  if (!(ax < 0x1p20)) return __builtin_nan("");
+  if (ax < 0x1p-27) return x;
+  int q = math_reduce(x, rh, rl);
+  double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
+  double v = (q & 1) ? c : s;
+  return (q & 2) ? -v : v;
+}
+
+__device__ __forceinline__ double pcos(double x)
+{
+  double ax = __builtin_fabs(x), rh, rl;
+  if (!(ax < 0x1p20)) return __builtin_nan("");
+  if (ax < 0x1p-27) return 1.0;
+  int q = math_reduce(x, rh, rl);
+  double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
+  double v = (q & 1) ? -s : c;
+  return ((q + 1) & 2) ? -v : v;
+}
+
+// sin and cos of the same argument share the reduction
+__device__ __forceinline__ void psincos(double x, double &sn, double &cs)
+{
+  double ax = __builtin_fabs(x), rh, rl;
+  if (!(ax < 0x1p20)) { sn = cs = __builtin_nan(""); return; }
+  if (ax < 0x1p-27) { sn = x; cs = 1.0; return; }
+  int q = math_reduce(x, rh, rl);
+  double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
+  double vs = (q & 1) ? c : s;
+  sn = (q & 2) ? -vs : vs;
+  double vc = (q & 1) ? -s : c;
+  cs = ((q + 1) & 2) ? -vc : vc;
+}
+
+// plog(x): x = m*2^k, m in [sqrt2/2, sqrt2); f = m-1; d = f+2; s = f/d;
+// sl = (fma(-s,d,f) - s*(2-(d-f)))/d; z = s*s; R = L1+z*(L2+..+z*L11);
+// lo = fma(k, LN2_LO, fma(s*z, R, 2*sl)); result fma(k, LN2_HI, 2*s+lo).
+__device__ __forceinline__ double plog(double x)
+{
+  if (x != x || x < 0.0) return __builtin_nan("");
+  if (x == 0.0) return -__builtin_inf();
+  if (x == __builtin_inf()) return x;
+  unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  int k = 0;
+  if ((b >> 52) == 0)
+  {
+    x *= 0x1p54;
+    b = (unsigned long long)__double_as_longlong(x);
+    k = -54;
+  }
+  k += (int)(b >> 52) - 1023;
+  b = (b & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+  double m = __longlong_as_double((long long)b);
+  if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; k += 1; }
+  double f = m - 1.0;
+  double d = f + 2.0;
+  double dl = 2.0 - (d - f);
+  double s = f / d;
+  double sl = (__builtin_fma(-s, d, f) - s * dl) / d;
+  double z = s * s;
+  double R = __builtin_fma(z, 0x1.642c8590b2164p-4, 0x1.8618618618618p-4);
+  R = __builtin_fma(z, R, 0x1.af286bca1af28p-4);
+  R = __builtin_fma(z, R, 0x1.e1e1e1e1e1e1ep-4);
+  R = __builtin_fma(z, R, 0x1.1111111111111p-3);
+  R = __builtin_fma(z, R, 0x1.3b13b13b13b14p-3);
+  R = __builtin_fma(z, R, 0x1.745d1745d1746p-3);
+  R = __builtin_fma(z, R, 0x1.c71c71c71c71cp-3);
+  R = __builtin_fma(z, R, 0x1.2492492492492p-2);
+  R = __builtin_fma(z, R, 0x1.999999999999ap-2);
+  R = __builtin_fma(z, R, 0x1.5555555555555p-1);
+  double dk = (double)k;
+  double lo = __builtin_fma(dk, 0x1.fdf473de6af28p-22, __builtin_fma(s * z, R, 2.0 * sl));
+  return __builtin_fma(dk, 0x1.62e4200000000p-1, 2.0 * s + lo);
+}
+
+// fmod(x, y) for finite x, y > 0: exact by definition (IEEE remainder toward
+// zero); long division by exactly representable multiples of y.  Each
+// subtraction is exact (Sterbenz), so the result equals libm's fmod bit for bit.
+__device__ __forceinline__ double pfmod(double x, double y)
+{
+  double ax = __builtin_fabs(x);
+  if (!(ax < __builtin_inf()) || !(y > 0.0)) return __builtin_nan("");
+  if (ax < y) return x;
+  int ex = (int)(((unsigned long long)__double_as_longlong(ax) >> 52) & 0x7FF);
+  int ey = (int)(((unsigned long long)__double_as_longlong(y) >> 52) & 0x7FF);
+  if (ey == 0 || ex - ey > 1000)
+    return fmod(x, y);                               // subnormal divisor / huge ratio: library path
+  // t = y * 2^(ex-ey): same exponent as ax
+  double t = __longlong_as_double(__double_as_longlong(y) + ((long long)(ex - ey) << 52));
+  for (int i = ex - ey; i >= 0; --i)
+  {
+    if (ax >= t) ax -= t;
+    t *= 0.5;
+  }
+  return __builtin_copysign(ax, x);
+}
+
+} // namespace grlx

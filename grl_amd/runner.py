@@ -1,0 +1,184 @@
+"""Thin Python host over the C ABI: one `Runner` = one grlx context = the
+replicas of one GPU.  All computation happens in the HIP kernels behind
+include/grlx.h; this file only marshals arguments."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import capi
+
+
+def pendulum_sarsa_config(n_replicas=1, **overrides) -> capi.Config:
+    """Config of the reference's tests/pendulum-sarsa-tc.yaml (cfg/pendulum/sarsa_tc.yaml semantics)."""
+    lib = capi.load()
+    cfg = capi.Config()
+    lib.grlx_config_pendulum_sarsa(C.byref(cfg))
+    cfg.n_replicas = n_replicas
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class Runner:
+    """N independent-seed replicas of one experiment graph on the current GPU
+    (the reference's experiment/multi clones, base/src/experiments/multi.cpp:44-75)."""
+
+    def __init__(self, cfg: capi.Config, seeds):
+        self.lib = capi.load()
+        self.cfg = cfg
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        if seeds.shape != (cfg.n_replicas,):
+            raise ValueError("need one seed per replica")
+        self.seeds = seeds
+        self._ctx = C.c_void_p()
+        capi.check(self.lib.grlx_create(C.byref(cfg), _ptr(seeds, C.c_int64), C.byref(self._ctx)))
+        sd, od = C.c_int(), C.c_int()
+        capi.check(self.lib.grlx_env_dims(cfg.env, C.byref(sd), C.byref(od)))
+        self.state_dims, self.obs_dims = sd.value, od.value
+
+    def close(self):
+        if self._ctx:
+            self.lib.grlx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # OnlineLearningExperiment::run for n_trials further trials (async on `stream`)
+    def run(self, n_trials: int, stream: int = 0):
+        capi.check(self.lib.grlx_run(self._ctx, int(n_trials), C.c_void_p(stream)))
+
+    def sync(self, stream: int = 0):
+        capi.check(self.lib.grlx_sync(self._ctx, C.c_void_p(stream)))
+
+    def n_rows(self) -> int:
+        return capi.check(self.lib.grlx_rows(self._ctx))
+
+    def rows(self, replica: int, first: int = 0, count: int = None):
+        if count is None:
+            count = self.n_rows() - first
+        trial = np.zeros(count, np.int64)
+        steps = np.zeros(count, np.int64)
+        reward = np.zeros(count, np.float64)
+        capi.check(self.lib.grlx_read_rows(self._ctx, replica, first, count, _ptr(trial, C.c_int64),
+                                           _ptr(steps, C.c_int64), _ptr(reward, C.c_double)))
+        return trial, steps, reward
+
+    def curve_stats(self, out_dev_ptr: int, first: int, count: int, stream: int = 0):
+        capi.check(self.lib.grlx_curve_stats(self._ctx, first, count, C.c_void_p(out_dev_ptr), C.c_void_p(stream)))
+
+    def step_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        capi.check(self.lib.grlx_step_counts(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def env_state(self, replica: int):
+        st = np.zeros(capi.MAX_STATE, np.float64)
+        capi.check(self.lib.grlx_get_env_state(self._ctx, replica, _ptr(st, C.c_double)))
+        return st[: self.state_dims]
+
+    def rng(self, replica: int):
+        out = np.zeros(4, np.uint64)
+        capi.check(self.lib.grlx_get_rng(self._ctx, replica, _ptr(out, C.c_uint64)))
+        return out
+
+    def weights(self, replica: int, slots, table: int = 0):
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.zeros(slots.size, np.float64)
+        capi.check(self.lib.grlx_get_weights(self._ctx, table, replica, _ptr(slots, C.c_uint32), slots.size, _ptr(out, C.c_double)))
+        return out
+
+    def table_load(self, replica: int, table: int = 0) -> int:
+        n = C.c_uint32()
+        capi.check(self.lib.grlx_table_load(self._ctx, table, replica, C.byref(n)))
+        return n.value
+
+    def taps(self):
+        cap = max(int(self.cfg.tap_capacity), 1)
+        buf = (capi.Tap * cap)()
+        n = C.c_int()
+        capi.check(self.lib.grlx_read_taps(self._ctx, buf, cap, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    # Representation::read / write / update (batched rows, applied in order)
+    def read(self, replica, idx, table: int = 0):
+        replica = np.ascontiguousarray(replica, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = np.zeros(replica.size, np.float64)
+        capi.check(self.lib.grlx_read(self._ctx, table, _ptr(replica, C.c_int32), _ptr(idx, C.c_uint32), replica.size, _ptr(out, C.c_double)))
+        return out
+
+    def write(self, replica, idx, target, alpha: float, table: int = 0):
+        replica = np.ascontiguousarray(replica, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        target = np.ascontiguousarray(target, dtype=np.float64)
+        capi.check(self.lib.grlx_write(self._ctx, table, _ptr(replica, C.c_int32), _ptr(idx, C.c_uint32), replica.size, _ptr(target, C.c_double), float(alpha)))
+
+    def update(self, replica, idx, delta, table: int = 0):
+        replica = np.ascontiguousarray(replica, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        delta = np.ascontiguousarray(delta, dtype=np.float64)
+        capi.check(self.lib.grlx_update(self._ctx, table, _ptr(replica, C.c_int32), _ptr(idx, C.c_uint32), replica.size, _ptr(delta, C.c_double)))
+
+
+# ---- stateless batched operators --------------------------------------------
+def project(spec: capi.TileSpec, x):
+    """Projector::project (TileCodingProjector::_project) for a batch of inputs."""
+    lib = capi.load()
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, spec.dims)
+    out = np.zeros((x.shape[0], spec.tilings), np.uint32)
+    capi.check(lib.grlx_project(C.byref(spec), _ptr(x, C.c_double), x.shape[0], _ptr(out, C.c_uint32)))
+    return out
+
+
+def env_step(cfg: capi.Config, state, action):
+    """Environment::step (ModeledEnvironment::step) for a batch of (state, action)."""
+    lib = capi.load()
+    sd, od = C.c_int(), C.c_int()
+    capi.check(lib.grlx_env_dims(cfg.env, C.byref(sd), C.byref(od)))
+    state = np.array(state, dtype=np.float64).reshape(-1, sd.value)
+    action = np.ascontiguousarray(action, dtype=np.float64).reshape(-1)
+    n = state.shape[0]
+    obs = np.zeros((n, od.value), np.float64)
+    reward = np.zeros(n, np.float64)
+    terminal = np.zeros(n, np.int32)
+    capi.check(lib.grlx_env_step(C.byref(cfg), _ptr(state, C.c_double), _ptr(action, C.c_double), n,
+                                 _ptr(obs, C.c_double), _ptr(reward, C.c_double), _ptr(terminal, C.c_int32)))
+    return state, obs, reward, terminal
+
+
+MATH_SIN, MATH_COS, MATH_LOG, MATH_FMOD, MATH_SQRT = 0, 1, 2, 3, 4
+
+
+def device_math(op: int, x, y=None):
+    lib = capi.load()
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    out = np.zeros_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        yp = _ptr(y, C.c_double)
+    capi.check(lib.grlx_math(op, _ptr(x, C.c_double), yp, x.size, _ptr(out, C.c_double)))
+    return out
+
+
+def rand48_at(seed: int, skip):
+    lib = capi.load()
+    skip = np.ascontiguousarray(skip, dtype=np.uint64).reshape(-1)
+    out = np.zeros(skip.size, np.float64)
+    capi.check(lib.grlx_rand48_at(int(seed), _ptr(skip, C.c_uint64), skip.size, _ptr(out, C.c_double)))
+    return out
+
+
+def format_row(trial: int, steps: int, reward: float) -> str:
+    """One row in the layout of the reference's golden files (three setw(15)
+    columns, default ostream precision; tests/template/pendulum-sarsa-tc-0.txt)."""
+    return "%15d%15d%15s\n" % (trial, steps, "%g" % reward) if not math.isnan(reward) else "%15d%15d%15s\n" % (trial, steps, "nan")

@@ -1,0 +1,195 @@
+/* grlx.h -- C ABI of the MI355X-native runner for grl's online-learning hot path.
+ *
+ * This is the drop-in boundary: plain C, POD structs, caller-allocated buffers,
+ * `int` status returns (0 = GRLX_OK, negative = error; grlx_last_error() has the
+ * text), no exceptions, no torch/Eigen types.  One context owns the replicas of
+ * one GPU; a context is not thread-safe.  Every entry point names the reference
+ * interface it replaces (paths relative to the wcaarls/grl checkout); the
+ * reference-side binding a grl maintainer would add is shown in INTEGRATION.md.
+ *
+ * There is NO CPU fallback: every compute entry point runs HIP kernels on the
+ * current device and returns GRLX_ERR_NO_DEVICE when there is none.
+ */
+#ifndef GRLX_H_
+#define GRLX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRLX_ABI_VERSION 1
+
+enum {
+  GRLX_OK = 0,
+  GRLX_ERR_INVALID = -1,       /* bad argument / unsupported configuration (grl: bad_param)   */
+  GRLX_ERR_NO_DEVICE = -2,     /* no HIP device: the product never computes on the CPU        */
+  GRLX_ERR_HIP = -3,           /* HIP runtime error                                           */
+  GRLX_ERR_TABLE_FULL = -4,    /* a replica's sparse weight table overflowed (raise capacity) */
+  GRLX_ERR_DOMAIN = -5,        /* portable sin/cos argument outside |x| < 2^20                */
+  GRLX_ERR_ROWS_FULL = -6,     /* more test rows than reserved at create                      */
+  GRLX_ERR_OOM = -7
+};
+
+/* YAML type strings of the reference these enumerators stand for */
+enum { GRLX_ENV_PENDULUM = 0,        /* dynamics/pendulum + task/pendulum/swingup   (pendulum.cpp)       */
+       GRLX_ENV_CART_POLE = 1,       /* dynamics/cart_pole + task/cart_pole/swingup (cart_pole.cpp)      */
+       GRLX_ENV_ACROBOT = 2,         /* dynamics/acrobot + task/acrobot/balancing   (acrobot.cpp)        */
+       GRLX_ENV_COMPASS_WALKER = 3   /* sandbox/compass_walker (walk task)          (compass_walker.cpp) */ };
+enum { GRLX_AGENT_SARSA = 0,         /* agent/td + policy/discrete/q + predictor/critic/sarsa (sarsa.cpp)     */
+       GRLX_AGENT_Q = 1,             /* ... + predictor/critic/q (advantage.cpp:71-110)                       */
+       GRLX_AGENT_AC = 2             /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */ };
+enum { GRLX_TRACE_NONE = 0, GRLX_TRACE_REPLACING = 1, GRLX_TRACE_ACCUMULATING = 2 };   /* trace.h:208-263 */
+
+#define GRLX_MAX_DIMS 8
+#define GRLX_MAX_STATE 12
+#define GRLX_MAX_ACTIONS 8
+
+/* projector/tile_coding (tile_coding.cpp:34-80): tilings, memory, resolution, wrapping; safe = 0 */
+typedef struct {
+  int32_t tilings;
+  int32_t memory;
+  int32_t dims;
+  int32_t reserved;
+  double  resolution[GRLX_MAX_DIMS];
+  double  wrapping[GRLX_MAX_DIMS];
+} grlx_tile_spec;
+
+/* representation/parameterized/linear (linear.cpp:34-101) */
+typedef struct {
+  double  init_min, init_max;
+  double  output_min, output_max;     /* +-DBL_MAX for the yaml's empty vectors */
+  int32_t limit;                      /* default 1 (linear.h:46-49)             */
+  int32_t reserved;
+} grlx_linear_spec;
+
+/* One fused experiment graph:
+ *   experiment/online_learning { environment/modeled { model/dynamical, task },
+ *                                agent/td { policy, predictor }, test_agent agent/fixed }
+ * Field names follow the reference's YAML parameter names. */
+typedef struct {
+  uint32_t struct_size;               /* = sizeof(grlx_config), ABI check                       */
+  int32_t  n_replicas;                /* independent-seed replicas on this GPU (experiment/multi analogue, multi.cpp:44-75) */
+  int32_t  test_interval;             /* experiment: -1 = none                                  */
+  int32_t  env;                       /* GRLX_ENV_*                                             */
+  double   control_step;              /* model/dynamical                                        */
+  int32_t  integration_steps;
+  int32_t  discrete_time;             /* environment/modeled: must be 1                         */
+  double   timeout;                   /* task                                                   */
+  double   randomization;
+  double   action_min, action_max;    /* discretizer/uniform over task action range             */
+  int32_t  action_steps;
+  int32_t  agent;                     /* GRLX_AGENT_*                                           */
+  grlx_tile_spec   projector;
+  grlx_linear_spec representation;
+  double   epsilon, decay_rate, decay_min;    /* sampler/epsilon_greedy                         */
+  double   alpha, gamma, lambda;              /* predictor                                      */
+  int32_t  trace;                             /* GRLX_TRACE_*                                   */
+  int32_t  reserved0;
+  /* actor-critic only */
+  grlx_tile_spec   actor_projector;
+  grlx_linear_spec actor_representation;
+  double   actor_alpha, sigma, theta, ac_decay_rate, ac_decay_min, ac_step_limit;
+  int32_t  ac_update_method;
+  /* GPU-side sizing (no reference counterpart) */
+  int32_t  table_log2_capacity;       /* sparse table slots per replica = 2^this; 0 = default   */
+  int32_t  max_rows;                  /* test rows reserved per replica                          */
+  int32_t  tap_replica;               /* -1: off; else record per-step taps of that replica      */
+  int32_t  tap_capacity;
+  int32_t  reserved1;
+} grlx_config;
+
+typedef struct grlx_ctx grlx_ctx;
+
+/* per-step record of the tapped replica (debug / parity tests) */
+typedef struct {
+  int32_t  test, action_index, terminal, trace_len;
+  double   obs[GRLX_MAX_DIMS];
+  double   action, reward, delta;
+  double   q[GRLX_MAX_ACTIONS];
+  uint32_t p_idx[32];
+} grlx_tap;
+
+const char *grlx_last_error(void);
+int  grlx_abi_version(void);
+int  grlx_device_count(void);
+
+/* Fill *cfg with the values of the reference's tests/pendulum-sarsa-tc.yaml. */
+void grlx_config_pendulum_sarsa(grlx_config *cfg);
+
+/* Replaces: Configurator::instantiate of the experiment subtree (configurable.cpp:603-715)
+ * for n_replicas deep clones (multi.cpp:49-59) after `srand48(seeds[r])`
+ * (deployer.cpp:70-74).  RNG streams are consumed exactly in the reference's
+ * YAML instantiate order; the 8,388,608-draw weight
+ * initialisation (linear.cpp:110-121) is performed lazily per touched slot by
+ * LCG jump-ahead and is bit-identical. */
+int  grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out);
+int  grlx_destroy(grlx_ctx *ctx);
+
+/* Replaces: OnlineLearningExperiment::run (online_learning.cpp:110-315) for every
+ * replica: advance each by n_trials trials (learning and test trials both
+ * count).  Asynchronous on `stream` (a hipStream_t passed as void*; NULL = default). */
+int  grlx_run(grlx_ctx *ctx, int n_trials, void *stream);
+/* Wait for the stream, then report sticky per-replica error flags (table full, ...). */
+int  grlx_sync(grlx_ctx *ctx, void *stream);
+
+/* Test rows written so far (same for every replica). */
+int  grlx_rows(grlx_ctx *ctx);
+/* Replaces the per-replica `<output>-<run>@<i>.txt` rows (online_learning.cpp:238-262):
+ * copy rows [first, first+count) of `replica` to host arrays (columns 1-3). */
+int  grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count,
+                    int64_t *trial, int64_t *steps, double *reward);
+/* Device-side learning-curve statistics over this GPU's replicas, written to a
+ * DEVICE buffer out[count][3] = {sum reward, sum reward^2, replica count};
+ * fixed reduction order (bitwise reproducible).  Input of the one RCCL
+ * all-reduce of the multi-GPU path. */
+int  grlx_curve_stats(grlx_ctx *ctx, int first, int count, double *out_dev, void *stream);
+
+/* counters: total env steps executed by all replicas since create */
+int  grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps);
+
+/* --- state inspection (parity tests) ------------------------------------ */
+int  grlx_get_env_state(grlx_ctx *ctx, int replica, double *state /*[GRLX_MAX_STATE]*/);
+int  grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4] /* G, TL, S1, S2 */);
+/* Replaces reading LinearRepresentation::params_ (linear.cpp; .dat dump
+ * representation.h:201-263): current weights of the given reference slots. */
+int  grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out);
+int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used);
+int  grlx_read_taps(grlx_ctx *ctx, grlx_tap *out, int cap, int *n);
+
+/* --- fine-grained batched operators (host pointers; each call copies in, runs a
+ *     HIP kernel, copies out).  They mirror the plug-in interfaces one to one. */
+
+/* Projector::project -> TileCodingProjector::_project (tile_coding.cpp:103-149):
+ * in[n][dims] -> out[n][tilings] reference slot indices. */
+int  grlx_project(const grlx_tile_spec *spec, const double *in, int n, uint32_t *out);
+
+/* Environment::step -> ModeledEnvironment::step (modeled.cpp:160-213):
+ * state[n][S] updated in place; obs[n][D], reward[n], terminal[n]. */
+int  grlx_env_step(const grlx_config *cfg, double *state, const double *action, int n,
+                   double *obs, double *reward, int32_t *terminal);
+int  grlx_env_dims(int env, int *state_dims, int *obs_dims);
+
+/* Representation::read / write / update on a context's table
+ * (linear.cpp:136-184, 186-196, 198-216): idx[n][tilings] reference slots,
+ * replica[n] selects the table instance.  Rows are applied in order. */
+int  grlx_read(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n, double *out);
+int  grlx_write(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n,
+                const double *target, double alpha);
+int  grlx_update(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n,
+                 const double *delta);
+
+/* device math used by the environments (bit-identical to the documented
+ * portable specification): op 0 sin, 1 cos, 2 log, 3 fmod(x, y[i]), 4 sqrt */
+int  grlx_math(int op, const double *x, const double *y, int n, double *out);
+
+/* Rand / RandGen streams (utils.h:84-137) evaluated on the device:
+ * out[n] = drand48 of the stream seeded by srand48(seed) after `skip[i]` draws. */
+int  grlx_rand48_at(int64_t seed, const uint64_t *skip, int n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRLX_H_ */

@@ -1,0 +1,193 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never by the product (grl_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+MAX_DIMS, MAX_STATE = 8, 12
+MATH_LIBM, MATH_PORTABLE = 0, 1
+ENV_PENDULUM = 0
+AGENT_SARSA, AGENT_Q, AGENT_AC = 0, 1, 2
+TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
+
+
+class TileSpec(C.Structure):
+    _fields_ = [("tilings", C.c_int), ("memory", C.c_int), ("dims", C.c_int),
+                ("resolution", C.c_double * MAX_DIMS), ("wrapping", C.c_double * MAX_DIMS)]
+
+
+class LinearSpec(C.Structure):
+    _fields_ = [("init_min", C.c_double), ("init_max", C.c_double), ("output_min", C.c_double),
+                ("output_max", C.c_double), ("limit", C.c_int)]
+
+
+class Spec(C.Structure):
+    _fields_ = [("test_interval", C.c_int), ("env", C.c_int), ("control_step", C.c_double),
+                ("integration_steps", C.c_int), ("timeout", C.c_double), ("randomization", C.c_double),
+                ("action_min", C.c_double), ("action_max", C.c_double), ("action_steps", C.c_int),
+                ("agent", C.c_int), ("projector", TileSpec), ("representation", LinearSpec),
+                ("epsilon", C.c_double), ("decay_rate", C.c_double), ("decay_min", C.c_double),
+                ("alpha", C.c_double), ("gamma", C.c_double), ("lambda_", C.c_double), ("trace", C.c_int),
+                ("actor_projector", TileSpec), ("actor_representation", LinearSpec),
+                ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
+                ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double),
+                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int)]
+
+
+class Row(C.Structure):
+    _fields_ = [("trial", C.c_int64), ("steps", C.c_int64), ("reward", C.c_double)]
+
+
+class Tap(C.Structure):
+    _fields_ = [("test", C.c_int32), ("action_index", C.c_int32), ("obs", C.c_double * MAX_DIMS),
+                ("action", C.c_double), ("reward", C.c_double), ("terminal", C.c_int32), ("trace_len", C.c_int32),
+                ("q", C.c_double * 8), ("delta", C.c_double), ("p_idx", C.c_uint32 * 32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("learn_steps", C.c_uint64), ("test_steps", C.c_uint64), ("weight_reads", C.c_uint64),
+                ("weight_rmws", C.c_uint64), ("trace_entries_sum", C.c_uint64), ("explorations", C.c_uint64),
+                ("ties", C.c_uint64)]
+
+
+class Rand48(C.Structure):
+    _fields_ = [("x", C.c_uint64)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    return LIB
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB)
+    P = C.POINTER
+    L.orc_srand48.argtypes = [P(Rand48), C.c_long]
+    L.orc_drand48.argtypes = [P(Rand48)]; L.orc_drand48.restype = C.c_double
+    L.orc_lrand48.argtypes = [P(Rand48)]; L.orc_lrand48.restype = C.c_uint32
+    L.orc_rand48_jump.argtypes = [P(Rand48), C.c_uint64]
+    for f in ("orc_psin", "orc_pcos", "orc_plog"):
+        getattr(L, f).argtypes = [C.c_double]; getattr(L, f).restype = C.c_double
+    L.orc_spec_pendulum_sarsa.argtypes = [P(Spec)]
+    L.orc_tile_project.argtypes = [P(TileSpec), P(C.c_double), P(C.c_uint32)]; L.orc_tile_project.restype = C.c_int
+    L.orc_env_step.argtypes = [P(Spec), P(C.c_double), C.c_double, P(C.c_double), P(C.c_double), P(C.c_int)]
+    L.orc_env_step.restype = C.c_double
+    L.orc_env_state_dims.argtypes = [C.c_int]; L.orc_env_obs_dims.argtypes = [C.c_int]
+    L.orc_create.argtypes = [P(Spec), C.c_long]; L.orc_create.restype = C.c_void_p
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_run.argtypes = [C.c_void_p, C.c_int, P(Row), C.c_int, P(Tap), C.c_int, P(C.c_int)]; L.orc_run.restype = C.c_int
+    L.orc_get_stats.argtypes = [C.c_void_p, P(Stats)]
+    L.orc_weights.argtypes = [C.c_void_p, C.c_int]; L.orc_weights.restype = P(C.c_double)
+    L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
+    L.orc_rng_states.argtypes = [C.c_void_p, P(C.c_uint64)]
+    L.orc_format_row.argtypes = [P(Row), C.c_char_p, C.c_size_t]; L.orc_format_row.restype = C.c_int
+    L.orc_lazy_weight.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double]
+    L.orc_lazy_weight.restype = C.c_double
+    _lib = L
+    return L
+
+
+def pendulum_sarsa_spec(math=MATH_PORTABLE, **over) -> Spec:
+    s = Spec()
+    load().orc_spec_pendulum_sarsa(C.byref(s))
+    s.math = math
+    for k, v in over.items():
+        setattr(s, k, v)
+    return s
+
+
+class Experiment:
+    """One scalar experiment instance of the oracle."""
+
+    def __init__(self, spec: Spec, seed: int):
+        self.L = load()
+        self.spec = spec
+        self.h = self.L.orc_create(C.byref(spec), seed)
+        if not self.h:
+            raise RuntimeError("orc_create failed (unsupported spec)")
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, n_trials, tap_cap=0):
+        rows = (Row * (n_trials + 1))()
+        taps = (Tap * max(tap_cap, 1))()
+        ntap = C.c_int(0)
+        n = self.L.orc_run(self.h, n_trials, rows, n_trials + 1, taps if tap_cap else None, tap_cap, C.byref(ntap))
+        return [rows[i] for i in range(n)], [taps[i] for i in range(ntap.value)]
+
+    def format_rows(self, rows) -> str:
+        buf = C.create_string_buffer(128)
+        out = []
+        for r in rows:
+            self.L.orc_format_row(C.byref(r), buf, 128)
+            out.append(buf.value.decode())
+        return "".join(out)
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self.L.orc_get_stats(self.h, C.byref(s))
+        return s
+
+    def weights(self, slots, table=0):
+        p = self.L.orc_weights(self.h, table)
+        return np.array([p[int(i)] for i in slots], dtype=np.float64)
+
+    def state(self):
+        st = (C.c_double * MAX_STATE)()
+        self.L.orc_get_state(self.h, st)
+        return np.array(st[: self.L.orc_env_state_dims(self.spec.env)])
+
+    def rng(self):
+        out = (C.c_uint64 * 4)()
+        self.L.orc_rng_states(self.h, out)
+        return np.array(out[:], dtype=np.uint64)
+
+
+def tile_project(ts: TileSpec, x):
+    L = load()
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, ts.dims)
+    out = np.zeros((x.shape[0], ts.tilings), np.uint32)
+    tmp = (C.c_uint32 * ts.tilings)()
+    for i in range(x.shape[0]):
+        row = (C.c_double * ts.dims)(*x[i])
+        if L.orc_tile_project(C.byref(ts), row, tmp) != 0:
+            raise ValueError("invalid tile spec")
+        out[i] = tmp[:]
+    return out
+
+
+def env_step(spec: Spec, state, action):
+    L = load()
+    S, D = L.orc_env_state_dims(spec.env), L.orc_env_obs_dims(spec.env)
+    state = np.array(state, dtype=np.float64).reshape(-1, S)
+    action = np.asarray(action, dtype=np.float64).reshape(-1)
+    n = state.shape[0]
+    obs = np.zeros((n, D)); reward = np.zeros(n); term = np.zeros(n, np.int32)
+    for i in range(n):
+        st = (C.c_double * S)(*state[i]); ob = (C.c_double * D)()
+        rw = C.c_double(); tm = C.c_int()
+        L.orc_env_step(C.byref(spec), st, float(action[i]), ob, C.byref(rw), C.byref(tm))
+        state[i] = st[:]; obs[i] = ob[:]; reward[i] = rw.value; term[i] = tm.value
+    return state, obs, reward, term

@@ -1,0 +1,61 @@
+"""The C-ABI library builds, loads and exports every symbol include/grlx.h declares
+(no compute calls: this runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "grlx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(grlx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_exports_every_declared_symbol(grlx):
+    lib = C.CDLL(grlx.capi.lib_path())
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/grlx.h but not exported"
+    # and the Python binding covers them all
+    assert set(names) == set(grlx.capi._SIGS.keys())
+
+
+def test_struct_layout_matches_header(grlx):
+    cfg = grlx.pendulum_sarsa_config(3)
+    assert cfg.struct_size == C.sizeof(grlx.capi.Config)
+    assert cfg.n_replicas == 3 and cfg.projector.tilings == 16 and cfg.projector.memory == 8388608
+    assert cfg.alpha == 0.2 and cfg.gamma == 0.97 and cfg.lambda_ == 0.65 and cfg.epsilon == 0.05
+    assert cfg.max_rows == 256 and cfg.tap_replica == -1
+
+
+def test_validation_errors_without_device(grlx):
+    """bad_param conditions surface as GRLX_ERR_INVALID before any device work."""
+    capi = grlx.capi
+    cfg = grlx.pendulum_sarsa_config(1)
+    cfg.projector.wrapping[0] = 1.0          # 1.0*16/0.31415 is not an integer (tile_coding.cpp:72-78)
+    with pytest.raises(capi.GrlxError) as ei:
+        grlx.Runner(cfg, [1])
+    assert ei.value.code == capi.ERR_INVALID and "wrapping" in str(ei.value)
+    cfg = grlx.pendulum_sarsa_config(1)
+    cfg.struct_size = 12
+    with pytest.raises(capi.GrlxError) as ei:
+        grlx.Runner(cfg, [1])
+    assert ei.value.code == capi.ERR_INVALID
+
+
+def test_no_cpu_fallback(grlx):
+    """Without a device every compute entry point refuses: the product never computes on the CPU."""
+    capi = grlx.capi
+    if capi.load().grlx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.GrlxError) as ei:
+        grlx.Runner(grlx.pendulum_sarsa_config(1), [1])
+    assert ei.value.code == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.GrlxError) as ei:
+        grlx.runner.device_math(0, [1.0])
+    assert ei.value.code == capi.ERR_NO_DEVICE

@@ -1,0 +1,293 @@
+"""Parity of the HIP path (through the C ABI) against the oracle: bit-exact for
+indices, RNG streams and -- because both sides follow the same portable
+arithmetic specification -- for weights, rewards and returns too."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc-0.txt")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    bad = np.nonzero(bits(a) != bits(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}: {a.flat[bad[0]]!r} vs {b.flat[bad[0]]!r}"
+
+
+# ---------------------------------------------------------------- math -----
+@pytest.mark.parametrize("op,name,lo,hi", [(0, "orc_psin", -200.0, 200.0), (1, "orc_pcos", -200.0, 200.0),
+                                           (2, "orc_plog", 1e-300, 1e3)])
+def test_device_math_bit_exact(grlx, oracle, op, name, lo, hi):
+    rng = np.random.default_rng(op)
+    x = np.concatenate([rng.uniform(lo, hi, 200000), rng.uniform(-1e-3, 1e-3, 20000) if op < 2 else rng.uniform(0, 1, 20000) ** 8,
+                        np.array([0.0, -0.0, 1e-30, 0.5, 1.0, np.pi, -np.pi, 2 * np.pi, 1e5, -1e5, 1048575.0])])
+    if op == 2:
+        x = np.abs(x) + 1e-308
+    got = grlx.runner.device_math(op, x)
+    f = getattr(oracle, name)
+    want = np.array([f(float(v)) for v in x])
+    assert_bit_equal(got, want, name)
+
+
+def test_device_fmod_sqrt_exact(grlx):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-500, 500, 100000), rng.uniform(-7, 7, 100000), [0.0, -0.0, 2 * np.pi, -2 * np.pi, 1e15]])
+    y = np.full_like(x, 2 * np.pi)
+    assert_bit_equal(grlx.runner.device_math(3, x, y), np.fmod(x, y), "fmod")
+    y2 = rng.uniform(1e-3, 50, x.size)
+    assert_bit_equal(grlx.runner.device_math(3, x, y2), np.fmod(x, y2), "fmod general")
+    z = rng.uniform(0, 1e6, 100000)
+    assert_bit_equal(grlx.runner.device_math(4, z), np.sqrt(z), "sqrt")
+
+
+def test_rand48_jump_on_device(grlx, oracle):
+    skip = np.array([0, 1, 2, 1000, 8388607, 8388608, 8388609, 2**33 + 5, 2**47 - 1], dtype=np.uint64)
+    for seed in (1, 77, 2**31 - 1):
+        got = grlx.runner.rand48_at(seed, skip)
+        want = []
+        for s in skip:
+            g = ob.Rand48()
+            oracle.orc_srand48(C.byref(g), seed)
+            oracle.orc_rand48_jump(C.byref(g), int(s))
+            want.append(oracle.orc_drand48(C.byref(g)))
+        assert_bit_equal(got, want, "rand48_at")
+
+
+# --------------------------------------------------------- tile coding -----
+def _tile_specs(grlx):
+    out = []
+    for (T, mem, res, wrap) in [
+        (16, 8388608, [0.31415, 3.1415, 3], [6.283, 0, 0]),                               # pendulum sarsa_tc.yaml
+        (16, 8388608, [2.5, 0.157075, 2.5, 1.57075], [0, 6.283, 0, 0]),                   # cart_pole ac_tc.yaml
+        (8, 1000003, [0.5, 0.25], [0, 0]),                                                # non power-of-two memory
+        (32, 4096, [0.1, 0.2, 0.3, 0.4, 0.5, 0.6], [0, 0, 1.2, 0, 0, 0]),                 # many collisions
+        (1, 65536, [1.0], [0]),
+    ]:
+        g = grlx.capi.TileSpec(); o = ob.TileSpec()
+        for s in (g, o):
+            s.tilings, s.memory, s.dims = T, mem, len(res)
+            for i, (r, w) in enumerate(zip(res, wrap)):
+                s.resolution[i] = r; s.wrapping[i] = w
+        out.append((g, o))
+    return out
+
+
+def test_project_bit_exact(grlx):
+    rng = np.random.default_rng(0)
+    for g, o in _tile_specs(grlx):
+        x = rng.uniform(-40, 40, (4000, g.dims))
+        x[:50] = np.round(x[:50])                      # tile boundaries
+        x[50:60] = 0.0
+        x[60:70] = -1e-12
+        got = grlx.runner.project(g, x)
+        want = ob.tile_project(o, x)
+        assert got.dtype == np.uint32 and (got == want).all()
+    # empty batch
+    g, _ = _tile_specs(grlx)[0]
+    assert grlx.runner.project(g, np.zeros((0, 3))).shape == (0, 16)
+
+
+def test_project_known_answer(grlx):
+    g, _ = _tile_specs(grlx)[0]
+    got = grlx.runner.project(g, [[0.0, 0.0, -3.0]])[0]
+    assert list(got) == [7880414, 393415, 3612154, 7585272, 7714558, 1817205, 6530852, 7084512,
+                         3784258, 7288551, 1290213, 7444255, 3032162, 6105701, 5672678, 4342842]
+
+
+# ----------------------------------------------------------- env step ------
+def test_env_step_bit_exact(grlx):
+    rng = np.random.default_rng(1)
+    n = 5000
+    state = np.stack([rng.uniform(-30, 30, n), rng.uniform(-40, 40, n), rng.uniform(0, 2.97, n)], axis=1)
+    state[0] = [np.pi, 0, 0]
+    action = rng.choice([-3.0, 0.0, 3.0], n)
+    cfg = grlx.pendulum_sarsa_config(1)
+    spec = ob.pendulum_sarsa_spec(math=ob.MATH_PORTABLE)
+    for _ in range(3):                                  # chained steps
+        gs, gobs, grew, gterm = grlx.runner.env_step(cfg, state, action)
+        os_, oobs, orew, oterm = ob.env_step(spec, state, action)
+        assert_bit_equal(gs, os_, "state"); assert_bit_equal(gobs, oobs, "obs"); assert_bit_equal(grew, orew, "reward")
+        assert (gterm == oterm).all()
+        state = gs
+    # KAT (libm == portable here): first step of seed 1
+    s1, _, r1, _ = grlx.runner.env_step(cfg, [[np.pi, 0, 0]], [-3.0])
+    assert list(s1[0]) == [3.1026908939925946, -2.5498788738732121, 0.030000000000000006]
+    assert r1[0] == -57.783642145465336
+
+
+# ------------------------------------------------- representation ops ------
+def test_table_ops_match_dense_reference(grlx):
+    """read/write/update against a dense numpy restatement of linear.cpp, incl. lazily
+    initialised slots, duplicate indices inside a projection and invalid indices."""
+    cfg = grlx.pendulum_sarsa_config(2, table_log2_capacity=10)
+    r = grlx.Runner(cfg, [11, 12])
+    e = [ob.Experiment(ob.pendulum_sarsa_spec(), seed=s) for s in (11, 12)]
+    dense = [dict(), dict()]
+
+    def w(rep, slot):
+        if slot not in dense[rep]:
+            dense[rep][slot] = float(e[rep].weights([slot])[0])
+        return dense[rep][slot]
+
+    rng = np.random.default_rng(2)
+    INV = 0xFFFFFFFF
+    for it in range(30):
+        n = 6
+        rep = rng.integers(0, 2, n).astype(np.int32)
+        idx = rng.integers(0, 200, (n, 16)).astype(np.uint32)       # small range: duplicates + shared slots
+        if it % 3 == 0:
+            idx[0, 5] = idx[0, 2]
+        op = it % 3
+        if op == 0:
+            got = r.read(rep, idx)
+            want = []
+            for k in range(n):
+                s = 0.0
+                for v in idx[k]:
+                    s += w(rep[k], int(v))
+                want.append(s / 16)
+            assert_bit_equal(got, want, "read")
+        elif op == 1:
+            target = rng.uniform(-5, 5, n)
+            r.write(rep, idx, target, 0.2)
+            for k in range(n):
+                s = 0.0
+                for v in idx[k]:
+                    s += w(rep[k], int(v))
+                d = 0.2 * (target[k] - s / 16)
+                for v in idx[k]:
+                    dense[rep[k]][int(v)] = w(rep[k], int(v)) + d
+        else:
+            idx[1, 3] = INV
+            delta = rng.uniform(-1, 1, n)
+            # rows containing an invalid index are update-only (linear.cpp:207)
+            r.update(rep, idx, delta)
+            for k in range(n):
+                for v in idx[k]:
+                    if int(v) != INV:
+                        dense[rep[k]][int(v)] = w(rep[k], int(v)) + delta[k]
+    for rep in (0, 1):
+        slots = np.array(sorted(dense[rep]), dtype=np.uint32)
+        assert_bit_equal(r.weights(rep, slots), [dense[rep][int(s)] for s in slots], "final weights")
+    assert r.table_load(0) + r.table_load(1) == len(dense[0]) + len(dense[1])
+    r.close()
+
+
+# ---------------------------------------------------------- fused path -----
+def _compare_taps(gt, ot, A=3):
+    assert gt.test == ot.test and gt.terminal == ot.terminal
+    assert gt.action_index == ot.action_index, (gt.action_index, ot.action_index)
+    assert list(gt.p_idx[:16]) == list(ot.p_idx[:16])
+    assert_bit_equal(list(gt.obs[:2]), list(ot.obs[:2]), "obs")
+    assert_bit_equal([gt.reward, gt.action, gt.delta], [ot.reward, ot.action, ot.delta], "reward/action/delta")
+    assert_bit_equal(list(gt.q[:A]), list(ot.q[:A]), "q")
+    assert gt.trace_len == ot.trace_len
+
+
+@pytest.mark.parametrize("agent", [0, 1])
+def test_fused_steps_bit_exact(grlx, agent):
+    """Every step of the first 23 trials (learning + 2 test trials) of one replica: tile
+    indices, Q-values, chosen actions, rewards, TD errors, trace lengths."""
+    seed, trials, cap = 4, 23, 2400
+    cfg = grlx.pendulum_sarsa_config(5, tap_replica=2, tap_capacity=cap, agent=agent)
+    seeds = [seed + 10, seed + 11, seed, seed + 12, seed + 13]
+    r = grlx.Runner(cfg, seeds)
+    r.run(12); r.run(11)                                 # two launches: state persists across launches
+    r.sync()
+    e = ob.Experiment(ob.pendulum_sarsa_spec(agent=agent), seed=seed)
+    rows, otaps = e.run(trials, tap_cap=cap)
+    gtaps = r.taps()
+    assert len(gtaps) == len(otaps) == trials * 100
+    for k, (gt, ot) in enumerate(zip(gtaps, otaps)):
+        try:
+            _compare_taps(gt, ot)
+        except AssertionError as ex:
+            raise AssertionError(f"step {k}: {ex}")
+    t, s, rew = r.rows(2)
+    assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
+    assert_bit_equal(rew, [x.reward for x in rows], "returns")
+    assert_bit_equal(r.env_state(2), e.state(), "env state")
+    assert list(r.rng(2))[:3] == list(e.rng())[:3]
+    r.close()
+
+
+def test_fused_many_replicas_vs_oracle(grlx):
+    """N ragged (not a multiple of 4) replicas with different seeds, 10 test rows each,
+    final weights of every slot the oracle touched."""
+    seeds = list(range(1, 8))
+    trials = 110
+    cfg = grlx.pendulum_sarsa_config(len(seeds))
+    r = grlx.Runner(cfg, seeds)
+    r.run(trials); r.sync()
+    assert r.n_rows() == 10
+    rng = np.random.default_rng(3)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=seed)
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        slots = rng.integers(0, 8388608, 3000).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots), e.weights(slots), "untouched/lazy weights")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3]
+    learn, test = r.step_counts()
+    assert learn == 100 * 100 * len(seeds) and test == 10 * 100 * len(seeds)
+    r.close()
+
+
+def test_replica0_reproduces_reference_golden(grlx):
+    """Config 2 semantics: replica r is seeded srand48(1+r); replica 0 must print the
+    reference's own 181-row golden file (tests/template/pendulum-sarsa-tc-0.txt)."""
+    cfg = grlx.pendulum_sarsa_config(64)
+    r = grlx.Runner(cfg, np.arange(1, 65))
+    for _ in range(20):
+        r.run(100)
+    r.sync()
+    t, s, rew = r.rows(0)
+    text = "".join(grlx.runner.format_row(int(a), int(b), float(c)) for a, b, c in zip(t, s, rew))
+    assert text == open(GOLDEN).read()
+    # every touched slot of replica 0 equals the oracle's dense table
+    e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=1)
+    e.run(2000)
+    dense = np.ctypeslib.as_array(e.L.orc_weights(e.h, 0), shape=(8388608,))
+    allslots = np.arange(8388608, dtype=np.uint32)
+    got = r.weights(0, allslots)
+    assert_bit_equal(got, dense, "all 8,388,608 weights of replica 0")
+    assert 10000 < r.table_load(0) < 30000
+    r.close()
+
+
+def test_table_overflow_is_reported(grlx):
+    cfg = grlx.pendulum_sarsa_config(4, table_log2_capacity=8)      # 256 slots: too small on purpose
+    r = grlx.Runner(cfg, [1, 2, 3, 4])
+    r.run(5)
+    with pytest.raises(grlx.capi.GrlxError) as ei:
+        r.sync()
+    assert ei.value.code == grlx.capi.ERR_TABLE_FULL
+    r.close()
+
+
+def test_curve_stats_device(grlx):
+    torch = pytest.importorskip("torch")
+    n = 37
+    cfg = grlx.pendulum_sarsa_config(n)
+    r = grlx.Runner(cfg, np.arange(100, 100 + n))
+    r.run(22); r.sync()
+    out = torch.zeros((2, 3), dtype=torch.float64, device="cuda")
+    r.curve_stats(out.data_ptr(), 0, 2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rew = np.stack([r.rows(k)[2] for k in range(n)])               # [n, 2]
+    np.testing.assert_allclose(out[:, 0].cpu().numpy(), rew.sum(0), rtol=1e-13)
+    np.testing.assert_allclose(out[:, 1].cpu().numpy(), (rew ** 2).sum(0), rtol=1e-13)
+    assert (out[:, 2].cpu().numpy() == n).all()
+    r.close()

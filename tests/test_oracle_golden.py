@@ -1,0 +1,84 @@
+"""The oracle against everything the reference's own tests pin for this path
+(SURVEY.md section 8c): the 181-row golden learning curve, plus known-answer values."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc-0.txt")
+
+
+@pytest.mark.parametrize("math", [ob.MATH_LIBM, ob.MATH_PORTABLE])
+def test_golden_curve_byte_exact(oracle, math):
+    """`grld -s 1 tests/pendulum-sarsa-tc.yaml` (bin/runtests.py:21) -> tests/template/pendulum-sarsa-tc-0.txt"""
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=math), seed=1)
+    rows, _ = e.run(2000)
+    text = e.format_rows(rows)
+    with open(GOLDEN) as f:
+        golden = f.read()
+    assert len(rows) == 181
+    assert text == golden
+
+
+def test_math_modes_agree_to_rounding(oracle):
+    """libm and portable arithmetic differ by <= 1 ulp per call; over a whole run the
+    discrete decisions are identical; returns agree to ~4e-9 relative (1-ulp differences
+    are amplified by the unstable upright equilibrium), far inside the 1e-5 of the north star."""
+    a = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_LIBM), seed=3)
+    b = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_PORTABLE), seed=3)
+    ra, _ = a.run(330)
+    rb, _ = b.run(330)
+    assert [r.steps for r in ra] == [r.steps for r in rb]
+    np.testing.assert_allclose([r.reward for r in ra], [r.reward for r in rb], rtol=1e-6)
+    assert list(a.rng()) == list(b.rng())
+
+
+def test_known_answers_seed1(oracle):
+    """KATs of SURVEY.md section 8(c), re-derived: first weights, first Q-values, first step."""
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_LIBM, test_interval=-1), seed=1)
+    np.testing.assert_array_equal(e.weights([0, 1, 2]),
+                                  [0.033849041982652039, 0.27507035559708015, 0.79539919112916024])
+    rows, taps = e.run(2, tap_cap=200)
+    assert len(taps) == 200
+    # tile indices of (obs=[0,0], a=-3): the projection updated by the first step
+    expect_idx = [7880414, 393415, 3612154, 7585272, 7714558, 1817205, 6530852, 7084512,
+                  3784258, 7288551, 1290213, 7444255, 3032162, 6105701, 5672678, 4342842]
+    assert list(taps[0].p_idx[:16]) == expect_idx
+    assert taps[0].reward == -57.783642145465336
+    assert rows[0].reward == -4390.8915000856532
+    assert rows[1].reward == -4452.4274919383552
+
+
+def test_first_q_values_seed1(oracle):
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_LIBM), seed=1)
+    ts = e.spec.projector
+    q = []
+    for a in (-3.0, 0.0, 3.0):
+        idx = ob.tile_project(ts, [[0.0, 0.0, a]])[0]
+        w = e.weights(idx)
+        s = 0.0
+        for v in w:
+            s += v
+        q.append(s / 16)
+    assert q == [0.57214509158813298, 0.48896661473106495, 0.53637563628866447]
+
+
+def test_stats_match_survey_probe(oracle):
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_LIBM), seed=1)
+    e.run(2000)
+    st = e.stats()
+    assert st.learn_steps == 181900 and st.test_steps == 18100
+    assert abs(st.weight_reads / st.learn_steps - 101.3) < 0.05
+    assert abs(st.weight_rmws / st.learn_steps - 91.2) < 0.05
+    assert abs(st.trace_entries_sum / st.learn_steps - 8.55) < 0.01
+
+
+def test_q_learning_runs(oracle):
+    """Q-learning predictor (advantage.cpp:71-110): parity unpinned by reference tests; sanity only."""
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_PORTABLE, agent=ob.AGENT_Q), seed=1)
+    rows, _ = e.run(110)
+    assert len(rows) == 10
+    assert all(np.isfinite(r.reward) and r.reward < 0 for r in rows)
