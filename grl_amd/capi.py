@@ -92,6 +92,24 @@ def lib_path() -> str:
     return _build.LIB
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as the system
+    one).  Two HIP runtimes in one process cannot both own the GPU, so when torch is
+    installed its runtime is loaded first and libgrlx.so binds to it (soname match);
+    a later `import torch` then reuses the same object.  Without torch the system
+    runtime in /opt/rocm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libgrlx.so (raises if it has not been built: no fallback)."""
     global _lib
@@ -101,6 +119,7 @@ def load():
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build the HIP extension first (python -m grl_amd._build); "
                           "grl_amd has no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported

@@ -99,7 +99,7 @@ __device__ __forceinline__ double pcos(double x)
   int q = math_reduce(x, rh, rl);
   double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
   double v = (q & 1) ? -s : c;
-  return ((q + 1) & 2) ? -v : v;
+  return (q & 2) ? -v : v;
 }
 
 // sin and cos of the same argument share the reduction
@@ -113,7 +113,7 @@ __device__ __forceinline__ void psincos(double x, double &sn, double &cs)
   double vs = (q & 1) ? c : s;
   sn = (q & 2) ? -vs : vs;
   double vc = (q & 1) ? -s : c;
-  cs = ((q + 1) & 2) ? -vc : vc;
+  cs = (q & 2) ? -vc : vc;
 }
 
 // plog(x): x = m*2^k, m in [sqrt2/2, sqrt2); f = m-1; d = f+2; s = f/d;
