@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused HIP rollout path (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): pendulum swing-up SARSA(lambda) tile coding,
+4096 independent-seed replicas per GPU (replica r seeded srand48(1+r), weights
+U(0,1) from the replica's own LCG stream -- synthetic inputs only).  One "step" is
+one launch of the hot path: every replica advances by 11 trials (10 learning
+episodes + 1 greedy test episode = 1100 env-steps).  Replica state, weight tables
+and RNG streams are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Replicas shard across ranks with no data-path
+collective (weak scaling: 4096 replicas per GPU); the only collective is the final
+RCCL all-reduce of the learning-curve statistics [rows][3], inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REPLICAS_PER_GPU = 4096
+TRIALS_PER_STEP = 11                      # test_interval 10 => 10 learning + 1 test episode
+STEPS_PER_EPISODE = 100                   # control step 0.03 s, timeout 2.99 s
+LEARN_STEPS_PER_STEP = 10 * STEPS_PER_EPISODE
+TEST_STEPS_PER_STEP = 1 * STEPS_PER_EPISODE
+# Algorithmic bytes (SURVEY.md section 8d / BASELINE.md section 5, restated in DESIGN.md):
+BYTES_PER_LEARN_STEP = 2228               # 768 B of weight reads + 16 B x 91.2 read-modify-writes
+BYTES_PER_TEST_STEP = 384                 # A*T 8-byte reads
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """The oracle (validated against the reference's golden curve) on ONE host core:
+    replica seed 1, the same trial mix, for about `budget_s` seconds of CPU work."""
+    from tests import oracle_binding as ob
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_LIBM), seed=1)      # libm = the reference's own arithmetic
+    chunk = 110 * 5
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        e.run(chunk)
+        steps += chunk * STEPS_PER_EPISODE
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C restatement of grl's scalar path, libm arithmetic), 1 replica seed 1, "
+                      f"{steps // STEPS_PER_EPISODE} trials = {steps} env-steps in {dt:.1f} s, weight init excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table-log2", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import grl_amd
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.replicas
+    total_steps = args.steps + args.warmup
+    rows_total = total_steps                                   # one test row per step
+    cfg = grl_amd.pendulum_sarsa_config(n, table_log2_capacity=args.table_log2, max_rows=rows_total + 1)
+    seeds = 1 + rank * n + np.arange(n, dtype=np.int64)        # contiguous partition of replica ids
+    runner = grl_amd.Runner(cfg, seeds)
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    curve = torch.zeros((rows_total, 3), dtype=torch.float64, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.run(TRIALS_PER_STEP, sptr)
+    runner.sync(sptr)
+
+    # per-launch kernel time: HIP events on the stream the kernel is launched on
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        runner.run(TRIALS_PER_STEP, sptr)
+        ev[k][1].record(stream)
+    # the job's only collective: learning-curve statistics over all replicas of all GPUs
+    runner.curve_stats(curve.data_ptr(), 0, rows_total, sptr)
+    if world > 1:
+        dist.all_reduce(curve, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    runner.sync(sptr)                                          # raises on table overflow etc.
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    env_steps_per_step = n * (LEARN_STEPS_PER_STEP + TEST_STEPS_PER_STEP)
+    total_env_steps = env_steps_per_step * args.steps * world
+    learn, test = runner.step_counts()
+    assert learn == n * LEARN_STEPS_PER_STEP * total_steps and test == n * TEST_STEPS_PER_STEP * total_steps, (learn, test)
+
+    if rank == 0:
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = n * (LEARN_STEPS_PER_STEP * BYTES_PER_LEARN_STEP + TEST_STEPS_PER_STEP * BYTES_PER_TEST_STEP)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        mean_curve = (curve[:, 0] / curve[:, 2]).cpu().numpy()
+        out = {
+            "metric": "env-steps/sec (batched rollouts), pendulum SARSA-tc",
+            "value": total_env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "pendulum swing-up SARSA(lambda) hashed tile coding (cfg/pendulum/sarsa_tc.yaml semantics), "
+                                   f"{n} independent-seed replicas per GPU, 11 trials (1100 env-steps) per replica per step",
+                       "replicas_per_gpu": n, "trials_per_step": TRIALS_PER_STEP, "env_steps_per_step": env_steps_per_step * world,
+                       "tilings": 16, "memory": 8388608, "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rollout_kernel<pendulum,3>", "kernel_ms_avg": avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    runner.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
