@@ -68,6 +68,8 @@ _SIGS = {
     "grlx_destroy": (C.c_int, [C.c_void_p]),
     "grlx_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "grlx_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grlx_set_diag": (C.c_int, [C.c_void_p, C.c_int]),
+    "grlx_read_diag": (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int, _P(C.c_int)]),
     "grlx_rows": (C.c_int, [C.c_void_p]),
     "grlx_read_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64), _P(C.c_double)]),
     "grlx_curve_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

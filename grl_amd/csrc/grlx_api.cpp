@@ -171,6 +171,7 @@ struct grlx_ctx {
   grlx_tap     *taps = nullptr;
   uint32_t     *tap_count = nullptr;
   uint64_t     *scratch = nullptr;        // 8 x u64
+  unsigned long long *diag = nullptr;
   int64_t      trials_run = 0;
 };
 
@@ -346,7 +347,32 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->taps);
   (void)hipFree(ctx->tap_count);
   (void)hipFree(ctx->scratch);
+  (void)hipFree(ctx->diag);
   delete ctx;
+  return GRLX_OK;
+}
+
+int grlx_set_diag(grlx_ctx *ctx, int enable)
+{
+  if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
+  const size_t waves = ((size_t)ctx->P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (enable && !ctx->diag)
+  {
+    HIP_TRY(hipMalloc((void **)&ctx->diag, waves * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->diag, 0, waves * 8 * sizeof(unsigned long long)));
+  }
+  ctx->P.diag_out = enable ? ctx->diag : nullptr;
+  return GRLX_OK;
+}
+
+int grlx_read_diag(grlx_ctx *ctx, uint64_t *out, int cap_waves, int *n_waves)
+{
+  if (!ctx || !out || !n_waves) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!ctx->diag) return fail(GRLX_ERR_INVALID, "diagnostics are not enabled");
+  int waves = (ctx->P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (waves > cap_waves) waves = cap_waves;
+  HIP_TRY(hipMemcpy(out, ctx->diag, (size_t)waves * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  *n_waves = waves;
   return GRLX_OK;
 }
 

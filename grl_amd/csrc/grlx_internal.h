@@ -77,6 +77,8 @@ struct DevParams {
   grlx_tap *taps;
   int32_t  tap_replica, tap_capacity;
   uint32_t *tap_count;
+  // diagnostic build only: per-wave cycle sums of 8 phases (NULL = production kernel)
+  unsigned long long *diag_out;
 };
 
 // ---------------------------------------------------------------------------

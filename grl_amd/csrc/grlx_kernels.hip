@@ -28,31 +28,56 @@ namespace grlx {
 // drand48 family (utils.h:84-137): X' = (A*X + C) mod 2^48.
 constexpr uint64_t kLcgA = 0x5DEECE66DULL, kLcgC = 0xBULL, kMask48 = (1ULL << 48) - 1;
 
-struct JumpTable { uint64_t a[48], c[48]; };
+// Jump-ahead x -> A^n x + C_n by byte windows of n: entry [w][b] is the affine map of
+// b * 256^w draws, so a jump of up to 2^32 draws costs four multiply-adds.
+struct JumpTable { uint64_t a[4][256], c[4][256]; };
 constexpr JumpTable make_jump_table()
 {
   JumpTable t{};
-  uint64_t a = kLcgA, c = kLcgC;
-  for (int i = 0; i < 48; ++i)
+  uint64_t sa = kLcgA, sc = kLcgC;                 // map of 256^w draws
+  for (int w = 0; w < 4; ++w)
   {
-    t.a[i] = a;
-    t.c[i] = c;
-    c = ((a + 1) * c) & kMask48;
-    a = (a * a) & kMask48;
+    uint64_t a = 1, c = 0;                         // identity = 0 draws
+    for (int b = 0; b < 256; ++b)
+    {
+      t.a[w][b] = a;
+      t.c[w][b] = c;
+      c = (sa * c + sc) & kMask48;                 // compose with one more window step
+      a = (sa * a) & kMask48;
+    }
+    sa = a;                                        // after 256 steps: map of 256^(w+1) draws
+    sc = c;
   }
   return t;
 }
-__constant__ JumpTable d_jump = make_jump_table();
+__device__ const JumpTable d_jump = make_jump_table();
 
 __device__ __forceinline__ uint64_t lcg_next(uint64_t x) { return (kLcgA * x + kLcgC) & kMask48; }
 __device__ __forceinline__ double   lcg_double(uint64_t x) { return (double)x * 0x1p-48; }
 __device__ __forceinline__ uint32_t lcg_long(uint64_t x) { return (uint32_t)(x >> 17); }
 
+__device__ inline uint64_t lcg_step_pow2(uint64_t x, uint64_t n)
+{ // generic O(log n) jump by repeated squaring (only for n >= 2^32)
+  uint64_t a = kLcgA, c = kLcgC;
+  while (n)
+  {
+    if (n & 1) x = (a * x + c) & kMask48;
+    c = ((a + 1) * c) & kMask48;
+    a = (a * a) & kMask48;
+    n >>= 1;
+  }
+  return x;
+}
+
 __device__ inline uint64_t lcg_jump(uint64_t x, uint64_t n)
 {
-  for (int k = 0; n != 0 && k < 48; ++k, n >>= 1)
-    if (n & 1)
-      x = (d_jump.a[k] * x + d_jump.c[k]) & kMask48;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+  {
+    const uint32_t b = (uint32_t)(n >> (8 * w)) & 0xFFu;
+    x = (d_jump.a[w][b] * x + d_jump.c[w][b]) & kMask48;
+  }
+  if (n >> 32) x = lcg_step_pow2(x, (n >> 32) << 32);
   return x;
 }
 
@@ -174,70 +199,116 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_wave_barrier();
 }
 
-// Find `slot` in the replica's table; create it with its lazy initial weight if
-// absent.  Lanes of one replica may miss on the same empty position, so inserts
-// are serialised within each 16-lane group (one lane per group at a time); they
-// are rare (about 17 k per replica over a whole pendulum run).
+// Probe sequence.  Entries are grouped in 128-byte buckets of 8 (one cache line): the
+// t-th probe of a slot stays inside its home bucket for t < 8 (so every probe after
+// the first is an L1 hit) and moves to the following buckets only when a bucket is full.
+__device__ __forceinline__ uint32_t probe_pos(const Table &t, uint32_t home, uint32_t n)
+{
+  uint32_t bucket = ((home >> 3) + (n >> 3)) & (t.mask >> 3);
+  return (bucket << 3) | ((home + n) & 7u);
+}
+
+// Resolve NP independent lookups of one lane at once: the first-round loads of all of
+// them are in flight together (one memory round trip per step in the common case).
+// found[i]: position of the entry (hit) or of the first empty position (miss).
+template <int NP>
+__device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&slot)[NP], uint32_t (&home)[NP], uint32_t (&tries)[NP],
+                                             double (&val)[NP], bool (&miss)[NP], uint32_t &status)
+{
+  uint4 raw[NP];
+  bool pending[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+  {
+    home[i] = table_home(t, slot[i]);
+    tries[i] = 0;
+    raw[i] = entry_load(t, probe_pos(t, home[i], 0));
+    pending[i] = true;
+    miss[i] = false;
+  }
+  for (int it = 0; it < kMaxProbe; ++it)
+  {
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (pending[i])
+      {
+        if (raw[i].x == slot[i] + 1u) { val[i] = entry_val(raw[i]); pending[i] = false; }
+        else if (raw[i].x == 0u) { miss[i] = true; pending[i] = false; }
+        else
+        {
+          tries[i]++;
+          raw[i] = entry_load(t, probe_pos(t, home[i], tries[i]));
+          any = true;
+        }
+      }
+    if (!any) break;
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+    if (pending[i]) status |= ST_TABLE_FULL;
+}
+
+// Create the slots that were missing, with their lazy initial weights.  Lanes of one
+// replica may miss on the same empty position, so inserts are serialised within each
+// 16-lane group (one lane per group at a time); they are rare (about 17 k per replica
+// over a whole pendulum run).
+__device__ inline void table_insert(const Table &t, const LinearParams &lp, uint64_t tl0, bool miss,
+                                    uint32_t slot, uint32_t home, uint32_t &tries, double &val, uint32_t &status, uint32_t &inserted)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long pend = __ballot(miss);
+  if (pend == 0ull) return;
+  double w0 = 0.0;
+  if (miss) w0 = lazy_weight(tl0, lp, slot);
+  while (pend != 0ull)
+  {
+    unsigned long long sel = 0ull;                 // lowest pending lane of every 16-lane group goes now
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg)
+    {
+      unsigned long long grp = pend & (0xFFFFull << (16 * gg));
+      sel |= grp & (~grp + 1ull);
+    }
+    if ((sel >> lane) & 1ull)
+    {
+      bool done = false;
+      for (int it = 0; it < kMaxProbe; ++it)
+      {
+        const uint32_t p = probe_pos(t, home, tries);
+        uint4 raw = entry_load(t, p);
+        if (raw.x == slot + 1u) { val = entry_val(raw); done = true; break; }   // a sibling lane created it
+        if (raw.x == 0u)
+        {
+          entry_store(t, p, slot + 1u, w0);
+          val = w0;
+          inserted++;
+          done = true;
+          break;
+        }
+        tries++;
+      }
+      if (!done) status |= ST_TABLE_FULL;
+    }
+    pend &= ~sel;
+    // The next lane's probe must observe this insert.  Both are vector memory operations
+    // of the same wave issued in this order, which the hardware keeps for one address;
+    // the fence only stops the compiler from reordering them.
+    wave_sync();
+  }
+}
+
+// single lookup-or-create (fine-grained operators)
 __device__ inline void table_probe(const Table &t, const LinearParams &lp, uint64_t tl0, bool active,
                                    uint32_t slot, uint32_t &pos, double &val, uint32_t &status, uint32_t &inserted)
 {
-  const int lane = threadIdx.x & 63;
-  bool miss = false;
-  uint32_t p = table_home(t, slot);
-  if (active)
-  {
-    bool hit = false;
-    for (int it = 0; it < kMaxProbe; ++it)
-    {
-      uint4 raw = entry_load(t, p);
-      if (raw.x == slot + 1u) { hit = true; val = entry_val(raw); break; }
-      if (raw.x == 0u) { miss = true; break; }
-      p = (p + 1u) & t.mask;
-    }
-    if (!hit && !miss) status |= ST_TABLE_FULL;
-  }
-  unsigned long long pend = __ballot(miss);
-  if (pend != 0ull)
-  {
-    double w0 = 0.0;
-    if (miss) w0 = lazy_weight(tl0, lp, slot);
-    while (pend != 0ull)
-    {
-      // lowest pending lane of every 16-lane group goes now
-      unsigned long long low = pend & (~pend + 1ull);                       // lowest set bit overall (unused lanes fall through)
-      unsigned long long sel = 0ull;
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg)
-      {
-        unsigned long long grp = pend & (0xFFFFull << (16 * gg));
-        sel |= grp & (~grp + 1ull);
-      }
-      (void)low;
-      if ((sel >> lane) & 1ull)
-      {
-        bool done = false;
-        for (int it = 0; it < kMaxProbe; ++it)
-        {
-          uint4 raw = entry_load(t, p);
-          if (raw.x == slot + 1u) { val = entry_val(raw); done = true; break; }   // a sibling lane created it
-          if (raw.x == 0u)
-          {
-            entry_store(t, p, slot + 1u, w0);
-            val = w0;
-            inserted++;
-            done = true;
-            break;
-          }
-          p = (p + 1u) & t.mask;
-        }
-        if (!done) status |= ST_TABLE_FULL;
-      }
-      pend &= ~sel;
-      // the insert must be visible to the next lane's probe: drain the wave's memory operations
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    }
-  }
-  pos = p;
+  uint32_t sl[1] = {slot}, home[1] = {0}, tries[1] = {0};
+  double v[1] = {0};
+  bool miss[1] = {false};
+  if (active) table_lookup<1>(t, sl, home, tries, v, miss, status);
+  table_insert(t, lp, tl0, active && miss[0], slot, home[0], tries[0], v[0], status, inserted);
+  pos = probe_pos(t, home[0], tries[0]);
+  val = v[0];
 }
 
 // ----------------------------------------------------------- environments --
@@ -377,7 +448,24 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 // makes both the per-lane writes and the 4 simultaneous broadcast reads conflict-free.
 #define SHW(row, k, g) sh_w[(((row) * 16 + (k)) << 2) + (g)]
 
-template <int ENV, int NA>
+// in-kernel stamps (diagnostic instantiation only; cdna_hip_programming.md section 7)
+__device__ __forceinline__ unsigned long long stamp()
+{
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define DIAG_STAMP(slot)                                   \
+  if (DIAG)                                                \
+  {                                                        \
+    unsigned long long now__ = stamp();                    \
+    diag_sum[slot] += now__ - diag_last;                   \
+    diag_last = now__;                                     \
+  }
+
+template <int ENV, int NA, bool DIAG>
 __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 {
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
@@ -418,6 +506,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   for (int e = 0; e < kMaxTrace; ++e) { tr_pos[e] = kInvalidPos; tr_val[e] = 0; tr_cnt[e] = 0; }
   int    tr_len = 0;
   double tr_total = 1.;
+  unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
+  if (DIAG) diag_last = stamp();
 
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
@@ -452,6 +542,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
       if (!__any(running)) break;
       if (running)
       {
+        DIAG_STAMP(0)
         // -------- environment step (skipped on the start() pass)
         if (!first)
         {
@@ -460,6 +551,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           time += 1;                                                       // tau = 1
         }
         const bool has_next = first || terminal != 2;
+        DIAG_STAMP(1)
 
         // -------- policy: Q(s', .) for all actions (q.cpp:94-107)
         double q[NA];
@@ -488,18 +580,29 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             slot[a] = murmur_final(h) % (uint32_t)P.tile.memory;
           }
         }
+        DIAG_STAMP(2)
         // previous step's stores precede these loads in program order; they were issued
         // a full RK4 ago, so this wait is free and makes the ordering explicit
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        DIAG_STAMP(6)
         if (update) wp = value_load(tab, p_pos);                           // current weights of project(s, a)
         if (has_next)
         {
+          uint32_t home[NA], tries[NA];
+          bool miss[NA];
+          table_lookup<NA>(tab, slot, home, tries, w, miss, status);
+          DIAG_STAMP(7)
 #pragma unroll
           for (int a = 0; a < NA; ++a)
-            table_probe(tab, P.lin, TL0, true, slot[a], pos[a], w[a], status, inserted);
+            table_insert(tab, P.lin, TL0, miss[a], slot[a], home[a], tries[a], w[a], status, inserted);
 #pragma unroll
-          for (int a = 0; a < NA; ++a) SHW(a, j, g) = w[a];
+          for (int a = 0; a < NA; ++a)
+          {
+            pos[a] = probe_pos(tab, home[a], tries[a]);
+            SHW(a, j, g) = w[a];
+          }
         }
+        DIAG_STAMP(3)
         if (update) SHW(NA, j, g) = wp;
         sh_ppos[g * 16 + j] = p_pos;
         sh_fbflag[j * 4 + g] = 0u;
@@ -552,6 +655,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           }
         }
 
+        DIAG_STAMP(4)
         // -------- predictor update (sarsa.cpp:98-124 / advantage.cpp:71-110)
         double delta = 0;
         if (update)
@@ -681,6 +785,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           }
         }
 
+        DIAG_STAMP(5)
         // -------- tap (debug / parity tests)
         if (tapped && !first)
         {
@@ -746,6 +851,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
     }
   }
 
+  if (DIAG && P.diag_out && lane == 0)
+    for (int k = 0; k < 8; ++k) P.diag_out[(size_t)blockIdx.x * 8 + k] = diag_sum[k];
+
   // write the replica back
   uint32_t ins = inserted;
 #pragma unroll
@@ -777,7 +885,10 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
 #define GRLX_LAUNCH(ENVID, NACT)                                                                              \
   if (P.env == ENVID && P.A == NACT)                                                                        \
   {                                                                                                         \
-    hipLaunchKernelGGL((rollout_kernel<ENVID, NACT>), dim3(waves), dim3(64), 0, stream, P, n_trials);       \
+    if (P.diag_out)                                                                                         \
+      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, true>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     return hipGetLastError();                                                                               \
   }
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 3)
@@ -915,14 +1026,13 @@ __global__ void get_weights_kernel(DevParams P, int table, int replica, const ui
   if (i >= n) return;
   const Table tab = table_of(P, table, replica);
   uint32_t slot = slots[i];
-  uint32_t p = table_home(tab, slot);
+  const uint32_t home = table_home(tab, slot);
   double v = lazy_weight(P.states[replica].TL0, P.lin, slot);
   for (int it = 0; it < kMaxProbe; ++it)
   {
-    uint4 raw = entry_load(tab, p);
+    uint4 raw = entry_load(tab, probe_pos(tab, home, (uint32_t)it));
     if (raw.x == slot + 1u) { v = entry_val(raw); break; }
     if (raw.x == 0u) break;
-    p = (p + 1u) & tab.mask;
   }
   out[i] = v;
 }

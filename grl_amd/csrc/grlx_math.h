@@ -12,12 +12,16 @@
 // Specification (checked bit for bit against an independent CPU restatement in
 // tests/test_gpu_math.py):
 //   reduce(x): fn = rint(x*INVPIO2); r0 = fma(-fn,P1,x)  (exact for |x| < 2^20)
-//              p = fn*P2; pl = fma(fn,P2,-p); (r,e) = TwoSum(r0,-p)
-//              t = (e-pl) - fn*P3; rh = r+t; rl = (r-rh)+t; quadrant = fn mod 4
-//   ksin(r,rl): z=r*r; v=z*r; P = S2+z*(S3+..+z*S8) (fma Horner);
-//               c = fma(v, fma(z,P,S1), fma(-0.5*z, rl, rl)); r+c
-//   kcos(r,rl): z=r*r; hz=0.5*z; w=1-hz; tail=(1-w)-hz; Q = C1+z*(C2+..+z*C8);
-//               c = fma(z*z, Q, fma(-r, rl, tail)); w+c
+//              p = fn*P2; pl = fma(fn,P2,-p); r = r0-p; e = (r0-r)-p   [Fast2Sum]
+//              t = (e-pl) - fn*P3; reduced argument = r + t, NOT renormalised (the
+//              kernels need t to first order only); quadrant = fn mod 4
+//   poly(z; c1..c8), Estrin: z2=z*z; z4=z2*z2; a=fma(z,c2,c1); b=fma(z,c4,c3);
+//              c=fma(z,c6,c5); d=fma(z,c8,c7); lo=fma(z2,b,a); hi=fma(z2,d,c); fma(z4,hi,lo)
+//   ksin(r,t): z=r*r; P=poly(z;S1..S8); r + fma(z*r, P, fma(-0.5*z, t, t))
+//   kcos(r,t): z=r*r; hz=0.5*z; w=1-hz; tail=(1-w)-hz; Q=poly(z;C1..C8);
+//              w + fma(z*z, Q, fma(-r, t, tail))
+// The dependent chain of one sine is ~13 operations; it bounds the RK4 latency at one
+// wave per SIMD, where a dependent f64 operation costs ~19 cycles.
 // Constants are Taylor coefficients 1/k! and a three-double split of pi/2, all
 // correctly rounded from exact rationals (tools/gen_math_constants.py).
 // Accuracy: <= 1 ulp from glibc on 3 % of arguments, identical elsewhere.
@@ -42,26 +46,28 @@ __device__ __forceinline__ int math_reduce(double x, double &rh, double &rl)
   double p  = fn * GRLX_PIO2_2;
   double pl = __builtin_fma(fn, GRLX_PIO2_2, -p);
   double r  = r0 - p;
-  double bb = r - r0;
-  double e  = (r0 - (r - bb)) + (-p - bb);
+  double e  = (r0 - r) - p;
   double t  = (e - pl) - fn * GRLX_PIO2_3;
-  double h  = r + t;
-  rh = h;
-  rl = (r - h) + t;
+  rh = r;
+  rl = t;
   return (int)((long long)fn & 3);
+}
+
+__device__ __forceinline__ double math_estrin8(double z, double c1, double c2, double c3, double c4,
+                                               double c5, double c6, double c7, double c8)
+{
+  double z2 = z * z, z4 = z2 * z2;
+  double a = __builtin_fma(z, c2, c1), b = __builtin_fma(z, c4, c3), c = __builtin_fma(z, c6, c5), d = __builtin_fma(z, c8, c7);
+  double lo = __builtin_fma(z2, b, a), hi = __builtin_fma(z2, d, c);
+  return __builtin_fma(z4, hi, lo);
 }
 
 __device__ __forceinline__ double math_ksin(double r, double rl)
 {
-  double z = r * r, v = z * r;
-  double P = __builtin_fma(z, 0x1.952c77030ad4ap-49, -0x1.ae7f3e733b81fp-41);
-  P = __builtin_fma(z, P, 0x1.6124613a86d09p-33);
-  P = __builtin_fma(z, P, -0x1.ae64567f544e4p-26);
-  P = __builtin_fma(z, P, 0x1.71de3a556c734p-19);
-  P = __builtin_fma(z, P, -0x1.a01a01a01a01ap-13);
-  P = __builtin_fma(z, P, 0x1.1111111111111p-7);
-  double c = __builtin_fma(v, __builtin_fma(z, P, -0x1.5555555555555p-3), __builtin_fma(-0.5 * z, rl, rl));
-  return r + c;
+  double z = r * r;
+  double P = math_estrin8(z, -0x1.5555555555555p-3, 0x1.1111111111111p-7, -0x1.a01a01a01a01ap-13, 0x1.71de3a556c734p-19,
+                          -0x1.ae64567f544e4p-26, 0x1.6124613a86d09p-33, -0x1.ae7f3e733b81fp-41, 0x1.952c77030ad4ap-49);
+  return r + __builtin_fma(z * r, P, __builtin_fma(-0.5 * z, rl, rl));
 }
 
 __device__ __forceinline__ double math_kcos(double r, double rl)
@@ -69,15 +75,29 @@ __device__ __forceinline__ double math_kcos(double r, double rl)
   double z = r * r, hz = 0.5 * z;
   double w = 1.0 - hz;
   double tail = (1.0 - w) - hz;
-  double Q = __builtin_fma(z, -0x1.6827863b97d97p-53, 0x1.ae7f3e733b81fp-45);
-  Q = __builtin_fma(z, Q, -0x1.93974a8c07c9dp-37);
-  Q = __builtin_fma(z, Q, 0x1.1eed8eff8d898p-29);
-  Q = __builtin_fma(z, Q, -0x1.27e4fb7789f5cp-22);
-  Q = __builtin_fma(z, Q, 0x1.a01a01a01a01ap-16);
-  Q = __builtin_fma(z, Q, -0x1.6c16c16c16c17p-10);
-  Q = __builtin_fma(z, Q, 0x1.5555555555555p-5);
-  double c = __builtin_fma(z * z, Q, __builtin_fma(-r, rl, tail));
-  return w + c;
+  double Q = math_estrin8(z, 0x1.5555555555555p-5, -0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-16, -0x1.27e4fb7789f5cp-22,
+                          0x1.1eed8eff8d898p-29, -0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-45, -0x1.6827863b97d97p-53);
+  return w + __builtin_fma(z * z, Q, __builtin_fma(-r, rl, tail));
+}
+
+// sin or cos kernel selected per lane (odd = cosine kernel): both kernels are the same
+// Estrin scheme, so one evaluation with per-lane coefficients performs exactly the
+// operations of math_ksin / math_kcos (bit-identical) at half the instruction count.
+__device__ __forceinline__ double math_ksincos(double r, double rl, bool odd)
+{
+  const double z = r * r;
+  const double P = math_estrin8(z,
+      odd ? 0x1.5555555555555p-5 : -0x1.5555555555555p-3,  odd ? -0x1.6c16c16c16c17p-10 : 0x1.1111111111111p-7,
+      odd ? 0x1.a01a01a01a01ap-16 : -0x1.a01a01a01a01ap-13, odd ? -0x1.27e4fb7789f5cp-22 : 0x1.71de3a556c734p-19,
+      odd ? 0x1.1eed8eff8d898p-29 : -0x1.ae64567f544e4p-26, odd ? -0x1.93974a8c07c9dp-37 : 0x1.6124613a86d09p-33,
+      odd ? 0x1.ae7f3e733b81fp-45 : -0x1.ae7f3e733b81fp-41, odd ? -0x1.6827863b97d97p-53 : 0x1.952c77030ad4ap-49);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double tail = (1.0 - w) - hz;
+  const double lead = odd ? w : r;
+  const double mul = odd ? z * z : z * r;
+  const double add = odd ? __builtin_fma(-r, rl, tail) : __builtin_fma(-hz, rl, rl);
+  return lead + __builtin_fma(mul, P, add);
 }
 
 __device__ __forceinline__ double psin(double x)
@@ -86,8 +106,7 @@ __device__ __forceinline__ double psin(double x)
   if (!(ax < 0x1p20)) return __builtin_nan("");
   if (ax < 0x1p-27) return x;
   int q = math_reduce(x, rh, rl);
-  double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
-  double v = (q & 1) ? c : s;
+  double v = math_ksincos(rh, rl, (q & 1) != 0);
   return (q & 2) ? -v : v;
 }
 
@@ -96,9 +115,8 @@ __device__ __forceinline__ double pcos(double x)
   double ax = __builtin_fabs(x), rh, rl;
   if (!(ax < 0x1p20)) return __builtin_nan("");
   if (ax < 0x1p-27) return 1.0;
-  int q = math_reduce(x, rh, rl);
-  double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
-  double v = (q & 1) ? -s : c;
+  int q = math_reduce(x, rh, rl) + 1;              // cos(x) = sin(x + pi/2)
+  double v = math_ksincos(rh, rl, (q & 1) != 0);
   return (q & 2) ? -v : v;
 }
 
@@ -112,8 +130,8 @@ __device__ __forceinline__ void psincos(double x, double &sn, double &cs)
   double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
   double vs = (q & 1) ? c : s;
   sn = (q & 2) ? -vs : vs;
-  double vc = (q & 1) ? -s : c;
-  cs = (q & 2) ? -vc : vc;
+  double vc = (q & 1) ? s : c;
+  cs = ((q + 1) & 2) ? -vc : vc;
 }
 
 // plog(x): x = m*2^k, m in [sqrt2/2, sqrt2); f = m-1; d = f+2; s = f/d;

@@ -59,6 +59,16 @@ class Runner:
     def sync(self, stream: int = 0):
         capi.check(self.lib.grlx_sync(self._ctx, C.c_void_p(stream)))
 
+    def set_diag(self, enable: bool = True):
+        capi.check(self.lib.grlx_set_diag(self._ctx, int(enable)))
+
+    def read_diag(self):
+        waves = (self.cfg.n_replicas + 3) // 4
+        out = np.zeros((waves, 8), np.uint64)
+        n = C.c_int()
+        capi.check(self.lib.grlx_read_diag(self._ctx, _ptr(out, C.c_uint64), waves, C.byref(n)))
+        return out[: n.value]
+
     def n_rows(self) -> int:
         return capi.check(self.lib.grlx_rows(self._ctx))
 

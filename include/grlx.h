@@ -150,6 +150,11 @@ int  grlx_curve_stats(grlx_ctx *ctx, int first, int count, double *out_dev, void
 /* counters: total env steps executed by all replicas since create */
 int  grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps);
 
+/* --- diagnostics: a separately compiled, stamped build of the rollout kernel
+ * (s_memtime per phase).  Its run time is NOT representative; only the shares. */
+int  grlx_set_diag(grlx_ctx *ctx, int enable);
+int  grlx_read_diag(grlx_ctx *ctx, uint64_t *out /*[waves][8] cycle sums*/, int cap_waves, int *n_waves);
+
 /* --- state inspection (parity tests) ------------------------------------ */
 int  grlx_get_env_state(grlx_ctx *ctx, int replica, double *state /*[GRLX_MAX_STATE]*/);
 int  grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4] /* G, TL, S1, S2 */);

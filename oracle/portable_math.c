@@ -14,12 +14,15 @@
  * compile with -ffp-contract=off):
  *
  *  reduce(x): fn = rint(x*INVPIO2); r0 = fma(-fn,P1,x)  [exact for |x|<2^20]
- *             p = fn*P2; pl = fma(fn,P2,-p); (r,e) = TwoSum(r0,-p)
- *             t = (e-pl) - fn*P3; rh = r+t; rl = (r-rh)+t; quadrant = fn mod 4
- *  ksin(r,rl): z=r*r; v=z*r; P = S2+z*(S3+...+z*S8) by fma-Horner;
- *              c = fma(v, fma(z,P,S1), fma(-0.5*z, rl, rl)); result r+c
- *  kcos(r,rl): z=r*r; hz=0.5*z; w=1-hz; tail=(1-w)-hz; Q = C1+z*(C2+...+z*C8);
- *              c = fma(z*z, Q, fma(-r, rl, tail)); result w+c
+ *             p = fn*P2; pl = fma(fn,P2,-p); r = r0-p; e = (r0-r)-p  [Fast2Sum]
+ *             t = (e-pl) - fn*P3;  reduced argument = r + t (NOT renormalised: the
+ *             kernels only need t to first order); quadrant = fn mod 4
+ *  poly(z; c1..c8) = Estrin: z2=z*z; z4=z2*z2;
+ *             a=fma(z,c2,c1); b=fma(z,c4,c3); c=fma(z,c6,c5); d=fma(z,c8,c7);
+ *             lo=fma(z2,b,a); hi=fma(z2,d,c); result fma(z4,hi,lo)
+ *  ksin(r,t): z=r*r; P=poly(z;S1..S8); result r + fma(z*r, P, fma(-0.5*z, t, t))
+ *  kcos(r,t): z=r*r; hz=0.5*z; w=1-hz; tail=(1-w)-hz; Q=poly(z;C1..C8);
+ *             result w + fma(z*z, Q, fma(-r, t, tail))
  *  Constants: tools/gen_math_constants.py (Taylor coefficients 1/k! and a
  *  three-double split of pi/2, all correctly rounded from exact rationals).
  *  Domain: |x| < 2^20 (NaN outside; the environments never get there).
@@ -71,26 +74,26 @@ static int reduce(double x, double *rh, double *rl)
   double p  = fn * PM_PIO2_2;
   double pl = fma(fn, PM_PIO2_2, -p);
   double r  = r0 - p;
-  double bb = r - r0;
-  double e  = (r0 - (r - bb)) + (-p - bb);
+  double e  = (r0 - r) - p;
   double t  = (e - pl) - fn * PM_PIO2_3;
-  double h  = r + t;
-  *rh = h;
-  *rl = (r - h) + t;
+  *rh = r;
+  *rl = t;
   return (int)((int64_t)fn & 3);
+}
+
+static double estrin8(double z, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double c8)
+{
+  double z2 = z * z, z4 = z2 * z2;
+  double a = fma(z, c2, c1), b = fma(z, c4, c3), c = fma(z, c6, c5), d = fma(z, c8, c7);
+  double lo = fma(z2, b, a), hi = fma(z2, d, c);
+  return fma(z4, hi, lo);
 }
 
 static double ksin(double r, double rl)
 {
-  double z = r * r, v = z * r;
-  double P = fma(z, PM_S8, PM_S7);
-  P = fma(z, P, PM_S6);
-  P = fma(z, P, PM_S5);
-  P = fma(z, P, PM_S4);
-  P = fma(z, P, PM_S3);
-  P = fma(z, P, PM_S2);
-  double c = fma(v, fma(z, P, PM_S1), fma(-0.5 * z, rl, rl));
-  return r + c;
+  double z = r * r;
+  double P = estrin8(z, PM_S1, PM_S2, PM_S3, PM_S4, PM_S5, PM_S6, PM_S7, PM_S8);
+  return r + fma(z * r, P, fma(-0.5 * z, rl, rl));
 }
 
 static double kcos(double r, double rl)
@@ -98,15 +101,8 @@ static double kcos(double r, double rl)
   double z = r * r, hz = 0.5 * z;
   double w = 1.0 - hz;
   double tail = (1.0 - w) - hz;
-  double Q = fma(z, PM_C8, PM_C7);
-  Q = fma(z, Q, PM_C6);
-  Q = fma(z, Q, PM_C5);
-  Q = fma(z, Q, PM_C4);
-  Q = fma(z, Q, PM_C3);
-  Q = fma(z, Q, PM_C2);
-  Q = fma(z, Q, PM_C1);
-  double c = fma(z * z, Q, fma(-r, rl, tail));
-  return w + c;
+  double Q = estrin8(z, PM_C1, PM_C2, PM_C3, PM_C4, PM_C5, PM_C6, PM_C7, PM_C8);
+  return w + fma(z * z, Q, fma(-r, rl, tail));
 }
 
 double orc_psin(double x)
