@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--table-log2", type=int, default=16)
+    ap.add_argument("--table-log2", type=int, default=17)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

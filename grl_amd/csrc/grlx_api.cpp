@@ -75,7 +75,7 @@ int make_tile_params(const grlx_tile_spec &ts, TileParams *tp)
 {
   if (ts.dims < 1 || ts.dims > GRLX_MAX_DIMS) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution (dims %d)", ts.dims);
   if (ts.tilings < 1 || ts.tilings > 32) return fail(GRLX_ERR_INVALID, "projector/tile_coding:tilings (%d)", ts.tilings);
-  if (ts.memory < 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:memory");
+  if (ts.memory < 1 || ts.memory >= (1 << 26)) return fail(GRLX_ERR_INVALID, "projector/tile_coding:memory (1 .. 2^26-1 supported)");
   memset(tp, 0, sizeof(*tp));
   tp->T = ts.tilings;
   tp->D = ts.dims;
@@ -263,7 +263,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   ctx->cfg = *cfg;
   env_dims(cfg->env, &ctx->S, &ctx->D);
   const int N = cfg->n_replicas;
-  uint32_t logC = cfg->table_log2_capacity ? (uint32_t)cfg->table_log2_capacity : 16u;
+  uint32_t logC = cfg->table_log2_capacity ? (uint32_t)cfg->table_log2_capacity : 17u;
   if (logC < 8 || logC > 26) { delete ctx; return fail(GRLX_ERR_INVALID, "table_log2_capacity must be in 8..26"); }
   P.n_replicas = N;
   P.logC = logC;

@@ -149,17 +149,34 @@ __device__ inline uint32_t tile_slot_generic(const TileParams &tp, const double 
 }
 
 // ---------------------------------------------------------- sparse table ---
+// One replica's weights: an open-addressing table of 64-byte buckets, 4 entries each,
+//   { key[4] (16 B) | aux[4] (16 B) | val[4] (32 B) }   = one fabric request per lookup.
+// key word: bits 0..25 reference slot index + 1 (0 = empty), bits 26..30 tiling that
+// created the entry, bit 31 "touched by a second tiling" (hash collision across tilings).
+// A lookup fetches the whole home bucket at once (3 x 16-byte loads in flight), so it
+// completes in ONE memory round trip unless the bucket is full (then: next bucket).
+// position = bucket * 4 + way; a position is stable for the life of the table.
+struct __attribute__((aligned(64))) Bucket {
+  uint32_t key[4];
+  uint32_t aux[4];
+  double   val[4];
+};
+static_assert(sizeof(Bucket) == 4 * sizeof(Entry), "a bucket is four 16-byte entries");
+
+constexpr uint32_t kKeyMask = 0x03FFFFFFu, kOwnerShift = 26, kSharedBit = 0x80000000u;
+
 struct Table {
-  Entry   *base;
-  uint32_t mask, shift;
+  Bucket  *base;
+  uint32_t bmask, shift;
 };
 
 __device__ __forceinline__ Table table_of(const DevParams &P, int table, int replica)
 {
   Table t;
-  t.base = P.tables + (((size_t)table * (size_t)P.n_replicas + (size_t)replica) << P.logC);
-  t.mask = (1u << P.logC) - 1u;
-  t.shift = 32u - P.logC;
+  Entry *e = P.tables + (((size_t)table * (size_t)P.n_replicas + (size_t)replica) << P.logC);
+  t.base = reinterpret_cast<Bucket *>(e);
+  t.bmask = (1u << (P.logC - 2)) - 1u;
+  t.shift = 32u - (P.logC - 2);
   return t;
 }
 
@@ -168,29 +185,33 @@ __device__ __forceinline__ uint32_t table_home(const Table &t, uint32_t slot)
   return ((slot + 1u) * 0x9E3779B1u) >> t.shift;
 }
 
-__device__ __forceinline__ uint4 entry_load(const Table &t, uint32_t pos)
+struct BucketRegs { uint4 k; double v[4]; };
+
+__device__ __forceinline__ BucketRegs bucket_load(const Table &t, uint32_t b)
 {
-  return *reinterpret_cast<const uint4 *>(&t.base[pos]);
+  BucketRegs r;
+  const Bucket *bp = &t.base[b];
+  r.k = *reinterpret_cast<const uint4 *>(bp->key);
+  const double2 v01 = *reinterpret_cast<const double2 *>(&bp->val[0]);
+  const double2 v23 = *reinterpret_cast<const double2 *>(&bp->val[2]);
+  r.v[0] = v01.x; r.v[1] = v01.y; r.v[2] = v23.x; r.v[3] = v23.y;
+  return r;
 }
 
-__device__ __forceinline__ double entry_val(const uint4 &raw)
+__device__ __forceinline__ uint4 bucket_keys(const Table &t, uint32_t b)
 {
-  return __longlong_as_double((long long)(((unsigned long long)raw.w << 32) | raw.z));
+  return *reinterpret_cast<const uint4 *>(t.base[b].key);
 }
 
-__device__ __forceinline__ void entry_store(const Table &t, uint32_t pos, uint32_t key, double v)
-{
-  unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  uint4 raw;
-  raw.x = key;
-  raw.y = 0;
-  raw.z = (uint32_t)b;
-  raw.w = (uint32_t)(b >> 32);
-  *reinterpret_cast<uint4 *>(&t.base[pos]) = raw;
-}
+__device__ __forceinline__ void value_store(const Table &t, uint32_t pos, double v) { t.base[pos >> 2].val[pos & 3u] = v; }
+__device__ __forceinline__ double value_load(const Table &t, uint32_t pos) { return t.base[pos >> 2].val[pos & 3u]; }
 
-__device__ __forceinline__ void value_store(const Table &t, uint32_t pos, double v) { t.base[pos].val = v; }
-__device__ __forceinline__ double value_load(const Table &t, uint32_t pos) { return t.base[pos].val; }
+__device__ __forceinline__ void entry_create(const Table &t, uint32_t pos, uint32_t slot, uint32_t owner, double v)
+{
+  Bucket *bp = &t.base[pos >> 2];
+  bp->key[pos & 3u] = (slot + 1u) | (owner << kOwnerShift);
+  bp->val[pos & 3u] = v;
+}
 
 // order LDS / global accesses of the lanes of one wave (no instruction beyond waits)
 __device__ __forceinline__ void wave_sync()
@@ -199,68 +220,104 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_wave_barrier();
 }
 
-// Probe sequence.  Entries are grouped in 128-byte buckets of 8 (one cache line): the
-// t-th probe of a slot stays inside its home bucket for t < 8 (so every probe after
-// the first is an L1 hit) and moves to the following buckets only when a bucket is full.
-__device__ __forceinline__ uint32_t probe_pos(const Table &t, uint32_t home, uint32_t n)
+// way of `slot` in a loaded bucket (0..3) or -1; *empty = bit mask of empty ways
+__device__ __forceinline__ int bucket_find(const uint4 &k, uint32_t slot, uint32_t &empty)
 {
-  uint32_t bucket = ((home >> 3) + (n >> 3)) & (t.mask >> 3);
-  return (bucket << 3) | ((home + n) & 7u);
+  const uint32_t want = slot + 1u;
+  const uint32_t k0 = k.x & kKeyMask, k1 = k.y & kKeyMask, k2 = k.z & kKeyMask, k3 = k.w & kKeyMask;
+  empty = (k0 == 0u ? 1u : 0u) | (k1 == 0u ? 2u : 0u) | (k2 == 0u ? 4u : 0u) | (k3 == 0u ? 8u : 0u);
+  int way = -1;
+  way = (k3 == want) ? 3 : way;
+  way = (k2 == want) ? 2 : way;
+  way = (k1 == want) ? 1 : way;
+  way = (k0 == want) ? 0 : way;
+  return way;
 }
 
-// Resolve NP independent lookups of one lane at once: the first-round loads of all of
-// them are in flight together (one memory round trip per step in the common case).
-// found[i]: position of the entry (hit) or of the first empty position (miss).
-template <int NP>
-__device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&slot)[NP], uint32_t (&home)[NP], uint32_t (&tries)[NP],
-                                             double (&val)[NP], bool (&miss)[NP], uint32_t &status)
+// State of one lookup.  hit: pos/val valid.  miss: `bucket` is the first bucket of the
+// probe sequence with an empty way and `empty` its empty-way mask (as loaded).
+struct Lookup {
+  uint32_t bucket, empty, pos;
+  uint32_t kw;                  // key word of the entry found (owner tiling, shared bit); 0 when created by this lane
+  bool     miss;
+};
+
+__device__ __forceinline__ uint32_t bucket_kw(const uint4 &k, int way)
 {
-  uint4 raw[NP];
-  bool pending[NP];
+  return (way == 0) ? k.x : (way == 1) ? k.y : (way == 2) ? k.z : k.w;
+}
+
+// Resolve NP independent lookups of one lane with all first-round loads in flight together.
+template <int NP>
+__device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], double (&val)[NP], uint32_t &status)
+{
+  BucketRegs br[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i)
   {
-    home[i] = table_home(t, slot[i]);
-    tries[i] = 0;
-    raw[i] = entry_load(t, probe_pos(t, home[i], 0));
-    pending[i] = true;
-    miss[i] = false;
+    lk[i].bucket = table_home(t, slot[i]);
+    br[i] = bucket_load(t, lk[i].bucket);
   }
-  for (int it = 0; it < kMaxProbe; ++it)
+  bool pending[NP];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
   {
-    bool any = false;
+    const int way = bucket_find(br[i].k, slot[i], lk[i].empty);
+    lk[i].miss = false;
+    lk[i].kw = 0u;
+    pending[i] = false;
+    if (way >= 0)
+    {
+      lk[i].pos = (lk[i].bucket << 2) | (uint32_t)way;
+      lk[i].kw = bucket_kw(br[i].k, way);
+      val[i] = (way == 0) ? br[i].v[0] : (way == 1) ? br[i].v[1] : (way == 2) ? br[i].v[2] : br[i].v[3];
+    }
+    else if (lk[i].empty != 0u)
+      lk[i].miss = true;
+    else
+    {
+      pending[i] = true;                           // home bucket full of other slots: overflow chain
+      any = true;
+    }
+  }
+  if (__any(any))
+  { // rare: walk the following buckets
+    for (int it = 1; it < kMaxProbe; ++it)
+    {
+      bool more = false;
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (pending[i])
+        {
+          lk[i].bucket = (lk[i].bucket + 1u) & t.bmask;
+          const BucketRegs b2 = bucket_load(t, lk[i].bucket);
+          const int way = bucket_find(b2.k, slot[i], lk[i].empty);
+          if (way >= 0)
+          {
+            lk[i].pos = (lk[i].bucket << 2) | (uint32_t)way;
+            lk[i].kw = bucket_kw(b2.k, way);
+            val[i] = (way == 0) ? b2.v[0] : (way == 1) ? b2.v[1] : (way == 2) ? b2.v[2] : b2.v[3];
+            pending[i] = false;
+          }
+          else if (lk[i].empty != 0u) { lk[i].miss = true; pending[i] = false; }
+          else more = true;
+        }
+      if (!__any(more)) break;
+    }
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      if (pending[i])
-      {
-        if (raw[i].x == slot[i] + 1u) { val[i] = entry_val(raw[i]); pending[i] = false; }
-        else if (raw[i].x == 0u) { miss[i] = true; pending[i] = false; }
-        else
-        {
-          tries[i]++;
-          raw[i] = entry_load(t, probe_pos(t, home[i], tries[i]));
-          any = true;
-        }
-      }
-    if (!any) break;
+      if (pending[i]) status |= ST_TABLE_FULL;
   }
-#pragma unroll
-  for (int i = 0; i < NP; ++i)
-    if (pending[i]) status |= ST_TABLE_FULL;
 }
 
-// Create the slots that were missing, with their lazy initial weights.  Lanes of one
-// replica may miss on the same empty position, so inserts are serialised within each
-// 16-lane group (one lane per group at a time); they are rare (about 17 k per replica
-// over a whole pendulum run).
-__device__ inline void table_insert(const Table &t, const LinearParams &lp, uint64_t tl0, bool miss,
-                                    uint32_t slot, uint32_t home, uint32_t &tries, double &val, uint32_t &status, uint32_t &inserted)
+// Serialised insert (one lane per 16-lane group at a time), re-reading the bucket: used for
+// the lanes the parallel path could not place (conflicts), and by the fine-grained operators.
+__device__ inline void table_insert_serial(const Table &t, bool todo, uint32_t slot, uint32_t owner, double w0,
+                                           Lookup &lk, double &val, uint32_t &status, uint32_t &inserted)
 {
   const int lane = threadIdx.x & 63;
-  unsigned long long pend = __ballot(miss);
-  if (pend == 0ull) return;
-  double w0 = 0.0;
-  if (miss) w0 = lazy_weight(tl0, lp, slot);
+  unsigned long long pend = __ballot(todo);
   while (pend != 0ull)
   {
     unsigned long long sel = 0ull;                 // lowest pending lane of every 16-lane group goes now
@@ -273,41 +330,63 @@ __device__ inline void table_insert(const Table &t, const LinearParams &lp, uint
     if ((sel >> lane) & 1ull)
     {
       bool done = false;
+      uint32_t b = lk.bucket;
       for (int it = 0; it < kMaxProbe; ++it)
       {
-        const uint32_t p = probe_pos(t, home, tries);
-        uint4 raw = entry_load(t, p);
-        if (raw.x == slot + 1u) { val = entry_val(raw); done = true; break; }   // a sibling lane created it
-        if (raw.x == 0u)
+        const BucketRegs br = bucket_load(t, b);
+        uint32_t empty;
+        const int way = bucket_find(br.k, slot, empty);
+        if (way >= 0)
+        { // a sibling lane created it meanwhile
+          lk.pos = (b << 2) | (uint32_t)way;
+          lk.kw = bucket_kw(br.k, way);
+          val = (way == 0) ? br.v[0] : (way == 1) ? br.v[1] : (way == 2) ? br.v[2] : br.v[3];
+          done = true;
+          break;
+        }
+        if (empty != 0u)
         {
-          entry_store(t, p, slot + 1u, w0);
+          const uint32_t w = (uint32_t)__builtin_ctz(empty);
+          lk.pos = (b << 2) | w;
+          lk.kw = 0u;
+          entry_create(t, lk.pos, slot, owner, w0);
           val = w0;
           inserted++;
           done = true;
           break;
         }
-        tries++;
+        b = (b + 1u) & t.bmask;
       }
       if (!done) status |= ST_TABLE_FULL;
     }
     pend &= ~sel;
-    // The next lane's probe must observe this insert.  Both are vector memory operations
-    // of the same wave issued in this order, which the hardware keeps for one address;
-    // the fence only stops the compiler from reordering them.
+    // The next lane's probe must observe this insert.  Both are vector memory operations of
+    // the same wave issued in this order, which the hardware keeps for one address; the
+    // fence only stops the compiler from reordering them.
     wave_sync();
   }
 }
 
-// single lookup-or-create (fine-grained operators)
+// single lookup-or-create (fine-grained operators): lane = tiling
 __device__ inline void table_probe(const Table &t, const LinearParams &lp, uint64_t tl0, bool active,
                                    uint32_t slot, uint32_t &pos, double &val, uint32_t &status, uint32_t &inserted)
 {
-  uint32_t sl[1] = {slot}, home[1] = {0}, tries[1] = {0};
+  uint32_t sl[1] = {slot};
+  Lookup lk[1];
+  lk[0].bucket = 0; lk[0].empty = 0; lk[0].pos = 0; lk[0].kw = 0; lk[0].miss = false;
   double v[1] = {0};
-  bool miss[1] = {false};
-  if (active) table_lookup<1>(t, sl, home, tries, v, miss, status);
-  table_insert(t, lp, tl0, active && miss[0], slot, home[0], tries[0], v[0], status, inserted);
-  pos = probe_pos(t, home[0], tries[0]);
+  if (active) table_lookup<1>(t, sl, lk, v, status);
+  const bool miss = active && lk[0].miss;
+  double w0 = 0;
+  if (__any(miss))
+  {
+    if (miss) w0 = lazy_weight(tl0, lp, slot);
+    table_insert_serial(t, miss, slot, (uint32_t)(threadIdx.x & 31), w0, lk[0], v[0], status, inserted);
+  }
+  // keep the "touched by a second tiling" bit current (the fused kernel relies on it)
+  if (active && lk[0].kw != 0u && ((lk[0].kw >> kOwnerShift) & 31u) != (uint32_t)(threadIdx.x & 31) && !(lk[0].kw & kSharedBit))
+    t.base[lk[0].pos >> 2].key[lk[0].pos & 3u] = lk[0].kw | kSharedBit;
+  pos = lk[0].pos;
   val = v[0];
 }
 
@@ -473,14 +552,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   __shared__ uint32_t sh_ppos[4 * 16];
   __shared__ double   sh_fb[16 * 4];
   __shared__ uint32_t sh_fbflag[16 * 4];
+  __shared__ uint32_t sh_mb[4][NA * 16];       // parallel insert: claimed bucket per (action, tiling), ~0 = none
+  __shared__ uint32_t sh_ms[4][NA * 16];       //                  and the slot claiming it
+  __shared__ uint32_t sh_mail[4];              // position of a slot that just became shared between tilings
 
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   const int r_raw = blockIdx.x * kReplicasPerWave + g;
   const bool live = r_raw < P.n_replicas;
   const int r = live ? r_raw : 0;
-  constexpr int A = NA;
   const bool tapped = live && (r == P.tap_replica);
+  const unsigned long long gmask = 0xFFFFull << (16 * g);
 
   ReplicaState &RS = P.states[r];
   double x[S];
@@ -495,19 +577,29 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
   const Table tab = table_of(P, 0, r);
   const double out_min = P.lin.out_min, out_max = P.lin.out_max;
+  const bool limit = P.lin.limit != 0;
   const double ee = P.gl;                       // pow(gamma*lambda, tau), tau = 1 (discrete_time)
   const double cut = (P.trace_kind == GRLX_TRACE_REPLACING) ? 0.01 : 0.0001;
+  const bool use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
 
-  // register-resident replacing trace (trace.h:208-235), newest first
+  // Register-resident replacing trace (trace.h:208-235), newest first.  tr_val is the
+  // AUTHORITATIVE weight of the slot while it is in the trace: it is written back to the
+  // table only when the slot leaves the trace (write-back), unless the slot is shared with
+  // another tiling (bit e of tr_wt), in which case every update is also stored (write-through)
+  // so that the other lane's loads see it.
   uint32_t tr_pos[kMaxTrace];
   double   tr_val[kMaxTrace];
   uint32_t tr_cnt[kMaxTrace];
+  uint32_t tr_wt = 0;
 #pragma unroll
   for (int e = 0; e < kMaxTrace; ++e) { tr_pos[e] = kInvalidPos; tr_val[e] = 0; tr_cnt[e] = 0; }
   int    tr_len = 0;
+  int    tr_len_ref = 0;        // length as the reference reports it (its trace survives test trials)
   double tr_total = 1.;
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
   if (DIAG) diag_last = stamp();
+
+  auto add_clamped = [&](double v, double d) { return limit ? clampd(v + d, out_min, out_max) : v + d; };
 
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
@@ -523,18 +615,14 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
       Env<ENV>::start(P, test, TL, G, x);
       Env<ENV>::observe(P, x, obs);
     }
-    // agent->start: TDAgent::start clears the trace (td.cpp:50-61, sarsa.cpp:126-132)
-    if (!test)
-    {
-#pragma unroll
-      for (int e = 0; e < kMaxTrace; ++e) tr_pos[e] = kInvalidPos;
-      tr_len = 0;
-      tr_total = 1.;
-    }
+    // agent->start: TDAgent::start clears the trace (td.cpp:50-61, sarsa.cpp:126-132); the
+    // trace was written back at the end of the previous learning trial, so it is empty here
     double time = 0;
     double action = 0;
     int    action_index = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0;
+    bool   p_sh = false;
+    if (!test) tr_len_ref = 0;          // TDAgent::start -> trace_->clear()
     bool first = true;                    // first pass = start(): act only, no env step / update
 
     for (;;)
@@ -557,20 +645,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         double q[NA];
         uint32_t slot[NA], pos[NA];
         double w[NA];
+        bool sh[NA];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) { q[a] = 0; slot[a] = 0; pos[a] = 0; w[a] = 0; }
+        for (int a = 0; a < NA; ++a) { q[a] = 0; slot[a] = 0; pos[a] = kInvalidPos; w[a] = 0; sh[a] = false; }
         double wp = 0;
         const bool update = !first && !test;                               // a TD update follows
         if (has_next)
         {
-          int qd[GRLX_MAX_DIMS];
           uint32_t hpre = 449u ^ (uint32_t)(D + 2);
 #pragma unroll
           for (int i = 0; i < D; ++i)
-          {
-            qd[i] = tile_quant(P.tile, i, obs[i]);
-            hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, qd[i], j));
-          }
+            hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, tile_quant(P.tile, i, obs[i]), j));
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
@@ -581,29 +666,154 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           }
         }
         DIAG_STAMP(2)
-        // previous step's stores precede these loads in program order; they were issued
-        // a full RK4 ago, so this wait is free and makes the ordering explicit
+        // every store of the previous step precedes these loads in program order (issued a
+        // full RK4 ago, so this wait is free; it makes the ordering explicit)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         DIAG_STAMP(6)
-        if (update) wp = value_load(tab, p_pos);                           // current weights of project(s, a)
+        if (update) wp = value_load(tab, p_pos);                           // weights of project(s, a) as stored
         if (has_next)
         {
-          uint32_t home[NA], tries[NA];
-          bool miss[NA];
-          table_lookup<NA>(tab, slot, home, tries, w, miss, status);
+          Lookup lk[NA];
+          table_lookup<NA>(tab, slot, lk, w, status);
           DIAG_STAMP(7)
+          bool anymiss = false;
 #pragma unroll
-          for (int a = 0; a < NA; ++a)
-            table_insert(tab, P.lin, TL0, miss[a], slot[a], home[a], tries[a], w[a], status, inserted);
+          for (int a = 0; a < NA; ++a) anymiss = anymiss || lk[a].miss;
+          if (__any(anymiss))
+          { // Create the missing slots.  All lookups of this step are complete, so every lane
+            // that misses into bucket B saw the same empty ways of B.  Claims are ranked in the
+            // fixed order (action, tiling) through LDS: the r-th claimant of a bucket takes its
+            // r-th empty way -- no reload, all lanes in parallel.  Equal slots claimed twice
+            // (a hash collision inside one state) or a bucket with too few empty ways fall back
+            // to the serialised path.
+            double w0[NA];
+            bool slow[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+            {
+              sh_mb[g][a * 16 + j] = lk[a].miss ? lk[a].bucket : 0xFFFFFFFFu;
+              sh_ms[g][a * 16 + j] = slot[a];
+              w0[a] = 0;
+              slow[a] = false;
+              if (lk[a].miss) w0[a] = lazy_weight(TL0, P.lin, slot[a]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+              if (lk[a].miss)
+              {
+                const int me = a * 16 + j;
+                uint32_t rank = 0;
+                bool dup = false;
+                for (int k = 0; k < NA * 16; ++k)
+                {
+                  const uint32_t ob = sh_mb[g][k], os = sh_ms[g][k];
+                  if (ob == lk[a].bucket && k != me)
+                  {
+                    if (os == slot[a]) dup = true;
+                    else if (k < me) rank++;
+                  }
+                }
+                uint32_t e = lk[a].empty;
+                for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;      // drop the ways taken by earlier claimants
+                if (dup || e == 0u)
+                  slow[a] = true;
+                else
+                {
+                  lk[a].pos = (lk[a].bucket << 2) | (uint32_t)__builtin_ctz(e);
+                  lk[a].kw = 0u;
+                  entry_create(tab, lk[a].pos, slot[a], (uint32_t)j, w0[a]);
+                  w[a] = w0[a];
+                  inserted++;
+                }
+              }
+            wave_sync();
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+              if (__any(slow[a]))
+                table_insert_serial(tab, slow[a], slot[a], (uint32_t)j, w0[a], lk[a], w[a], status, inserted);
+          }
+
+          // ---- slots shared between tilings (a collision of the reference's hash across
+          // tilings, ~70 per replica and run).  A slot found with a foreign owner and no shared
+          // bit yet is a NEW sharing event: mark it in the table and tell the owner's lane, whose
+          // trace may hold the only current copy of the weight.
+          bool fresh[NA];
+          bool anyfresh = false;
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
-            pos[a] = probe_pos(tab, home[a], tries[a]);
-            SHW(a, j, g) = w[a];
+            pos[a] = lk[a].pos;
+            const bool found = lk[a].kw != 0u;
+            const bool foreign = found && ((lk[a].kw >> kOwnerShift) & 31u) != (uint32_t)j;
+            sh[a] = found && (foreign || (lk[a].kw & kSharedBit) != 0u);
+            fresh[a] = foreign && (lk[a].kw & kSharedBit) == 0u;
+            anyfresh = anyfresh || fresh[a];
           }
+          if (__any(anyfresh))
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+            {
+              if (fresh[a]) tab.base[pos[a] >> 2].key[pos[a] & 3u] = lk[a].kw | kSharedBit;
+              unsigned long long pend = __ballot(fresh[a]);
+              while (pend != 0ull)
+              { // one event per 16-lane group at a time
+                unsigned long long sel = 0ull;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                {
+                  unsigned long long grp = pend & (0xFFFFull << (16 * gg));
+                  sel |= grp & (~grp + 1ull);
+                }
+                const bool mine = ((sel >> lane) & 1ull) != 0ull;
+                const bool grp_has = (sel & gmask) != 0ull;
+                if (mine) sh_mail[g] = pos[a];
+                wave_sync();
+                if (grp_has)
+                {
+                  const uint32_t mp = sh_mail[g];
+                  // owner side: write the cached weight back and switch the entry to write-through
+#pragma unroll
+                  for (int e = 0; e < kMaxTrace; ++e)
+                    if (tr_pos[e] == mp && !((tr_wt >> e) & 1u))
+                    {
+                      value_store(tab, mp, tr_val[e]);
+                      tr_wt |= 1u << e;
+                    }
+                  if (p_pos == mp) p_sh = true;
+#pragma unroll
+                  for (int b2 = 0; b2 < NA; ++b2)
+                    if (pos[b2] == mp) sh[b2] = true;
+                }
+                wave_sync();
+                if (mine) w[a] = value_load(tab, pos[a]);       // the value the owner just wrote back
+                pend &= ~sel;
+              }
+            }
+            if (update) wp = value_load(tab, p_pos);
+          }
+
+          // ---- forward from the trace: a slot that is in this lane's trace has its current
+          // weight in tr_val, not (yet) in the table
+#pragma unroll
+          for (int e = 0; e < kMaxTrace; ++e)
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+              w[a] = (tr_pos[e] == pos[a]) ? tr_val[e] : w[a];
+          }
+#pragma unroll
+          for (int a = 0; a < NA; ++a) SHW(a, j, g) = w[a];
+        }
+        if (update)
+        {
+#pragma unroll
+          for (int e = 0; e < kMaxTrace; ++e)
+            wp = (tr_pos[e] == p_pos) ? tr_val[e] : wp;
+          SHW(NA, j, g) = wp;
         }
         DIAG_STAMP(3)
-        if (update) SHW(NA, j, g) = wp;
         sh_ppos[g * 16 + j] = p_pos;
         sh_fbflag[j * 4 + g] = 0u;
         wave_sync();
@@ -648,7 +858,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             if (rnd < eps_decay * P.epsilon)
             {
               G = lcg_next(G);
-              a_next = (int)(lcg_long(G) % (uint32_t)A);
+              a_next = (int)(lcg_long(G) % (uint32_t)NA);
             }
             else
               a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
@@ -677,91 +887,137 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           const double dW = P.alpha * (target - qsa);          // LinearRepresentation::write (linear.cpp:186-196)
           const double dT = P.alpha * delta;                   // VectorConstructor(alpha_*delta)
 
-          // positions of p for the 16 tilings of this replica
-          uint32_t pp[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) pp[k] = sh_ppos[g * 16 + k];
-          uint32_t cp = 0;                                     // duplicates of my slot inside p
-#pragma unroll
-          for (int k = 0; k < 16; ++k) cp += (pp[k] == p_pos) ? 1u : 0u;
-
-          // trace entries, newest first (representation.h:79-83, trace.h:150-178)
-          if (P.trace_kind == GRLX_TRACE_REPLACING)
-          {
+          // Cross-lane aliasing needs a lane whose p is a slot shared between tilings (only such
+          // a slot can sit in another lane's trace, or twice in p).  Otherwise every lane works
+          // on its own registers.
+          const bool cross = (__ballot(p_sh) & gmask) != 0ull;
+          double v;                                            // final weight of p's slot after this step
+          uint32_t cp = 1;
+          if (!cross)
+          { // ---- common case: aliasing between p and the trace can only happen inside a lane
             double weight = 1.;
-            bool upd = true;
-#pragma unroll
-            for (int e = 0; e < kMaxTrace; ++e)
+            bool upd = true, aliased = false;
+            double v_alias = 0;
+            if (use_trace)
             {
-              if (e < tr_len)
-              {
-                upd = upd && (weight > 0.001);
-                const double de = weight * dT * ee;
-                if (tr_pos[e] != kInvalidPos)
-                {
-                  uint32_t m = 0;
 #pragma unroll
-                  for (int k = 0; k < 16; ++k) m |= (pp[k] == tr_pos[e]) ? (1u << k) : 0u;
-                  if (m == 0u)
+              for (int e = 0; e < kMaxTrace; ++e)
+                if (e < tr_len)
+                {
+                  upd = upd && (weight > 0.001);                 // representation.h:81
+                  const double de = weight * dT * ee;
+                  if (tr_pos[e] != kInvalidPos)
                   {
-                    if (upd)
-                    { // LinearRepresentation::update (linear.cpp:198-216), duplicates applied tr_cnt times
-                      double v = tr_val[e];
-                      for (uint32_t c = 0; c < tr_cnt[e]; ++c)
-                        v = P.lin.limit ? clampd(v + de, out_min, out_max) : v + de;
-                      tr_val[e] = v;
-                      value_store(tab, tr_pos[e], v);
+                    if (tr_pos[e] == p_pos)
+                    { // p's write first, then this entry's update; the slot leaves the trace (ssub)
+                      if (upd) { v_alias = add_clamped(add_clamped(tr_val[e], dW), de); aliased = true; }
+                      tr_pos[e] = kInvalidPos;
+                    }
+                    else if (upd)
+                    {
+                      if ((tr_wt >> e) & 1u)
+                      { // shared slot (possibly twice in its projection): keep the table current
+                        double vv = tr_val[e];
+                        for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
+                        tr_val[e] = vv;
+                        value_store(tab, tr_pos[e], vv);
+                      }
+                      else
+                        tr_val[e] = add_clamped(tr_val[e], de);
                     }
                   }
-                  else
-                  { // this slot is also written through p: p's write comes first, then this entry's update;
-                    // the slot leaves the trace (IndexProjection::ssub, projection.h:94-104)
-                    if (upd)
+                  weight *= ee;
+                }
+            }
+            v = aliased ? v_alias : add_clamped(wp, dW);
+          }
+          else
+          { // ---- general case: positions of p for the 16 tilings of this replica via LDS
+            uint32_t pp[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) pp[k] = sh_ppos[g * 16 + k];
+            cp = 0;                                            // duplicates of my slot inside p
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cp += (pp[k] == p_pos) ? 1u : 0u;
+            if (use_trace)
+            {
+              double weight = 1.;
+              bool upd = true;
+#pragma unroll
+              for (int e = 0; e < kMaxTrace; ++e)
+              {
+                if (e < tr_len)
+                {
+                  upd = upd && (weight > 0.001);
+                  const double de = weight * dT * ee;
+                  if (tr_pos[e] != kInvalidPos)
+                  {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m |= (pp[k] == tr_pos[e]) ? (1u << k) : 0u;
+                    if (m == 0u)
                     {
-                      double v = tr_val[e];
-                      const uint32_t cpx = (uint32_t)__builtin_popcount(m);
-                      for (uint32_t c = 0; c < cpx; ++c)
-                        v = P.lin.limit ? clampd(v + dW, out_min, out_max) : v + dW;
-                      for (uint32_t c = 0; c < tr_cnt[e]; ++c)
-                        v = P.lin.limit ? clampd(v + de, out_min, out_max) : v + de;
-                      for (uint32_t mm = m; mm != 0u; mm &= mm - 1u)
-                      {
-                        int k = __builtin_ctz(mm);
-                        sh_fb[k * 4 + g] = v;
-                        sh_fbflag[k * 4 + g] = 1u;
+                      if (upd)
+                      { // LinearRepresentation::update (linear.cpp:198-216), duplicates applied tr_cnt times
+                        double vv = tr_val[e];
+                        for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
+                        tr_val[e] = vv;
+                        if ((tr_wt >> e) & 1u) value_store(tab, tr_pos[e], vv);
                       }
                     }
-                    tr_pos[e] = kInvalidPos;
+                    else
+                    { // also written through p: p's write comes first, then this entry's update;
+                      // the slot leaves the trace (IndexProjection::ssub, projection.h:94-104)
+                      if (upd)
+                      {
+                        double vv = tr_val[e];
+                        const uint32_t cpx = (uint32_t)__builtin_popcount(m);
+                        for (uint32_t c = 0; c < cpx; ++c) vv = add_clamped(vv, dW);
+                        for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
+                        for (uint32_t mm = m; mm != 0u; mm &= mm - 1u)
+                        {
+                          int k = __builtin_ctz(mm);
+                          sh_fb[k * 4 + g] = vv;
+                          sh_fbflag[k * 4 + g] = 1u;
+                        }
+                      }
+                      tr_pos[e] = kInvalidPos;
+                      tr_wt &= ~(1u << e);
+                    }
                   }
+                  weight *= ee;
                 }
-                weight *= ee;
               }
             }
+            wave_sync();
+            if (sh_fbflag[j * 4 + g] != 0u)
+              v = sh_fb[j * 4 + g];
+            else
+            {
+              v = wp;
+              for (uint32_t c = 0; c < cp; ++c) v = add_clamped(v, dW);
+            }
           }
-          wave_sync();
-          // p's own write (linear.cpp:186-216): cp sequential additions of dW
-          double v;
-          if (sh_fbflag[j * 4 + g] != 0u)
-            v = sh_fb[j * 4 + g];
-          else
-          {
-            v = wp;
-            for (uint32_t c = 0; c < cp; ++c)
-              v = P.lin.limit ? clampd(v + dW, out_min, out_max) : v + dW;
-          }
-          value_store(tab, p_pos, v);
+          // a shared slot is kept current in the table; an exclusive one only if no trace follows
+          if (p_sh || !use_trace) value_store(tab, p_pos, v);
 
           // trace_->add(p, decay) (trace.h:215-234)
-          if (P.trace_kind == GRLX_TRACE_REPLACING)
+          if (use_trace)
           {
             if (ee < cut)
-            {
+            { // decay below the cut: clear() first
 #pragma unroll
-              for (int e = 0; e < kMaxTrace; ++e) tr_pos[e] = kInvalidPos;
+              for (int e = 0; e < kMaxTrace; ++e)
+              {
+                if (tr_pos[e] != kInvalidPos && !((tr_wt >> e) & 1u)) value_store(tab, tr_pos[e], tr_val[e]);
+                tr_pos[e] = kInvalidPos;
+              }
+              tr_wt = 0;
               tr_len = 0;
               tr_total = 1.;
             }
             if (tr_len >= kMaxTrace) status |= ST_TRACE_OVERFLOW;
+            // the entry that falls off the end of the register file (never valid: validated at create)
 #pragma unroll
             for (int e = kMaxTrace - 1; e > 0; --e)
             {
@@ -769,9 +1025,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
               tr_val[e] = tr_val[e - 1];
               tr_cnt[e] = tr_cnt[e - 1];
             }
+            tr_wt = (tr_wt << 1) & ((1u << kMaxTrace) - 1u);
             tr_pos[0] = p_pos;
             tr_val[0] = v;
             tr_cnt[0] = cp;
+            if (p_sh) tr_wt |= 1u;
             tr_len = (tr_len < kMaxTrace) ? tr_len + 1 : kMaxTrace;
             tr_total *= ee;
             while (tr_total < cut && tr_len > 1)
@@ -779,12 +1037,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
               tr_total /= ee;
               tr_len--;
             }
+            // entries popped off the front of the reference's deque: write their weights back
 #pragma unroll
             for (int e = 0; e < kMaxTrace; ++e)
-              if (e >= tr_len) tr_pos[e] = kInvalidPos;
+              if (e >= tr_len)
+              {
+                if (tr_pos[e] != kInvalidPos && !((tr_wt >> e) & 1u)) value_store(tab, tr_pos[e], tr_val[e]);
+                tr_pos[e] = kInvalidPos;
+                tr_wt &= ~(1u << e);
+              }
           }
         }
 
+        if (update) tr_len_ref = tr_len;
         DIAG_STAMP(5)
         // -------- tap (debug / parity tests)
         if (tapped && !first)
@@ -800,7 +1065,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
               tp->test = test;
               tp->action_index = has_next ? a_next : action_index;
               tp->terminal = terminal;
-              tp->trace_len = tr_len;
+              tp->trace_len = tr_len_ref;
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? P.actions[a_next] : action;
               tp->reward = reward;
@@ -826,10 +1091,26 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           action = P.actions[a_next];                                      // discretizer_->at(index), uniform.cpp:140-151
           p_pos = pick<uint32_t, NA>(pos, a_next);
           p_slot = pick<uint32_t, NA>(slot, a_next);
+          p_sh = pick<bool, NA>(sh, a_next);
         }
         if (!first && terminal) running = false;
         first = false;
       }
+    }
+
+    // end of the trial: the trace is cleared by the next TDAgent::start (td.cpp:54); write the
+    // cached weights back now so that test trials and the host see them
+    if (!test)
+    {
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+      {
+        if (tr_pos[e] != kInvalidPos && !((tr_wt >> e) & 1u)) value_store(tab, tr_pos[e], tr_val[e]);
+        tr_pos[e] = kInvalidPos;
+      }
+      tr_wt = 0;
+      tr_len = 0;
+      tr_total = 1.;
     }
 
     // row of a test trial (online_learning.cpp:238-262) -- or of every trial when test_interval < 0
@@ -1026,13 +1307,16 @@ __global__ void get_weights_kernel(DevParams P, int table, int replica, const ui
   if (i >= n) return;
   const Table tab = table_of(P, table, replica);
   uint32_t slot = slots[i];
-  const uint32_t home = table_home(tab, slot);
+  uint32_t b = table_home(tab, slot);
   double v = lazy_weight(P.states[replica].TL0, P.lin, slot);
   for (int it = 0; it < kMaxProbe; ++it)
   {
-    uint4 raw = entry_load(tab, probe_pos(tab, home, (uint32_t)it));
-    if (raw.x == slot + 1u) { v = entry_val(raw); break; }
-    if (raw.x == 0u) break;
+    const BucketRegs br = bucket_load(tab, b);
+    uint32_t empty;
+    const int way = bucket_find(br.k, slot, empty);
+    if (way >= 0) { v = (way == 0) ? br.v[0] : (way == 1) ? br.v[1] : (way == 2) ? br.v[2] : br.v[3]; break; }
+    if (empty != 0u) break;
+    b = (b + 1u) & tab.bmask;
   }
   out[i] = v;
 }

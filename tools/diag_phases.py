@@ -9,7 +9,7 @@ import grl_amd
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 11
-logc = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+logc = int(sys.argv[3]) if len(sys.argv) > 3 else 17
 cfg = grl_amd.pendulum_sarsa_config(n, max_rows=64, table_log2_capacity=logc)
 r = grl_amd.Runner(cfg, np.arange(1, n + 1))
 r.run(33); r.sync()                       # warm tables
