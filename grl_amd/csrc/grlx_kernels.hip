@@ -313,7 +313,7 @@ __device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&sl
 
 // Serialised insert (one lane per 16-lane group at a time), re-reading the bucket: used for
 // the lanes the parallel path could not place (conflicts), and by the fine-grained operators.
-__device__ inline void table_insert_serial(const Table &t, bool todo, uint32_t slot, uint32_t owner, double w0,
+__device__ __noinline__ void table_insert_serial(const Table &t, bool todo, uint32_t slot, uint32_t owner, double w0,
                                            Lookup &lk, double &val, uint32_t &status, uint32_t &inserted)
 {
   const int lane = threadIdx.x & 63;
@@ -414,6 +414,7 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
     x[2] = 0;
   }
   __device__ static __forceinline__ double actuate(double a) { return fmin(fmax(a, -3.0), 3.0); }   // :105-109
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[0]) < 0x1p19; }
   __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
   { // :111-129
     double a = pfmod(x[0] + GRLX_PI, GRLX_2PI);
@@ -433,45 +434,52 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
   }
 };
 
-// DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps
+// DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps.
+// The last state component is time (xd = 1 in every supported dynamics, and no eom reads
+// it), so its stage values are the constant h and its update the constant
+// (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
 template <int ENV>
 __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
 {
-  constexpr int S = Env<ENV>::S;
+  constexpr int S = Env<ENV>::S, SD = S - 1;
   const double h = P.h;
-  double xd[S], k1[S], k2[S], k3[S], k4[S], t[S];
+  const double tinc = (((h + 2 * h) + 2 * h) + h) / 6;
+  double xd[S], k1[SD], k2[SD], k3[SD], k4[SD], t[S];
 #pragma unroll
-  for (int i = 0; i < S; ++i) next[i] = x[i];
+  for (int i = 0; i < S; ++i) { next[i] = x[i]; t[i] = x[i]; }
   for (int ii = 0; ii < P.integration_steps; ++ii)
   {
     Env<ENV>::eom(next, u, xd);
 #pragma unroll
-    for (int i = 0; i < S; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
+    for (int i = 0; i < SD; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
     Env<ENV>::eom(t, u, xd);
 #pragma unroll
-    for (int i = 0; i < S; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
+    for (int i = 0; i < SD; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
     Env<ENV>::eom(t, u, xd);
 #pragma unroll
-    for (int i = 0; i < S; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
+    for (int i = 0; i < SD; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
     Env<ENV>::eom(t, u, xd);
 #pragma unroll
-    for (int i = 0; i < S; ++i)
+    for (int i = 0; i < SD; ++i)
     {
       k4[i] = h * xd[i];
-      next[i] = next[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6;
+      next[i] = next[i] + div6(k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
     }
+    next[SD] = next[SD] + tinc;
   }
 }
 
 // ModeledEnvironment::step (modeled.cpp:160-213), window 1, no delta, discrete_time 1
 template <int ENV>
-__device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal)
+__device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal, uint32_t &status)
 {
   constexpr int S = Env<ENV>::S;
   double next[S];
   rk4_step<ENV>(P, x, Env<ENV>::actuate(action), next);
   terminal = Env<ENV>::observe(P, next, obs);
   reward = Env<ENV>::evaluate(P, x, action, next);
+  // the branch-free sin/cos need |angle| < 2^20; 2^19 at step ends leaves room for the stages
+  if (!Env<ENV>::in_domain(next)) status |= ST_DOMAIN;
 #pragma unroll
   for (int i = 0; i < S; ++i) x[i] = next[i];
 }
@@ -591,6 +599,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   double   tr_val[kMaxTrace];
   uint32_t tr_cnt[kMaxTrace];
   uint32_t tr_wt = 0;
+  bool tr_dup = false;          // some entry of this lane's trace occurs twice in its projection (sticky per trial)
 #pragma unroll
   for (int e = 0; e < kMaxTrace; ++e) { tr_pos[e] = kInvalidPos; tr_val[e] = 0; tr_cnt[e] = 0; }
   int    tr_len = 0;
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         // -------- environment step (skipped on the start() pass)
         if (!first)
         {
-          env_step<ENV>(P, x, action, obs, reward, terminal);             // online_learning.cpp:196
+          env_step<ENV>(P, x, action, obs, reward, terminal, status);     // online_learning.cpp:196
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
         }
@@ -887,58 +896,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           const double dW = P.alpha * (target - qsa);          // LinearRepresentation::write (linear.cpp:186-196)
           const double dT = P.alpha * delta;                   // VectorConstructor(alpha_*delta)
 
-          // Cross-lane aliasing needs a lane whose p is a slot shared between tilings (only such
-          // a slot can sit in another lane's trace, or twice in p).  Otherwise every lane works
-          // on its own registers.
-          const bool cross = (__ballot(p_sh) & gmask) != 0ull;
+          // Aliasing between p and the trace (IndexProjection::ssub, projection.h:94-104).  Inside a
+          // lane it is a register compare.  Across lanes it needs a p that is a slot shared between
+          // tilings (only such a slot can sit in another lane's trace, or twice in p): those lanes'
+          // positions are compared through LDS -- usually none.
+          const uint32_t shmask = (uint32_t)((__ballot(p_sh) >> (16 * g)) & 0xFFFFull);
+          uint32_t cp = 1;                                     // occurrences of my slot inside p
           double v;                                            // final weight of p's slot after this step
-          uint32_t cp = 1;
-          if (!cross)
-          { // ---- common case: aliasing between p and the trace can only happen inside a lane
-            double weight = 1.;
-            bool upd = true, aliased = false;
-            double v_alias = 0;
-            if (use_trace)
-            {
-#pragma unroll
-              for (int e = 0; e < kMaxTrace; ++e)
-                if (e < tr_len)
-                {
-                  upd = upd && (weight > 0.001);                 // representation.h:81
-                  const double de = weight * dT * ee;
-                  if (tr_pos[e] != kInvalidPos)
-                  {
-                    if (tr_pos[e] == p_pos)
-                    { // p's write first, then this entry's update; the slot leaves the trace (ssub)
-                      if (upd) { v_alias = add_clamped(add_clamped(tr_val[e], dW), de); aliased = true; }
-                      tr_pos[e] = kInvalidPos;
-                    }
-                    else if (upd)
-                    {
-                      if ((tr_wt >> e) & 1u)
-                      { // shared slot (possibly twice in its projection): keep the table current
-                        double vv = tr_val[e];
-                        for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
-                        tr_val[e] = vv;
-                        value_store(tab, tr_pos[e], vv);
-                      }
-                      else
-                        tr_val[e] = add_clamped(tr_val[e], de);
-                    }
-                  }
-                  weight *= ee;
-                }
-            }
-            v = aliased ? v_alias : add_clamped(wp, dW);
-          }
-          else
-          { // ---- general case: positions of p for the 16 tilings of this replica via LDS
-            uint32_t pp[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) pp[k] = sh_ppos[g * 16 + k];
-            cp = 0;                                            // duplicates of my slot inside p
-#pragma unroll
-            for (int k = 0; k < 16; ++k) cp += (pp[k] == p_pos) ? 1u : 0u;
+          if (!__any(shmask != 0u || tr_dup))
+          { // ---- common case (no lane of the wave has a shared p, no slot occurs twice): aliasing
+            // is a register compare inside the lane; straight-line code, no exec-mask branches
+            double a_val = 0, a_de = 0;
+            bool aliased = false, a_upd = false;
+            uint32_t stmask = 0;
             if (use_trace)
             {
               double weight = 1.;
@@ -946,37 +916,95 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 #pragma unroll
               for (int e = 0; e < kMaxTrace; ++e)
               {
+                const bool in = e < tr_len;
+                upd = upd && (!in || weight > 0.001);            // representation.h:81
+                const double de = weight * dT * ee;
+                const bool valid = in && tr_pos[e] != kInvalidPos;
+                const bool own = valid && tr_pos[e] == p_pos;
+                const double vv = add_clamped(tr_val[e], de);
+                const bool doit = valid && !own && upd;
+                tr_val[e] = doit ? vv : tr_val[e];
+                stmask |= (doit && ((tr_wt >> e) & 1u)) ? (1u << e) : 0u;
+                a_val = own ? tr_val[e] : a_val;
+                a_de = own ? de : a_de;
+                a_upd = own ? upd : a_upd;
+                aliased = aliased || own;
+                tr_pos[e] = own ? kInvalidPos : tr_pos[e];       // ssub: the slot leaves the trace
+                tr_wt = own ? (tr_wt & ~(1u << e)) : tr_wt;
+                weight = in ? weight * ee : weight;
+              }
+            }
+            // p's write first, then the aliased entry's update (if it is still being updated)
+            const double base = aliased ? a_val : wp;
+            const double v1 = add_clamped(base, dW);
+            const double v2 = add_clamped(v1, a_de);
+            v = (aliased && a_upd) ? v2 : v1;
+            if (__any(stmask != 0u))
+            {
+#pragma unroll
+              for (int e = 0; e < kMaxTrace; ++e)
+                if ((stmask >> e) & 1u) value_store(tab, tr_pos[e], tr_val[e]);   // shared slot: keep the table current
+            }
+          }
+          else
+          {
+            uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
+  #pragma unroll
+            for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
+            for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
+            {
+              const int k = __builtin_ctz(mm);
+              const uint32_t ppk = sh_ppos[g * 16 + k];
+              if (k != j)
+              {
+                if (ppk == p_pos) cp++;
+  #pragma unroll
+                for (int e = 0; e < kMaxTrace; ++e) xm[e] |= (tr_pos[e] == ppk) ? (1u << k) : 0u;
+              }
+            }
+
+            double v_alias = 0;
+            bool aliased = false;
+            if (use_trace)
+            { // trace entries, newest first (representation.h:79-83, trace.h:150-178)
+              double weight = 1.;
+              bool upd = true;
+  #pragma unroll
+              for (int e = 0; e < kMaxTrace; ++e)
                 if (e < tr_len)
                 {
-                  upd = upd && (weight > 0.001);
+                  upd = upd && (weight > 0.001);                 // representation.h:81
                   const double de = weight * dT * ee;
                   if (tr_pos[e] != kInvalidPos)
                   {
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) m |= (pp[k] == tr_pos[e]) ? (1u << k) : 0u;
-                    if (m == 0u)
+                    const bool own = tr_pos[e] == p_pos;
+                    if (!own && xm[e] == 0u)
                     {
                       if (upd)
-                      { // LinearRepresentation::update (linear.cpp:198-216), duplicates applied tr_cnt times
-                        double vv = tr_val[e];
-                        for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
+                      { // LinearRepresentation::update (linear.cpp:198-216); a slot that occurs twice in
+                        // its projection is updated twice
+                        double vv = add_clamped(tr_val[e], de);
+                        if ((tr_wt >> e) & 1u)
+                        {
+                          for (uint32_t c = 1; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
+                          value_store(tab, tr_pos[e], vv);       // shared slot: keep the table current
+                        }
                         tr_val[e] = vv;
-                        if ((tr_wt >> e) & 1u) value_store(tab, tr_pos[e], vv);
                       }
                     }
                     else
-                    { // also written through p: p's write comes first, then this entry's update;
-                      // the slot leaves the trace (IndexProjection::ssub, projection.h:94-104)
+                    { // the slot is also written through p: p's write comes first, then this entry's
+                      // update; the slot leaves the trace
                       if (upd)
                       {
                         double vv = tr_val[e];
-                        const uint32_t cpx = (uint32_t)__builtin_popcount(m);
+                        const uint32_t cpx = (own ? 1u : 0u) + (uint32_t)__builtin_popcount(xm[e]);
                         for (uint32_t c = 0; c < cpx; ++c) vv = add_clamped(vv, dW);
                         for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
-                        for (uint32_t mm = m; mm != 0u; mm &= mm - 1u)
+                        if (own) { v_alias = vv; aliased = true; }
+                        for (uint32_t mm = xm[e]; mm != 0u; mm &= mm - 1u)
                         {
-                          int k = __builtin_ctz(mm);
+                          const int k = __builtin_ctz(mm);
                           sh_fb[k * 4 + g] = vv;
                           sh_fbflag[k * 4 + g] = 1u;
                         }
@@ -987,10 +1015,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
                   }
                   weight *= ee;
                 }
-              }
             }
             wave_sync();
-            if (sh_fbflag[j * 4 + g] != 0u)
+            if (aliased)
+              v = v_alias;
+            else if (shmask != 0u && sh_fbflag[j * 4 + g] != 0u)
               v = sh_fb[j * 4 + g];
             else
             {
@@ -1029,6 +1058,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             tr_pos[0] = p_pos;
             tr_val[0] = v;
             tr_cnt[0] = cp;
+            tr_dup = tr_dup || cp > 1u;
             if (p_sh) tr_wt |= 1u;
             tr_len = (tr_len < kMaxTrace) ? tr_len + 1 : kMaxTrace;
             tr_total *= ee;
@@ -1109,6 +1139,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         tr_pos[e] = kInvalidPos;
       }
       tr_wt = 0;
+      tr_dup = false;
       tr_len = 0;
       tr_total = 1.;
     }
@@ -1208,12 +1239,14 @@ __global__ void env_step_kernel(DevParams P, double *state, const double *action
   double x[S], o[D], rw;
   int term;
   for (int k = 0; k < S; ++k) x[k] = state[(size_t)i * S + k];
-  env_step<ENV>(P, x, action[i], o, rw, term);
+  uint32_t st = 0;
+  if (!Env<ENV>::in_domain(x)) st |= ST_DOMAIN;
+  env_step<ENV>(P, x, action[i], o, rw, term, st);
   for (int k = 0; k < S; ++k) state[(size_t)i * S + k] = x[k];
   for (int k = 0; k < D; ++k) obs[(size_t)i * D + k] = o[k];
   reward[i] = rw;
   terminal[i] = term;
-  bool bad = false;
+  bool bad = st != 0;
   for (int k = 0; k < S; ++k) bad = bad || (x[k] != x[k]);
   if (bad) atomicOr(err, ST_DOMAIN);
 }
@@ -1336,10 +1369,11 @@ __global__ void math_kernel(int op, const double *x, const double *y, int n, dou
   double v = x[i], r;
   switch (op)
   {
-    case 0: r = psin(v); break;
-    case 1: r = pcos(v); break;
+    case 0: r = psin_checked(v); break;
+    case 1: r = pcos_checked(v); break;
     case 2: r = plog(v); break;
     case 3: r = pfmod(v, y[i]); break;
+    case 5: r = div6(v); break;
     default: r = __builtin_sqrt(v); break;
   }
   out[i] = r;

@@ -25,7 +25,9 @@
 // Constants are Taylor coefficients 1/k! and a three-double split of pi/2, all
 // correctly rounded from exact rationals (tools/gen_math_constants.py).
 // Accuracy: <= 1 ulp from glibc on 3 % of arguments, identical elsewhere.
-// Domain: |x| < 2^20, NaN outside (callers raise GRLX_ERR_DOMAIN).
+// No tiny-argument shortcut (the general path returns x resp. 1; sin(-0) = +0).
+// Domain: |x| < 2^20: psin/pcos are branch-free and unchecked, psin_checked/pcos_checked
+// return NaN outside; the rollout kernel checks its states once per step (GRLX_ERR_DOMAIN).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -80,58 +82,86 @@ __device__ __forceinline__ double math_kcos(double r, double rl)
   return w + __builtin_fma(z * z, Q, __builtin_fma(-r, rl, tail));
 }
 
-// sin or cos kernel selected per lane (odd = cosine kernel): both kernels are the same
-// Estrin scheme, so one evaluation with per-lane coefficients performs exactly the
-// operations of math_ksin / math_kcos (bit-identical) at half the instruction count.
-__device__ __forceinline__ double math_ksincos(double r, double rl, bool odd)
+// Both kernels of one reduced argument, sharing z, z^2, z^4 (the selects a per-lane choice
+// of coefficients would need cost more than the second set of seven fma).
+__device__ __forceinline__ void math_kboth(double r, double t, double &sn, double &cs)
 {
-  const double z = r * r;
-  const double P = math_estrin8(z,
-      odd ? 0x1.5555555555555p-5 : -0x1.5555555555555p-3,  odd ? -0x1.6c16c16c16c17p-10 : 0x1.1111111111111p-7,
-      odd ? 0x1.a01a01a01a01ap-16 : -0x1.a01a01a01a01ap-13, odd ? -0x1.27e4fb7789f5cp-22 : 0x1.71de3a556c734p-19,
-      odd ? 0x1.1eed8eff8d898p-29 : -0x1.ae64567f544e4p-26, odd ? -0x1.93974a8c07c9dp-37 : 0x1.6124613a86d09p-33,
-      odd ? 0x1.ae7f3e733b81fp-45 : -0x1.ae7f3e733b81fp-41, odd ? -0x1.6827863b97d97p-53 : 0x1.952c77030ad4ap-49);
+  const double z = r * r, z2 = z * z, z4 = z2 * z2;
+  const double sa = __builtin_fma(z, 0x1.1111111111111p-7, -0x1.5555555555555p-3);
+  const double sb = __builtin_fma(z, 0x1.71de3a556c734p-19, -0x1.a01a01a01a01ap-13);
+  const double sc = __builtin_fma(z, 0x1.6124613a86d09p-33, -0x1.ae64567f544e4p-26);
+  const double sd = __builtin_fma(z, 0x1.952c77030ad4ap-49, -0x1.ae7f3e733b81fp-41);
+  const double P = __builtin_fma(z4, __builtin_fma(z2, sd, sc), __builtin_fma(z2, sb, sa));
+  const double ca = __builtin_fma(z, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5);
+  const double cb = __builtin_fma(z, -0x1.27e4fb7789f5cp-22, 0x1.a01a01a01a01ap-16);
+  const double cc = __builtin_fma(z, -0x1.93974a8c07c9dp-37, 0x1.1eed8eff8d898p-29);
+  const double cd = __builtin_fma(z, -0x1.6827863b97d97p-53, 0x1.ae7f3e733b81fp-45);
+  const double Q = __builtin_fma(z4, __builtin_fma(z2, cd, cc), __builtin_fma(z2, cb, ca));
   const double hz = 0.5 * z;
+  sn = r + __builtin_fma(z * r, P, __builtin_fma(-hz, t, t));
   const double w = 1.0 - hz;
   const double tail = (1.0 - w) - hz;
-  const double lead = odd ? w : r;
-  const double mul = odd ? z * z : z * r;
-  const double add = odd ? __builtin_fma(-r, rl, tail) : __builtin_fma(-hz, rl, rl);
-  return lead + __builtin_fma(mul, P, add);
+  cs = w + __builtin_fma(z2, Q, __builtin_fma(-r, t, tail));
 }
 
+// Branch-free forms: callers guarantee |x| < 2^20 (checked once per environment step;
+// outside the domain the result is unspecified and the replica is flagged).
 __device__ __forceinline__ double psin(double x)
 {
-  double ax = __builtin_fabs(x), rh, rl;
-  if (!(ax < 0x1p20)) return __builtin_nan("");
-  if (ax < 0x1p-27) return x;
-  int q = math_reduce(x, rh, rl);
-  double v = math_ksincos(rh, rl, (q & 1) != 0);
+  double r, t, sn, cs;
+  const double fn = __builtin_rint(x * GRLX_INVPIO2);
+  {
+    const double r0 = __builtin_fma(-fn, GRLX_PIO2_1, x);
+    const double p  = fn * GRLX_PIO2_2;
+    const double pl = __builtin_fma(fn, GRLX_PIO2_2, -p);
+    r = r0 - p;
+    const double e = (r0 - r) - p;
+    t = (e - pl) - fn * GRLX_PIO2_3;
+  }
+  const int q = (int)fn;                        // |fn| < 2^20
+  math_kboth(r, t, sn, cs);
+  const double v = (q & 1) ? cs : sn;
   return (q & 2) ? -v : v;
 }
 
 __device__ __forceinline__ double pcos(double x)
 {
-  double ax = __builtin_fabs(x), rh, rl;
-  if (!(ax < 0x1p20)) return __builtin_nan("");
-  if (ax < 0x1p-27) return 1.0;
-  int q = math_reduce(x, rh, rl) + 1;              // cos(x) = sin(x + pi/2)
-  double v = math_ksincos(rh, rl, (q & 1) != 0);
+  double rh, rl, sn, cs;
+  const int q = math_reduce(x, rh, rl) + 1;     // cos(x) = sin(x + pi/2)
+  math_kboth(rh, rl, sn, cs);
+  const double v = (q & 1) ? cs : sn;
   return (q & 2) ? -v : v;
 }
 
-// sin and cos of the same argument share the reduction
-__device__ __forceinline__ void psincos(double x, double &sn, double &cs)
+// sin and cos of the same argument share everything but the final selection
+__device__ __forceinline__ void psincos(double x, double &sn_out, double &cs_out)
 {
-  double ax = __builtin_fabs(x), rh, rl;
-  if (!(ax < 0x1p20)) { sn = cs = __builtin_nan(""); return; }
-  if (ax < 0x1p-27) { sn = x; cs = 1.0; return; }
-  int q = math_reduce(x, rh, rl);
-  double s = math_ksin(rh, rl), c = math_kcos(rh, rl);
-  double vs = (q & 1) ? c : s;
-  sn = (q & 2) ? -vs : vs;
-  double vc = (q & 1) ? s : c;
-  cs = ((q + 1) & 2) ? -vc : vc;
+  double rh, rl, sn, cs;
+  const int q = math_reduce(x, rh, rl);
+  math_kboth(rh, rl, sn, cs);
+  const double vs = (q & 1) ? cs : sn;
+  sn_out = (q & 2) ? -vs : vs;
+  const double vc = (q & 1) ? sn : cs;
+  cs_out = ((q + 1) & 2) ? -vc : vc;
+}
+
+// checked entry points (fine-grained operators): NaN outside the domain
+__device__ __forceinline__ double psin_checked(double x) { return (__builtin_fabs(x) < 0x1p20) ? psin(x) : __builtin_nan(""); }
+__device__ __forceinline__ double pcos_checked(double x) { return (__builtin_fabs(x) < 0x1p20) ? pcos(x) : __builtin_nan(""); }
+
+// x / 6, correctly rounded, in three operations: q0 = x*c, r = fma(-6,q0,x) (exact),
+// q = fma(r,c,q0) = RN(x/6 * (1 + 2^-107)).  x/6 = (x/3)/2 and the quotient of a double by 3
+// is either exact or 1/3 resp. 2/3 of an ulp beyond a representable number -- never within
+// 2^-54 ulp of a rounding midpoint -- so the perturbation cannot change the rounding:
+// the result equals the IEEE division bit for bit (checked against v_div on random and
+// structured inputs in tests/test_gpu_parity.py).  Tiny |x| takes the true division.
+__device__ __forceinline__ double div6(double x)
+{
+  const double c = 0x1.5555555555555p-3;        // RN(1/6)
+  const double q0 = x * c;
+  const double r = __builtin_fma(-6.0, q0, x);
+  const double q = __builtin_fma(r, c, q0);
+  return (__builtin_fabs(x) > 0x1p-900) ? q : x / 6.0;
 }
 
 // plog(x): x = m*2^k, m in [sqrt2/2, sqrt2); f = m-1; d = f+2; s = f/d;

@@ -25,6 +25,7 @@
  *             result w + fma(z*z, Q, fma(-r, t, tail))
  *  Constants: tools/gen_math_constants.py (Taylor coefficients 1/k! and a
  *  three-double split of pi/2, all correctly rounded from exact rationals).
+ *  No special case for tiny |x| (the general path returns x resp. 1 there; sin(-0) = +0).
  *  Domain: |x| < 2^20 (NaN outside; the environments never get there).
  */
 #include <math.h>
@@ -109,7 +110,6 @@ double orc_psin(double x)
 {
   double ax = fabs(x), rh, rl;
   if (!(ax < 0x1p20)) return NAN;
-  if (ax < 0x1p-27) return x;
   switch (reduce(x, &rh, &rl))
   {
     case 0:  return ksin(rh, rl);
@@ -123,7 +123,6 @@ double orc_pcos(double x)
 {
   double ax = fabs(x), rh, rl;
   if (!(ax < 0x1p20)) return NAN;
-  if (ax < 0x1p-27) return 1.0;
   switch (reduce(x, &rh, &rl))
   {
     case 0:  return kcos(rh, rl);

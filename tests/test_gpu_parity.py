@@ -50,6 +50,18 @@ def test_device_fmod_sqrt_exact(grlx):
     assert_bit_equal(grlx.runner.device_math(4, z), np.sqrt(z), "sqrt")
 
 
+def test_div6_equals_ieee_division(grlx):
+    """RK4's (k1+2k2+2k3+k4)/6 (modeled.cpp:272) uses a 3-operation form proven to be correctly
+    rounded; check it against the true division on random, structured and extreme inputs."""
+    rng = np.random.default_rng(9)
+    m = rng.integers(1 << 52, 1 << 53, 400000).astype(np.float64)          # every mantissa pattern class
+    e = rng.integers(-300, 300, m.size)
+    x = np.concatenate([np.ldexp(m, e - 52) * rng.choice([-1.0, 1.0], m.size), rng.uniform(-1e3, 1e3, 200000),
+                        np.arange(-3000, 3000, dtype=np.float64), np.arange(1, 4000, dtype=np.float64) * (2.0 ** -60),
+                        [0.0, -0.0, 1e-310, -1e-310, 5e-324, 1e308, -1e308, 6.0, 3.0, 1.0 / 3.0]])
+    assert_bit_equal(grlx.runner.device_math(5, x), x / 6.0, "x/6")
+
+
 def test_rand48_jump_on_device(grlx, oracle):
     skip = np.array([0, 1, 2, 1000, 8388607, 8388608, 8388609, 2**33 + 5, 2**47 - 1], dtype=np.uint64)
     for seed in (1, 77, 2**31 - 1):

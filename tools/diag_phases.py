@@ -12,14 +12,15 @@ trials = int(sys.argv[2]) if len(sys.argv) > 2 else 11
 logc = int(sys.argv[3]) if len(sys.argv) > 3 else 17
 cfg = grl_amd.pendulum_sarsa_config(n, max_rows=64, table_log2_capacity=logc)
 r = grl_amd.Runner(cfg, np.arange(1, n + 1))
-r.run(33); r.sync()                       # warm tables
+warm = int(sys.argv[4]) if len(sys.argv) > 4 else 33
+r.run(warm); r.sync()                     # warm tables
 r.set_diag(True)
 t0 = time.perf_counter(); r.run(trials); r.sync(); dt = time.perf_counter() - t0
 d = r.read_diag().astype(np.float64)
 names = ["loop/bookkeeping", "env step (RK4)", "tile hashing", "inserts + LDS writes", "LDS sums + sampler", "TD update + trace", "wait for previous stores", "table lookup (loads)"]
 steps = trials * 100 + trials
 tot = d.sum(1).mean()
-print(f"logC {logc} replicas {n}, {trials} trials, stamped launch {dt*1e3:.1f} ms, mean cycles/step/wave {tot/steps:.0f}")
+print(f"warmup {warm} trials; logC {logc} replicas {n}, {trials} trials, stamped launch {dt*1e3:.1f} ms, mean cycles/step/wave {tot/steps:.0f}")
 for k, nm in enumerate(names):
     print(f"  {nm:22s} {d[:,k].mean()/steps:9.0f} cycles/step  {100*d[:,k].mean()/tot:5.1f} %")
 r.set_diag(False)
