@@ -75,17 +75,16 @@ def main():
     import torch
     import torch.distributed as dist
     import grl_amd
+    from grl_amd import parallel
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    parallel.init_distributed("nccl")
 
     n = args.replicas
     total_steps = args.steps + args.warmup
     rows_total = total_steps                                   # one test row per step
     cfg = grl_amd.pendulum_sarsa_config(n, table_log2_capacity=args.table_log2, max_rows=rows_total + 1)
-    seeds = 1 + rank * n + np.arange(n, dtype=np.int64)        # contiguous partition of replica ids
+    seeds = parallel.replica_seeds(rank, world, n)             # contiguous partition of replica ids
     runner = grl_amd.Runner(cfg, seeds)
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
@@ -110,16 +109,12 @@ def main():
         ev[k][1].record(stream)
     # the job's only collective: learning-curve statistics over all replicas of all GPUs
     runner.curve_stats(curve.data_ptr(), 0, rows_total, sptr)
-    if world > 1:
-        dist.all_reduce(curve, op=dist.ReduceOp.SUM)
+    parallel.reduce_curve(curve, world)
     barrier()
     elapsed = time.perf_counter() - t0
     runner.sync(sptr)                                          # raises on table overflow etc.
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = parallel.max_over_ranks(elapsed, world, device="cuda")
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     env_steps_per_step = n * (LEARN_STEPS_PER_STEP + TEST_STEPS_PER_STEP)

@@ -1,0 +1,508 @@
+// objects.cpp -- the reference's plug-in classes on the hot path, as configuration
+// descriptors with the same TYPEINFO strings, parameter names, defaults and bad_param
+// conditions; `experiment/online_learning` lowers the instantiated graph to a grlx_config
+// and runs it on the GPU through the C ABI (include/grlx.h).  Nothing here computes the
+// algorithm on the CPU: a graph the fused kernels do not implement is refused.
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+#include "../../../include/grlx.h"
+#include "configurable.h"
+#include "objects.h"
+
+namespace grlx_host {
+
+using VecD = std::vector<double>;
+static const double kPi = 3.14159265358979323846;
+
+// ------------------------------------------------------------ environment ---
+struct Dynamics : Configurable { virtual int env_id() const = 0; };
+struct Task : Configurable {
+  virtual int env_id() const = 0;
+  double timeout = 0, randomization = 0;
+};
+
+// dynamics/pendulum (pendulum.cpp:36-49): no parameters
+struct PendulumDynamics : Dynamics {
+  GRLX_TYPEINFO("dynamics/pendulum")
+  int env_id() const override { return GRLX_ENV_PENDULUM; }
+};
+GRLX_REGISTER(PendulumDynamics)
+
+// task/pendulum/swingup (pendulum.cpp:70-95)
+struct PendulumSwingupTask : Task {
+  GRLX_TYPEINFO("task/pendulum/swingup")
+  int env_id() const override { return GRLX_ENV_PENDULUM; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("timeout", "Episode timeout", 2.99));
+    config->push_back(CRP("randomization", "Level of start state randomization", 0.));
+    config->push_back(CRP::provided("observation_dims", "int.observation_dims", "Number of observation dimensions"));
+    config->push_back(CRP::provided("observation_min", "vector.observation_min", "Lower limit on observations"));
+    config->push_back(CRP::provided("observation_max", "vector.observation_max", "Upper limit on observations"));
+    config->push_back(CRP::provided("action_dims", "int.action_dims", "Number of action dimensions"));
+    config->push_back(CRP::provided("action_min", "vector.action_min", "Lower limit on actions"));
+    config->push_back(CRP::provided("action_max", "vector.action_max", "Upper limit on actions"));
+    config->push_back(CRP::provided("reward_min", "double.reward_min", "Lower limit on immediate reward"));
+    config->push_back(CRP::provided("reward_max", "double.reward_max", "Upper limit on immediate reward"));
+  }
+  void configure(Configuration &config) override
+  {
+    timeout = config["timeout"];
+    randomization = config["randomization"];
+    if (timeout < 0) throw bad_param("task/pendulum/swingup:timeout");
+    if (randomization < 0 || randomization > 1) throw bad_param("task/pendulum/swingup:randomization");
+    config.set("observation_dims", 2);
+    config.set("observation_min", VecD{0., -12 * kPi});
+    config.set("observation_max", VecD{2 * kPi, 12 * kPi});
+    config.set("action_dims", 1);
+    config.set("action_min", VecD{-3});
+    config.set("action_max", VecD{3});
+    config.set("reward_min", -5 * std::pow(kPi, 2) - 0.1 * std::pow(12 * kPi, 2) - 1 * std::pow(3, 2));
+    config.set("reward_max", 0.);
+  }
+};
+GRLX_REGISTER(PendulumSwingupTask)
+
+// model/dynamical (modeled.cpp:234-252)
+struct DynamicalModel : Configurable {
+  GRLX_TYPEINFO("model/dynamical")
+  double control_step = 0.05;
+  int integration_steps = 5;
+  Dynamics *dynamics = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("control_step", "Control step time", 0.05));
+    config->push_back(CRP("integration_steps", "Number of integration steps per control step", 5));
+    config->push_back(CRP("dynamics", "dynamics", "Equations of motion", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    dynamics = dynamic_cast<Dynamics *>(config["dynamics"].ptr());
+    control_step = config["control_step"];
+    integration_steps = config["integration_steps"];
+    if (!(control_step >= 0.00001)) throw bad_param("model/dynamical:control_step");
+    if (integration_steps < 1) throw bad_param("model/dynamical:integration_steps");
+    if (!dynamics) throw Exception(path() + ": dynamics outside the accelerated path");
+  }
+};
+GRLX_REGISTER(DynamicalModel)
+
+// environment/modeled (modeled.cpp:35-119)
+struct ModeledEnvironment : Configurable {
+  GRLX_TYPEINFO("environment/modeled")
+  DynamicalModel *model = nullptr;
+  Task *task = nullptr;
+  int discrete_time = 1;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("discrete_time", "Always report unit step time", 1));
+    config->push_back(CRP("window", "Number of observations to concatenate", 1));
+    config->push_back(CRP("stride", "Time steps between concatenated observations", 1));
+    config->push_back(CRP("delta", "Action delta for differential actions", VecD{}));
+    config->push_back(CRP("model", "model", "Environment model", (Configurable *)nullptr));
+    config->push_back(CRP("task", "task", "Task to perform in the environment (should match model)", (Configurable *)nullptr));
+    config->push_back(CRP("exporter", "exporter", "Optional exporter for transition log", (Configurable *)nullptr, true));
+    for (const char *n : {"observation_dims", "observation_min", "observation_max", "action_dims", "action_min", "action_max", "reward_min", "reward_max"})
+      config->push_back(CRP::provided(n, std::string("vector.") + n, "Forwarded task parameter"));
+  }
+  void configure(Configuration &config) override
+  {
+    model = dynamic_cast<DynamicalModel *>(config["model"].ptr());
+    task = dynamic_cast<Task *>(config["task"].ptr());
+    discrete_time = config["discrete_time"];
+    if (!model || !task) throw Exception(path() + ": model/task outside the accelerated path");
+    if ((int)config["window"] != 1 || (int)config["stride"] != 1 || !config["delta"].v().empty())
+      throw Exception(path() + ": window/stride/delta are not supported by the accelerated path");
+    if (config["exporter"].ptr()) throw Exception(path() + ": exporters are not supported by the accelerated path");
+    if (discrete_time != 1) throw Exception(path() + ": discrete_time must be 1 on the accelerated path");
+    if (model->dynamics->env_id() != task->env_id()) throw Exception(path() + ": task does not match dynamics");
+    // forward the task's provided parameters (modeled.cpp:79-114)
+    Configurator *t = task->configurator;
+    for (const char *n : {"observation_dims", "observation_min", "observation_max", "action_dims", "action_min", "action_max", "reward_min", "reward_max"})
+      config.set(n, t->child(n)->value);
+  }
+};
+GRLX_REGISTER(ModeledEnvironment)
+
+// ------------------------------------------------------------------ agent ---
+// discretizer/uniform (uniform.cpp:34-95)
+struct UniformDiscretizer : Configurable {
+  GRLX_TYPEINFO("discretizer/uniform")
+  VecD min, max, steps;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("min", "Lower limit", VecD{}, CRP::System));
+    config->push_back(CRP("max", "Upper limit", VecD{}, CRP::System));
+    config->push_back(CRP("steps", "Discretization steps per dimension", VecD{}));
+  }
+  void configure(Configuration &config) override
+  {
+    min = config["min"].v(); max = config["max"].v(); steps = config["steps"].v();
+    if (min.size() != max.size() || min.size() != steps.size()) throw bad_param("discretizer/uniform:{min,max,steps}");
+    for (double s : steps) if (s < 1) throw bad_param("discretizer/uniform:steps");
+  }
+};
+GRLX_REGISTER(UniformDiscretizer)
+
+// projector/tile_coding (tile_coding.cpp:34-80)
+struct TileCodingProjector : Configurable {
+  GRLX_TYPEINFO("projector/tile_coding")
+  int tilings = 16, memory = 8 * 1024 * 1024, safe = 0;
+  VecD resolution, wrapping;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("tilings", "Number of tilings", 16));
+    config->push_back(CRP("memory", "Hash table size", 8 * 1024 * 1024));
+    config->push_back(CRP("safe", "Collision detection (0=off, 1=claim on write, 2=claim always)", 0));
+    config->push_back(CRP("resolution", "Size of a single tile", VecD{}));
+    config->push_back(CRP("wrapping", "Wrapping boundaries (must be multiple of resolution)", VecD{}));
+  }
+  void configure(Configuration &config) override
+  {
+    tilings = config["tilings"]; memory = config["memory"]; safe = config["safe"];
+    resolution = config["resolution"].v(); wrapping = config["wrapping"].v();
+    if (wrapping.empty()) wrapping.assign(resolution.size(), 0.);
+    if (wrapping.size() != resolution.size()) throw bad_param("projector/tile_coding:wrapping");
+    for (size_t ii = 0; ii < resolution.size(); ++ii)
+    { // tile_coding.cpp:66-78
+      double w = wrapping[ii] * (tilings / resolution[ii]);
+      if (std::fabs(w - std::round(w)) > 0.001) throw bad_param("projector/tile_coding:wrapping");
+    }
+    if (safe != 0) throw Exception(path() + ": safe >= 1 (collision claim table) is outside the accelerated path");
+  }
+};
+GRLX_REGISTER(TileCodingProjector)
+
+// representation/parameterized/linear (linear.cpp:34-101)
+struct LinearRepresentation : Configurable {
+  GRLX_TYPEINFO("representation/parameterized/linear")
+  VecD init_min, init_max, output_min, output_max;
+  int memory = 8 * 1024 * 1024, outputs = 1, limit = 1;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("init_min", "Lower initial value limit", VecD{0.}));
+    config->push_back(CRP("init_max", "Upper initial value limit", VecD{1.}));
+    config->push_back(CRP("memory", "Feature vector size", 8 * 1024 * 1024, CRP::System));
+    config->push_back(CRP("outputs", "Number of outputs", 1, CRP::System));
+    config->push_back(CRP("output_min", "Lower output limit", VecD{}, CRP::System));
+    config->push_back(CRP("output_max", "Upper output limit", VecD{}, CRP::System));
+    config->push_back(CRP("limit", "Limit parameters to same range as outputs", 1));
+    config->push_back(CRP("interval", "Target network update interval", 0.));     // ParameterizedRepresentation (unused here)
+    config->push_back(CRP("tau", "Target network update rate", 1.));
+  }
+  void configure(Configuration &config) override
+  {
+    memory = config["memory"]; outputs = config["outputs"]; limit = config["limit"];
+    init_min = config["init_min"].v(); init_max = config["init_max"].v();
+    if (!init_min.empty() && (int)init_min.size() < outputs) init_min.assign((size_t)outputs, init_min[0]);
+    if ((int)init_min.size() != outputs) throw bad_param("representation/parameterized/linear:init_min");
+    if (!init_max.empty() && (int)init_max.size() < outputs) init_max.assign((size_t)outputs, init_max[0]);
+    if ((int)init_max.size() != outputs) throw bad_param("representation/parameterized/linear:max");
+    output_min = config["output_min"].v();
+    if (output_min.empty()) output_min.assign((size_t)outputs, -DBL_MAX);
+    if ((int)output_min.size() != outputs) throw bad_param("representation/parameterized/linear:output_min");
+    output_max = config["output_max"].v();
+    if (output_max.empty()) output_max.assign((size_t)outputs, DBL_MAX);
+    if ((int)output_max.size() != outputs) throw bad_param("representation/parameterized/linear:output_max");
+    if ((double)config["interval"] != 0. || (double)config["tau"] != 1.)
+      throw Exception(path() + ": target networks are outside the accelerated path");
+  }
+};
+GRLX_REGISTER(LinearRepresentation)
+
+// sampler/greedy, sampler/epsilon_greedy (greedy.cpp:34-130)
+struct GreedySampler : Configurable {
+  GRLX_TYPEINFO("sampler/greedy")
+  virtual bool explores() const { return false; }
+};
+GRLX_REGISTER(GreedySampler)
+struct EpsilonGreedySampler : GreedySampler {
+  GRLX_TYPEINFO("sampler/epsilon_greedy")
+  VecD epsilon; double decay_rate = 1, decay_min = 0;
+  bool explores() const override { return true; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("epsilon", "Exploration rate (can be defined per action)", VecD{0.05}, CRP::Online));
+    config->push_back(CRP("decay_rate", "Multiplicative decay factor per episode", 1.));
+    config->push_back(CRP("decay_min", "Minimum decay (eps_min = eps*decay_min)", 0.));
+  }
+  void configure(Configuration &config) override
+  {
+    epsilon = config["epsilon"].v(); decay_rate = config["decay_rate"]; decay_min = config["decay_min"];
+    if (epsilon.size() < 1) throw bad_param("sampler/epsilon_greedy:epsilon");
+    if (epsilon.size() > 1) throw Exception(path() + ": per-action epsilon is outside the accelerated path");
+  }
+};
+GRLX_REGISTER(EpsilonGreedySampler)
+
+// mapping/policy/discrete/value/q (q.cpp:35-52); the reference's own test yaml still says policy/discrete/q
+struct QPolicy : Configurable {
+  GRLX_TYPEINFO("mapping/policy/discrete/value/q")
+  UniformDiscretizer *discretizer = nullptr; TileCodingProjector *projector = nullptr;
+  LinearRepresentation *representation = nullptr; GreedySampler *sampler = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("discretizer", "discretizer.action", "Action discretizer", (Configurable *)nullptr));
+    config->push_back(CRP("projector", "projector.pair", "Projects observation-action pairs onto representation space", (Configurable *)nullptr));
+    config->push_back(CRP("representation", "representation.value/action", "Action-value representation", (Configurable *)nullptr));
+    config->push_back(CRP("sampler", "sampler", "Samples actions from action-values", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    discretizer = dynamic_cast<UniformDiscretizer *>(config["discretizer"].ptr());
+    projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
+    representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
+    sampler = dynamic_cast<GreedySampler *>(config["sampler"].ptr());
+    if (!discretizer || !projector || !representation || !sampler)
+      throw Exception(path() + ": the accelerated path needs discretizer/uniform, projector/tile_coding, representation/parameterized/linear and a greedy sampler");
+  }
+};
+GRLX_REGISTER(QPolicy)
+struct QPolicyLegacy : QPolicy { GRLX_TYPEINFO("mapping/policy/discrete/q") };      // name used by tests/pendulum-sarsa-tc.yaml
+GRLX_REGISTER(QPolicyLegacy)
+
+struct Trace : Configurable { virtual int kind() const = 0; };
+struct ReplacingTrace : Trace { GRLX_TYPEINFO("trace/enumerated/replacing") int kind() const override { return GRLX_TRACE_REPLACING; } };
+GRLX_REGISTER(ReplacingTrace)
+struct AccumulatingTrace : Trace { GRLX_TYPEINFO("trace/enumerated/accumulating") int kind() const override { return GRLX_TRACE_ACCUMULATING; } };
+GRLX_REGISTER(AccumulatingTrace)
+
+// predictor/critic/sarsa (sarsa.cpp:35-60), predictor/critic/q (advantage.cpp:35-62)
+struct TDPredictorBase : Configurable {
+  double alpha = 0.2, gamma = 0.97, lambda = 0.65;
+  TileCodingProjector *projector = nullptr; LinearRepresentation *representation = nullptr; Trace *trace = nullptr;
+  virtual int agent_id() const = 0;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("alpha", "Learning rate", 0.2));
+    config->push_back(CRP("gamma", "Discount rate", 0.97));
+    config->push_back(CRP("lambda", "Trace decay rate", 0.65));
+    if (agent_id() == GRLX_AGENT_Q)
+      config->push_back(CRP("discretizer", "discretizer.action", "Action discretizer", (Configurable *)nullptr));
+    config->push_back(CRP("projector", "projector.pair", "Projects observation-action pairs onto representation space", (Configurable *)nullptr));
+    config->push_back(CRP("representation", "representation.value/action", "Q-value representation", (Configurable *)nullptr));
+    config->push_back(CRP("trace", "trace", "Trace of projections", (Configurable *)nullptr, true));
+    config->push_back(CRP("importer", "importer", "Optional importer", (Configurable *)nullptr, true));
+    config->push_back(CRP("exporter", "exporter", "Optional exporter", (Configurable *)nullptr, true));
+  }
+  void configure(Configuration &config) override
+  {
+    alpha = config["alpha"]; gamma = config["gamma"]; lambda = config["lambda"];
+    projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
+    representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
+    trace = dynamic_cast<Trace *>(config["trace"].ptr());
+    if (!projector || !representation) throw Exception(path() + ": projector/representation outside the accelerated path");
+    if (config["importer"].ptr() || config["exporter"].ptr()) throw Exception(path() + ": importer/exporter are outside the accelerated path");
+  }
+};
+struct SARSAPredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/sarsa") int agent_id() const override { return GRLX_AGENT_SARSA; } };
+GRLX_REGISTER(SARSAPredictor)
+struct QPredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/q") int agent_id() const override { return GRLX_AGENT_Q; } };
+GRLX_REGISTER(QPredictor)
+// names from before the reference's predictor/critic/* rename, still used by its tests/pendulum-sarsa-tc.yaml
+struct SARSAPredictorLegacy : SARSAPredictor { GRLX_TYPEINFO("predictor/sarsa") };
+GRLX_REGISTER(SARSAPredictorLegacy)
+struct QPredictorLegacy : QPredictor { GRLX_TYPEINFO("predictor/q") };
+GRLX_REGISTER(QPredictorLegacy)
+
+// agent/td (td.cpp:34-48), agent/fixed (fixed.cpp:34-45)
+struct TDAgent : Configurable {
+  GRLX_TYPEINFO("agent/td")
+  QPolicy *policy = nullptr; TDPredictorBase *predictor = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("policy", "mapping/policy", "Control policy", (Configurable *)nullptr));
+    config->push_back(CRP("predictor", "predictor", "Value function predictor", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    policy = dynamic_cast<QPolicy *>(config["policy"].ptr());
+    predictor = dynamic_cast<TDPredictorBase *>(config["predictor"].ptr());
+    if (!policy || !predictor) throw Exception(path() + ": policy/predictor outside the accelerated path");
+  }
+};
+GRLX_REGISTER(TDAgent)
+struct FixedAgent : Configurable {
+  GRLX_TYPEINFO("agent/fixed")
+  QPolicy *policy = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  { config->push_back(CRP("policy", "mapping/policy", "Control policy", (Configurable *)nullptr)); }
+  void configure(Configuration &config) override
+  {
+    policy = dynamic_cast<QPolicy *>(config["policy"].ptr());
+    if (!policy) throw Exception(path() + ": policy outside the accelerated path");
+  }
+};
+GRLX_REGISTER(FixedAgent)
+
+// ------------------------------------------------------------- experiment ---
+struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
+  GRLX_TYPEINFO("experiment/online_learning")
+  int runs = 1, run_offset = 0, trials = 0, steps = 0, test_interval = -1, test_trials = 1;
+  std::string output, load_file, save_every;
+  ModeledEnvironment *environment = nullptr; TDAgent *agent = nullptr; FixedAgent *test_agent = nullptr;
+
+  void request(const std::string &, ConfigurationRequest *config) override
+  { // online_learning.cpp:40-62
+    config->push_back(CRP("runs", "Number of separate learning runs to perform", 1));
+    config->push_back(CRP("run_offset", "Run offset to start at", 0));
+    config->push_back(CRP("trials", "Number of episodes per learning run", 0));
+    config->push_back(CRP("steps", "Number of steps per learning run", 0));
+    config->push_back(CRP("rate", "Control step frequency in Hz", 0, CRP::Online));
+    config->push_back(CRP("test_interval", "Number of episodes in between test trials", -1));
+    config->push_back(CRP("test_trials", "Number of test trials per interval", 1));
+    config->push_back(CRP("output", "Output base filename", std::string()));
+    config->push_back(CRP("environment", "environment", "Environment in which the agent acts", (Configurable *)nullptr));
+    config->push_back(CRP("agent", "agent", "Agent", (Configurable *)nullptr));
+    config->push_back(CRP("test_agent", "agent", "Agent to use in test trials", (Configurable *)nullptr, true));
+    config->push_back(CRP("exporter", "exporter", "Optional exporter for transition log", (Configurable *)nullptr, true));
+    config->push_back(CRP("load_file", "Load policy filename", std::string()));
+    config->push_back(CRP("save_every", "Save policy to 'output' at the end of event", std::string("never")));
+  }
+  void configure(Configuration &config) override
+  {
+    runs = config["runs"]; run_offset = config["run_offset"]; trials = config["trials"]; steps = config["steps"];
+    test_interval = config["test_interval"]; test_trials = config["test_trials"];
+    output = config["output"].str(); load_file = config["load_file"].str(); save_every = config["save_every"].str();
+    environment = dynamic_cast<ModeledEnvironment *>(config["environment"].ptr());
+    agent = dynamic_cast<TDAgent *>(config["agent"].ptr());
+    test_agent = dynamic_cast<FixedAgent *>(config["test_agent"].ptr());
+    if (runs < 1) throw bad_param("experiment/online_learning:runs");
+    if (test_interval < -1) throw bad_param("experiment/online_learning:test_interval");
+    if (test_interval >= 0 && !config["test_agent"].ptr()) throw bad_param("experiment/online_learning:test_agent");   // :100-101
+    if (!environment || !agent || (config["test_agent"].ptr() && !test_agent))
+      throw Exception(path() + ": the accelerated path needs environment/modeled, agent/td and agent/fixed");
+    if (config["exporter"].ptr() || !load_file.empty() || save_every != "never" || (int)config["rate"] != 0 || test_trials != 1 || steps != 0)
+      throw Exception(path() + ": exporter/load_file/save_every/rate/test_trials/steps are outside the accelerated path");
+  }
+
+  // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernel makes is checked
+  void lower(grlx_config *c) const
+  {
+    grlx_config_pendulum_sarsa(c);
+    const DynamicalModel *m = environment->model;
+    const Task *t = environment->task;
+    const QPolicy *pol = agent->policy;
+    const TDPredictorBase *pred = agent->predictor;
+    if (pred->projector != pol->projector || pred->representation != pol->representation)
+      throw Exception(pred->path() + ": predictor and policy must share projector and representation on the accelerated path");
+    if (test_agent && (test_agent->policy->projector != pol->projector || test_agent->policy->representation != pol->representation ||
+                       test_agent->policy->discretizer != pol->discretizer))
+      throw Exception(test_agent->path() + ": the test policy must share discretizer, projector and representation with the learning policy");
+    if (!pol->sampler->explores() || (test_agent && test_agent->policy->sampler->explores()))
+      throw Exception(path() + ": the accelerated path needs sampler/epsilon_greedy for learning and sampler/greedy for testing");
+    // RNG streams are consumed in instantiate order: representation, learning sampler, test sampler
+    int at_repr = -1, at_s1 = -1, at_s2 = -1, k = 0;
+    for (Configurator *n : instantiate_order())
+    {
+      if (n->object.get() == pol->representation) at_repr = k;
+      if (n->object.get() == pol->sampler) at_s1 = k;
+      if (test_agent && n->object.get() == test_agent->policy->sampler) at_s2 = k;
+      ++k;
+    }
+    if (!(at_repr >= 0 && at_repr < at_s1 && (!test_agent || at_s1 < at_s2)))
+      throw Exception(path() + ": this yaml instantiates representation/samplers in an order the fused kernel does not reproduce");
+
+    c->test_interval = test_interval;
+    c->env = t->env_id();
+    c->control_step = m->control_step;
+    c->integration_steps = m->integration_steps;
+    c->discrete_time = environment->discrete_time;
+    c->timeout = t->timeout;
+    c->randomization = t->randomization;
+    const UniformDiscretizer *d = pol->discretizer;
+    if (d->min.size() != 1) throw Exception(d->path() + ": one action dimension supported");
+    c->action_min = d->min[0]; c->action_max = d->max[0]; c->action_steps = (int)d->steps[0];
+    const TileCodingProjector *p = pol->projector;
+    memset(&c->projector, 0, sizeof(c->projector));
+    c->projector.tilings = p->tilings; c->projector.memory = p->memory; c->projector.dims = (int)p->resolution.size();
+    if (p->resolution.size() > GRLX_MAX_DIMS) throw bad_param("projector/tile_coding:resolution");
+    for (size_t i = 0; i < p->resolution.size(); ++i) { c->projector.resolution[i] = p->resolution[i]; c->projector.wrapping[i] = p->wrapping[i]; }
+    const LinearRepresentation *r = pol->representation;
+    if (r->outputs != 1) throw Exception(r->path() + ": outputs must be 1 for a Q table");
+    if (r->memory != p->memory) throw bad_param("representation/parameterized/linear:memory (or matching projector)");
+    c->representation.init_min = r->init_min[0]; c->representation.init_max = r->init_max[0];
+    c->representation.output_min = r->output_min[0]; c->representation.output_max = r->output_max[0];
+    c->representation.limit = r->limit;
+    const EpsilonGreedySampler *s = static_cast<const EpsilonGreedySampler *>(pol->sampler);
+    c->epsilon = s->epsilon[0]; c->decay_rate = s->decay_rate; c->decay_min = s->decay_min;
+    c->agent = pred->agent_id();
+    c->alpha = pred->alpha; c->gamma = pred->gamma; c->lambda = pred->lambda;
+    c->trace = pred->trace ? pred->trace->kind() : GRLX_TRACE_NONE;
+  }
+
+  std::vector<double> run(const RunOptions &opt) override
+  {
+    if (trials <= 0) throw Exception(path() + ": trials must be > 0 (the reference's trials: 0 runs forever)");
+    grlx_config c;
+    lower(&c);
+    c.n_replicas = opt.replicas;
+    c.max_rows = (test_interval >= 0 ? trials / (test_interval + 1) : trials) + 1;
+    if (opt.table_log2_capacity) c.table_log2_capacity = opt.table_log2_capacity;
+    std::vector<double> curve;
+
+    if (!output.empty())
+    { // store the resolved configuration with the output (online_learning.cpp:117-122)
+      std::ofstream ofs(output + ".yaml");
+      ofs << configurator->root()->yaml();
+    }
+    for (int rr = run_offset; rr < runs + run_offset; ++rr)
+    {
+      std::vector<int64_t> seeds((size_t)opt.replicas);
+      for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i + (int64_t)(rr - run_offset) * opt.replicas;
+      grlx_ctx *ctx = nullptr;
+      if (grlx_create(&c, seeds.data(), &ctx) != GRLX_OK) throw Exception(grlx_last_error());
+      auto start = std::chrono::steady_clock::now();
+      int rc = grlx_run(ctx, trials, nullptr);
+      if (rc == GRLX_OK) rc = grlx_sync(ctx, nullptr);
+      if (rc != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
+      double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+
+      const int n = grlx_rows(ctx);
+      std::vector<int64_t> trial((size_t)n), stp((size_t)n);
+      std::vector<double> reward((size_t)n);
+      const double episode_time = c.control_step * std::floor(c.timeout / c.control_step + 1);
+      for (int i = 0; i < opt.replicas; ++i)
+      {
+        grlx_read_rows(ctx, i, 0, n, trial.data(), stp.data(), reward.data());
+        std::ostringstream name;                       // <output>-<run><identity>.txt, identity "@i" for clones (multi.cpp:52-56)
+        name << output << "-" << rr;
+        if (opt.replicas > 1) name << "@" << i;
+        name << ".txt";
+        std::ofstream ofs;
+        if (!output.empty()) ofs.open(name.str());
+        for (int k = 0; k < n; ++k)
+        {
+          std::ostringstream oss;
+          if (opt.legacy_rows)                         // the 3-column layout of the reference's committed golden files
+            oss << std::setw(15) << trial[(size_t)k] << std::setw(15) << stp[(size_t)k] << std::setw(15) << reward[(size_t)k];
+          else                                         // online_learning.cpp:243
+            oss << std::setw(15) << trial[(size_t)k] << std::setw(15) << stp[(size_t)k] << std::setw(15) << std::setprecision(3) << std::fixed
+                << reward[(size_t)k] << std::setw(15) << std::setprecision(3) << episode_time << std::setw(15) << std::setprecision(3)
+                << reward[(size_t)k] / episode_time << std::setw(15) << std::setprecision(3) << wall;
+          if (ofs.is_open()) ofs << oss.str() << std::endl;
+          if (i == 0 && opt.print_rows) std::cout << oss.str() << std::endl;
+        }
+        if (i == 0) curve = reward;
+      }
+      uint64_t learn = 0, test = 0;
+      grlx_step_counts(ctx, &learn, &test);
+      std::ostringstream msg;
+      msg << "run " << rr << ": " << opt.replicas << " replicas, " << (learn + test) << " env-steps in " << wall << " s = "
+          << (double)(learn + test) / wall / 1e6 << " M env-steps/s";
+      log(2, msg.str());
+      grlx_destroy(ctx);
+    }
+    return curve;
+  }
+};
+GRLX_REGISTER(OnlineLearningExperimentImpl)
+
+} // namespace grlx_host

@@ -303,3 +303,21 @@ def test_curve_stats_device(grlx):
     np.testing.assert_allclose(out[:, 1].cpu().numpy(), (rew ** 2).sum(0), rtol=1e-13)
     assert (out[:, 2].cpu().numpy() == n).all()
     r.close()
+
+
+def test_deployer_reproduces_golden_file(grlx, tmp_path):
+    """The reference's own regression test (bin/runtests.py:21-43): run the deployer on
+    tests/pendulum-sarsa-tc.yaml with seed 1 and byte-compare `<output>-0.txt` with the template."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    yaml = os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")
+    res = subprocess.run([grlxd, "-s", "1", "-l", "-q", yaml], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == open(GOLDEN).read()
+    # clones: replica i is seeded seed+i and writes <output>-0@i.txt (multi.cpp:52-56)
+    res = subprocess.run([grlxd, "-s", "1", "-l", "-q", "-r", "3", "-t", "110", yaml], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    first = (tmp_path / "pendulum-sarsa-tc-0@0.txt").read_text()
+    assert first == "".join(open(GOLDEN).readlines()[:10])
+    assert (tmp_path / "pendulum-sarsa-tc-0@2.txt").read_text() != first

@@ -1,0 +1,62 @@
+"""The C++ host layer (grl's Configurable / YAML / deployer roles) without a GPU: it must
+instantiate the reference's own yaml, resolve references and provided parameters, reproduce
+the reference's bad_param conditions, and refuse to compute without a device."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+YAML = os.path.join(ROOT, "tests", "golden", "pendulum-sarsa-tc.yaml")
+
+
+@pytest.fixture(scope="module")
+def grlxd():
+    from grl_amd import _build
+    return _build.build_host()
+
+
+def run(grlxd, args, cwd):
+    return subprocess.run([grlxd] + args, cwd=cwd, capture_output=True, text=True, timeout=120)
+
+
+def test_instantiates_reference_yaml(grlxd, tmp_path):
+    from grl_amd import capi
+    res = run(grlxd, ["-s", "1", "-l", "-q", YAML], tmp_path)
+    dumped = (tmp_path / "pendulum-sarsa-tc.yaml").read_text()
+    # references and provided parameters resolved (configurable.cpp:355-432, 691-712)
+    assert "min: [ -3 ]" in dumped and "max: [ 3 ]" in dumped            # experiment/environment/task/action_min
+    assert "memory: 8388608" in dumped                                    # ../../projector/memory
+    assert "projector: experiment/agent/policy/projector" in dumped       # object reference
+    assert "type: predictor/sarsa" in dumped or "type: predictor/critic/sarsa" in dumped
+    if capi.load().grlx_device_count() == 0:
+        assert res.returncode == 1 and "no HIP device" in res.stderr     # no CPU fallback
+
+
+def _variant(tmp_path, old, new):
+    text = open(YAML).read()
+    assert old in text
+    p = tmp_path / "variant.yaml"
+    p.write_text(text.replace(old, new))
+    return str(p)
+
+
+@pytest.mark.parametrize("old,new,needle", [
+    ("wrapping: [ 6.283, 0, 0 ]", "wrapping: [ 1.0, 0, 0 ]", "projector/tile_coding:wrapping"),        # tile_coding.cpp:72-78
+    ("steps: [ 3 ]", "steps: [ 3, 3 ]", "discretizer/uniform:{min,max,steps}"),                          # uniform.cpp:66-67
+    ("init_min: [ 0 ]", "init_min: [ 0, 1, 2 ]", "representation/parameterized/linear:init_min"),       # linear.cpp:62-66
+    ("type: dynamics/pendulum", "type: dynamics/flyer2d", "unknown object type"),
+    ("safe: 0", "safe: 1", "safe >= 1"),
+    ("      sampler:\n        type: sampler/greedy", "      sampler:\n        type: sampler/epsilon_greedy", "sampler/greedy for testing"),
+    ("      sampler:\n        epsilon: 0.05\n        type: sampler/epsilon_greedy\n", "", "required parameter 'sampler'"),
+])
+def test_bad_configurations_are_refused(grlxd, tmp_path, old, new, needle):
+    res = run(grlxd, ["-s", "1", "-q", _variant(tmp_path, old, new)], tmp_path)
+    assert res.returncode == 1
+    assert needle in res.stderr, res.stderr
+
+
+def test_usage_and_seed_errors(grlxd, tmp_path):
+    assert run(grlxd, [], tmp_path).returncode == 1
+    res = run(grlxd, ["-s", "0", YAML], tmp_path)
+    assert res.returncode == 1 and "seed 0" in res.stderr
