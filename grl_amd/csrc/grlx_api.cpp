@@ -66,6 +66,7 @@ int env_dims(int env, int *S, int *D)
   switch (env)
   {
     case GRLX_ENV_PENDULUM: *S = 3; *D = 2; return GRLX_OK;
+    case GRLX_ENV_ACROBOT: *S = 5; *D = 4; return GRLX_OK;
     default: return GRLX_ERR_INVALID;
   }
 }

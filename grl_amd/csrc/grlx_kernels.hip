@@ -434,6 +434,67 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
   }
 };
 
+// dynamics/acrobot + task/acrobot/balancing (acrobot.cpp:48-151); state = [theta1, theta2,
+// thetad1, thetad2, time].  No reference test pins it: parity is against the oracle only.
+template <> struct Env<GRLX_ENV_ACROBOT> {
+  static constexpr int S = 5, D = 4;
+  __device__ static __forceinline__ void eom(const double *x, double u, double *xd)
+  { // acrobot.cpp:48-79, expression for expression
+    const double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
+    const double theta1 = x[0], theta2 = x[1], thetad1 = x[2], thetad2 = x[3];
+    const double tau = u;
+    double sin2, cos2;
+    psincos(theta2, sin2, cos2);
+
+    double phi2 = m2*lc2*g*pcos(theta1+theta2-GRLX_PI/2);
+    double phi1 = -m2*l1*lc2*thetad2*thetad2*sin2-2*m2*l1*lc2*thetad2*thetad1*sin2 +
+                  (m1*lc1+m2*l1)*g*pcos(theta1-GRLX_PI/2)+phi2;
+    double d2 = m2*(lc2*lc2+l1*lc2*cos2)+I2;
+    double d1 = m1*lc1*lc1 + m2*(l1*l1+lc2*lc2+2*l1*lc2*cos2)+I1+I2;
+    double thetadd2 = (tau+d2*phi1/d1-m2*l1*lc2*thetad2*thetad2*sin2-phi2)/
+                      (m2*lc2*lc2+I2-d2*d2/d1);
+    double thetadd1 = -(d2*thetadd2+phi1)/d1;
+
+    if (thetad1 >  4*GRLX_PI) thetadd1 = fmin(thetadd1, 0.);
+    if (thetad1 < -4*GRLX_PI) thetadd1 = fmax(thetadd1, 0.);
+    if (thetad2 >  9*GRLX_PI) thetadd2 = fmin(thetadd2, 0.);
+    if (thetad2 < -9*GRLX_PI) thetadd2 = fmax(thetadd2, 0.);
+
+    xd[0] = thetad1;
+    xd[1] = thetad2;
+    xd[2] = thetadd1;
+    xd[3] = thetadd2;
+    xd[4] = 1;
+  }
+  __device__ static __forceinline__ bool failed(const double *x)
+  { // :147-151
+    return __builtin_fabs(x[0]-GRLX_PI) > 12*GRLX_PI/180 || __builtin_fabs(x[1]) > 12*GRLX_PI/180;
+  }
+  __device__ static __forceinline__ void start(const DevParams &, int, uint64_t &TL, uint64_t &, double *x)
+  { // :102-107
+    TL = lcg_next(TL);
+    const double r1 = lcg_double(TL);
+    TL = lcg_next(TL);
+    const double r2 = lcg_double(TL);
+    x[0] = GRLX_PI+r1*0.01-0.005;
+    x[1] = r2*0.01-0.005;
+    x[2] = 0; x[3] = 0; x[4] = 0;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return a; }                  // Task::actuate default (environment.h:94)
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[0]) < 0x1p18 && __builtin_fabs(x[1]) < 0x1p18; }
+  __device__ static __forceinline__ int observe(const DevParams &, const double *x, double *obs)
+  { // :109-125
+#pragma unroll
+    for (int i = 0; i < 4; ++i) obs[i] = x[i];
+    if (failed(x)) return 2;
+    return x[4] > 20 ? 1 : 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &, const double *, double, const double *next)
+  { // :127-133
+    return failed(next) ? 0. : 1.;
+  }
+};
+
 // DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps.
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
@@ -1205,6 +1266,7 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
   }
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 3)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 5)
+  GRLX_LAUNCH(GRLX_ENV_ACROBOT, 3)
 #undef GRLX_LAUNCH
   return hipErrorInvalidValue;
 }
@@ -1260,6 +1322,10 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
   {
     case GRLX_ENV_PENDULUM:
       hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_PENDULUM>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
+                         obs_dev, reward_dev, terminal_dev, err_dev);
+      break;
+    case GRLX_ENV_ACROBOT:
+      hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_ACROBOT>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
                          obs_dev, reward_dev, terminal_dev, err_dev);
       break;
     default:

@@ -70,6 +70,36 @@ struct PendulumSwingupTask : Task {
 };
 GRLX_REGISTER(PendulumSwingupTask)
 
+// dynamics/acrobot, task/acrobot/balancing (acrobot.cpp:36-100): no parameters; the class
+// default control step of model/dynamical (0.05 s) applies
+struct AcrobotDynamics : Dynamics {
+  GRLX_TYPEINFO("dynamics/acrobot")
+  int env_id() const override { return GRLX_ENV_ACROBOT; }
+};
+GRLX_REGISTER(AcrobotDynamics)
+struct AcrobotBalancingTask : Task {
+  GRLX_TYPEINFO("task/acrobot/balancing")
+  int env_id() const override { return GRLX_ENV_ACROBOT; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    for (const char *n : {"observation_dims", "observation_min", "observation_max", "action_dims", "action_min", "action_max", "reward_min", "reward_max"})
+      config->push_back(CRP::provided(n, std::string("vector.") + n, "Task limits"));
+  }
+  void configure(Configuration &config) override
+  {
+    timeout = 20;                                       // acrobot.cpp:125 (fixed)
+    config.set("observation_dims", 4);
+    config.set("observation_min", VecD{kPi - 12 * kPi / 180, -12 * kPi / 180, -0.6, -1.1});
+    config.set("observation_max", VecD{kPi + 12 * kPi / 180, 12 * kPi / 180, 0.6, 1.1});
+    config.set("action_dims", 1);
+    config.set("action_min", VecD{-1});
+    config.set("action_max", VecD{1});
+    config.set("reward_min", 1.);
+    config.set("reward_max", 1.);
+  }
+};
+GRLX_REGISTER(AcrobotBalancingTask)
+
 // model/dynamical (modeled.cpp:234-252)
 struct DynamicalModel : Configurable {
   GRLX_TYPEINFO("model/dynamical")

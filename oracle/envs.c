@@ -2,7 +2,8 @@
  *
  * ModeledEnvironment + DynamicalModel (RK4): base/src/environments/modeled.cpp:132-276
  * Pendulum dynamics + swing-up task:          base/src/environments/pendulum.cpp:40-145
- * (cart-pole, acrobot, compass walker are added by later sections of this file.)
+ * Acrobot dynamics + balancing task:         base/src/environments/acrobot.cpp:48-151
+ *   (no reference test pins the acrobot: parity unpinned by reference tests)
  *
  * All arithmetic is IEEE double in the reference's expression order with no
  * fused multiply-add (compile with -ffp-contract=off).
@@ -30,6 +31,7 @@ int orc_env_state_dims(int env)
   switch (env)
   {
     case ORC_ENV_PENDULUM: return 3;
+    case ORC_ENV_ACROBOT: return 5;
     default: return -1;
   }
 }
@@ -39,6 +41,7 @@ int orc_env_obs_dims(int env)
   switch (env)
   {
     case ORC_ENV_PENDULUM: return 2;
+    case ORC_ENV_ACROBOT: return 4;
     default: return -1;
   }
 }
@@ -81,12 +84,62 @@ static double pendulum_evaluate(const orc_spec *s, const double *x, double actio
   return reward;
 }
 
+/* -------------------------------------------------------------- acrobot -- */
+static void acrobot_eom(const orc_spec *s, const double *x, double u, double *xd)
+{ /* acrobot.cpp:48-79; state = [theta1, theta2, thetad1, thetad2, time] */
+  double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
+  double theta1 = x[0], theta2 = x[1], thetad1 = x[2], thetad2 = x[3];
+  double tau = u;
+  double sin2 = orc_m_sin(s, theta2), cos2 = orc_m_cos(s, theta2);
+
+  double phi2 = m2*lc2*g*orc_m_cos(s, theta1+theta2-M_PI/2);
+  double phi1 = -m2*l1*lc2*thetad2*thetad2*sin2-2*m2*l1*lc2*thetad2*thetad1*sin2 +
+                (m1*lc1+m2*l1)*g*orc_m_cos(s, theta1-M_PI/2)+phi2;
+  double d2 = m2*(lc2*lc2+l1*lc2*cos2)+I2;
+  double d1 = m1*lc1*lc1 + m2*(l1*l1+lc2*lc2+2*l1*lc2*cos2)+I1+I2;
+  double thetadd2 = (tau+d2*phi1/d1-m2*l1*lc2*thetad2*thetad2*sin2-phi2)/
+                    (m2*lc2*lc2+I2-d2*d2/d1);
+  double thetadd1 = -(d2*thetadd2+phi1)/d1;
+
+  /* limit velocity */
+  if (thetad1 >  4*M_PI) thetadd1 = fmin(thetadd1, 0);
+  if (thetad1 < -4*M_PI) thetadd1 = fmax(thetadd1, 0);
+  if (thetad2 >  9*M_PI) thetadd2 = fmin(thetadd2, 0);
+  if (thetad2 < -9*M_PI) thetadd2 = fmax(thetadd2, 0);
+
+  xd[0] = thetad1;
+  xd[1] = thetad2;
+  xd[2] = thetadd1;
+  xd[3] = thetadd2;
+  xd[4] = 1;
+}
+
+static int acrobot_failed(const double *x)
+{ /* acrobot.cpp:147-151 */
+  return fabs(x[0]-M_PI) > 12*M_PI/180 || fabs(x[1]) > 12*M_PI/180;
+}
+
+static void acrobot_start(orc_exp *e, double *x)
+{ /* acrobot.cpp:102-107: two RandGen draws, angle 1 first */
+  for (int i = 0; i < 5; ++i) x[i] = 0.;
+  x[0] = M_PI+orc_drand48(&e->TL)*0.01-0.005;
+  x[1] = orc_drand48(&e->TL)*0.01-0.005;
+}
+
+static int acrobot_observe(const double *x, double *obs)
+{ /* acrobot.cpp:109-125 */
+  for (int i = 0; i < 4; ++i) obs[i] = x[i];
+  if (acrobot_failed(x)) return 2;
+  return x[4] > 20;
+}
+
 /* ------------------------------------------------------ generic dispatch -- */
 static void env_eom(const orc_spec *s, const double *x, double u, double *xd)
 {
   switch (s->env)
   {
     case ORC_ENV_PENDULUM: pendulum_eom(s, x, u, xd); break;
+    case ORC_ENV_ACROBOT: acrobot_eom(s, x, u, xd); break;
   }
 }
 
@@ -104,6 +157,7 @@ void orc_env_start(const orc_spec *s, orc_exp *e, int test, double *x)
   switch (s->env)
   {
     case ORC_ENV_PENDULUM: pendulum_start(s, e, test, x); break;
+    case ORC_ENV_ACROBOT: acrobot_start(e, x); break;
   }
 }
 
@@ -112,6 +166,7 @@ int orc_env_observe(const orc_spec *s, const double *x, double *obs)
   switch (s->env)
   {
     case ORC_ENV_PENDULUM: return pendulum_observe(s, x, obs);
+    case ORC_ENV_ACROBOT: return acrobot_observe(x, obs);
   }
   return 0;
 }
@@ -156,6 +211,7 @@ double orc_env_step(const orc_spec *s, double *state, double action,
   switch (s->env)
   {
     case ORC_ENV_PENDULUM: *reward = pendulum_evaluate(s, state, action, next); break;
+    case ORC_ENV_ACROBOT: *reward = !acrobot_failed(next); break;        /* acrobot.cpp:127-133 */
     default: *reward = 0;
   }
   memcpy(state, next, sizeof(double) * S);

@@ -297,7 +297,8 @@ static double *table_alloc_init(orc_exp *e, const orc_tile_spec *ts, const orc_l
 
 orc_exp *orc_create(const orc_spec *spec, long seed)
 {
-  if (spec->env != ORC_ENV_PENDULUM) return NULL;                 /* others: later sections */
+  if (orc_env_state_dims(spec->env) < 0) return NULL;             /* environments not restated yet */
+  if (spec->projector.dims != orc_env_obs_dims(spec->env) + 1) return NULL;
   if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q) return NULL;
   if (spec->action_steps < 1 || spec->action_steps > ORC_MAX_ACTIONS) return NULL;
   if (spec->projector.tilings > ORC_MAX_TILINGS) return NULL;

@@ -196,13 +196,14 @@ def test_table_ops_match_dense_reference(grlx):
 
 
 # ---------------------------------------------------------- fused path -----
-def _compare_taps(gt, ot, A=3):
+def _compare_taps(gt, ot, A=3, D=2):
     assert gt.test == ot.test and gt.terminal == ot.terminal
     assert gt.action_index == ot.action_index, (gt.action_index, ot.action_index)
     assert list(gt.p_idx[:16]) == list(ot.p_idx[:16])
-    assert_bit_equal(list(gt.obs[:2]), list(ot.obs[:2]), "obs")
+    assert_bit_equal(list(gt.obs[:D]), list(ot.obs[:D]), "obs")
     assert_bit_equal([gt.reward, gt.action, gt.delta], [ot.reward, ot.action, ot.delta], "reward/action/delta")
-    assert_bit_equal(list(gt.q[:A]), list(ot.q[:A]), "q")
+    if ot.terminal != 2:                               # no next action after an absorbing state (td.cpp:76-81)
+        assert_bit_equal(list(gt.q[:A]), list(ot.q[:A]), "q")
     assert gt.trace_len == ot.trace_len
 
 
@@ -321,3 +322,52 @@ def test_deployer_reproduces_golden_file(grlx, tmp_path):
     first = (tmp_path / "pendulum-sarsa-tc-0@0.txt").read_text()
     assert first == "".join(open(GOLDEN).readlines()[:10])
     assert (tmp_path / "pendulum-sarsa-tc-0@2.txt").read_text() != first
+
+
+# ------------------------------------------------------------- acrobot -----
+def test_acrobot_env_step_bit_exact(grlx):
+    from tests import configs
+    cfg, spec = configs.acrobot(grlx, 1)
+    rng = np.random.default_rng(11)
+    n = 4000
+    state = np.stack([np.pi + rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-15, 15, n),
+                      rng.uniform(-30, 30, n), rng.uniform(0, 19.9, n)], axis=1)
+    state[:200, 2] = rng.uniform(12, 14, 200)           # beyond the velocity limits (acrobot.cpp:68-72)
+    state[200:400, 3] = -rng.uniform(28, 30, 200)
+    action = rng.choice([-1.0, 0.0, 1.0], n)
+    for _ in range(3):
+        gs, gobs, grew, gterm = grlx.runner.env_step(cfg, state, action)
+        os_, oobs, orew, oterm = ob.env_step(spec, state, action)
+        assert_bit_equal(gs, os_, "state"); assert_bit_equal(gobs, oobs, "obs"); assert_bit_equal(grew, orew, "reward")
+        assert (gterm == oterm).all() and set(np.unique(gterm)) >= {0, 2}
+        state = gs
+
+
+@pytest.mark.parametrize("agent", [0, 1])
+def test_acrobot_fused_bit_exact(grlx, agent):
+    """Episodes end by absorbing failure (terminal 2 -> TDAgent::end, td.cpp:76-81) at different
+    lengths per replica; every step of one replica and the rows of all are compared."""
+    from tests import configs
+    seeds = [21, 22, 23, 24, 25, 26]
+    trials, cap = 44, 20000
+    cfg, spec = configs.acrobot(grlx, len(seeds), agent=agent, tap_replica=3, tap_capacity=cap)
+    r = grlx.Runner(cfg, seeds)
+    r.run(20); r.run(24); r.sync()
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, otaps = e.run(trials, tap_cap=cap)
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3]
+        assert_bit_equal(r.env_state(k), e.state(), "env state")
+        if k == 3:
+            gtaps = r.taps()
+            assert len(gtaps) == len(otaps) and len(otaps) > 100
+            assert any(tp.terminal == 2 for tp in otaps)
+            for i, (gt, ot) in enumerate(zip(gtaps, otaps)):
+                try:
+                    _compare_taps(gt, ot, D=4)
+                except AssertionError as ex:
+                    raise AssertionError(f"step {i}: {ex}")
+    r.close()
