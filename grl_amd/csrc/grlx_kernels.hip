@@ -596,6 +596,381 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 // makes both the per-lane writes and the 4 simultaneous broadcast reads conflict-free.
 #define SHW(row, k, g) sh_w[(((row) * 16 + (k)) << 2) + (g)]
 
+// ------------------------------------------------------- register trace ----
+// Replacing eligibility trace (trace.h:208-235) of one tiling, newest first, kept in
+// registers.  val is the AUTHORITATIVE weight of the slot while it is in the trace: it is
+// written back to the table only when the slot leaves the trace (write-back), unless the
+// slot is shared with another tiling (bit e of wt): then every update is also stored
+// (write-through) so that the other lane's loads see it.
+struct TraceRegs {
+  uint32_t pos[kMaxTrace];
+  double   val[kMaxTrace];
+  uint32_t cnt[kMaxTrace];
+  uint32_t wt;
+  bool     dup;                 // some entry occurs twice in its projection (sticky until cleared)
+  int      len;
+  double   total;
+};
+
+__device__ __forceinline__ void trace_init(TraceRegs &tr)
+{
+#pragma unroll
+  for (int e = 0; e < kMaxTrace; ++e) { tr.pos[e] = kInvalidPos; tr.val[e] = 0; tr.cnt[e] = 0; }
+  tr.wt = 0;
+  tr.dup = false;
+  tr.len = 0;
+  tr.total = 1.;
+}
+
+// write every cached weight back; optionally forget the entries (EnumeratedTrace::clear)
+__device__ __forceinline__ void trace_flush(TraceRegs &tr, const Table &tab, bool clear)
+{
+#pragma unroll
+  for (int e = 0; e < kMaxTrace; ++e)
+  {
+    if (tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u)) value_store(tab, tr.pos[e], tr.val[e]);
+    if (clear) tr.pos[e] = kInvalidPos;
+  }
+  if (clear)
+  {
+    tr.wt = 0;
+    tr.dup = false;
+    tr.len = 0;
+    tr.total = 1.;
+  }
+}
+
+// a slot that is in this lane's trace has its current weight in val, not (yet) in the table
+__device__ __forceinline__ double trace_forward(const TraceRegs &tr, uint32_t pos, double w)
+{
+#pragma unroll
+  for (int e = 0; e < kMaxTrace; ++e) w = (tr.pos[e] == pos) ? tr.val[e] : w;
+  return w;
+}
+
+// slot `mp` has just become shared between tilings: the owner writes its cached weight back
+// and keeps the table current from now on
+__device__ __forceinline__ void trace_share_event(TraceRegs &tr, const Table &tab, uint32_t mp)
+{
+#pragma unroll
+  for (int e = 0; e < kMaxTrace; ++e)
+    if (tr.pos[e] == mp && !((tr.wt >> e) & 1u))
+    {
+      value_store(tab, mp, tr.val[e]);
+      tr.wt |= 1u << e;
+    }
+}
+
+struct UpdateParams {
+  double dW, dT, ee, cut, out_min, out_max;
+  bool   limit, use_trace;
+};
+
+__device__ __forceinline__ double add_clamped(const UpdateParams &u, double v, double d)
+{
+  return u.limit ? clampd(v + d, u.out_min, u.out_max) : v + d;
+}
+
+// One TD update of a linear representation with a replacing trace, as the reference orders it:
+//   write(p, target, alpha)            -> every slot of p gets +dW          (linear.cpp:186-216)
+//   update(trace, alpha*delta, e)      -> entry k gets +weight_k*dT*ee      (representation.h:79-83)
+//   trace->add(p, e)                   -> ssub, push, pop                   (trace.h:215-234)
+// Lane j handles tiling j.  Returns nothing; p's final weight becomes trace entry 0.
+// sh_ppos / sh_fb / sh_fbflag: LDS scratch of the wave (see rollout kernels).
+__device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, const UpdateParams &u, uint32_t p_pos, bool p_sh, double wp,
+                                               int g, int j, const uint32_t *sh_ppos, double *sh_fb, uint32_t *sh_fbflag, uint32_t &status)
+{
+  // Aliasing between p and the trace (IndexProjection::ssub, projection.h:94-104).  Inside a
+  // lane it is a register compare.  Across lanes it needs a p that is a slot shared between
+  // tilings (only such a slot can sit in another lane's trace, or twice in p): those lanes'
+  // positions are compared through LDS -- usually none.
+  const uint32_t shmask = (uint32_t)((__ballot(p_sh) >> (16 * g)) & 0xFFFFull);
+  uint32_t cp = 1;                                     // occurrences of my slot inside p
+  double v;                                            // final weight of p's slot after this step
+  if (!__any(shmask != 0u || tr.dup))
+  { // ---- common case (no lane of the wave has a shared p, no slot occurs twice): aliasing
+    // is a register compare inside the lane; straight-line code, no exec-mask branches
+    double a_val = 0, a_de = 0;
+    bool aliased = false, a_upd = false;
+    uint32_t stmask = 0;
+    if (u.use_trace)
+    {
+      double weight = 1.;
+      bool upd = true;
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+      {
+        const bool in = e < tr.len;
+        upd = upd && (!in || weight > 0.001);            // representation.h:81
+        const double de = weight * u.dT * u.ee;
+        const bool valid = in && tr.pos[e] != kInvalidPos;
+        const bool own = valid && tr.pos[e] == p_pos;
+        const double vv = add_clamped(u, tr.val[e], de);
+        const bool doit = valid && !own && upd;
+        tr.val[e] = doit ? vv : tr.val[e];
+        stmask |= (doit && ((tr.wt >> e) & 1u)) ? (1u << e) : 0u;
+        a_val = own ? tr.val[e] : a_val;
+        a_de = own ? de : a_de;
+        a_upd = own ? upd : a_upd;
+        aliased = aliased || own;
+        tr.pos[e] = own ? kInvalidPos : tr.pos[e];       // ssub: the slot leaves the trace
+        tr.wt = own ? (tr.wt & ~(1u << e)) : tr.wt;
+        weight = in ? weight * u.ee : weight;
+      }
+    }
+    // p's write first, then the aliased entry's update (if it is still being updated)
+    const double base = aliased ? a_val : wp;
+    const double v1 = add_clamped(u, base, u.dW);
+    const double v2 = add_clamped(u, v1, a_de);
+    v = (aliased && a_upd) ? v2 : v1;
+    if (__any(stmask != 0u))
+    {
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+        if ((stmask >> e) & 1u) value_store(tab, tr.pos[e], tr.val[e]);   // shared slot: keep the table current
+    }
+  }
+  else
+  { // ---- general case
+    uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
+#pragma unroll
+    for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
+    for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
+    {
+      const int k = __builtin_ctz(mm);
+      const uint32_t ppk = sh_ppos[g * 16 + k];
+      if (k != j)
+      {
+        if (ppk == p_pos) cp++;
+#pragma unroll
+        for (int e = 0; e < kMaxTrace; ++e) xm[e] |= (tr.pos[e] == ppk) ? (1u << k) : 0u;
+      }
+    }
+    double v_alias = 0;
+    bool aliased = false;
+    if (u.use_trace)
+    { // trace entries, newest first (representation.h:79-83, trace.h:150-178)
+      double weight = 1.;
+      bool upd = true;
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+        if (e < tr.len)
+        {
+          upd = upd && (weight > 0.001);
+          const double de = weight * u.dT * u.ee;
+          if (tr.pos[e] != kInvalidPos)
+          {
+            const bool own = tr.pos[e] == p_pos;
+            if (!own && xm[e] == 0u)
+            {
+              if (upd)
+              { // LinearRepresentation::update (linear.cpp:198-216); a slot that occurs twice in
+                // its projection is updated twice
+                double vv = add_clamped(u, tr.val[e], de);
+                if ((tr.wt >> e) & 1u)
+                {
+                  for (uint32_t c = 1; c < tr.cnt[e]; ++c) vv = add_clamped(u, vv, de);
+                  value_store(tab, tr.pos[e], vv);
+                }
+                tr.val[e] = vv;
+              }
+            }
+            else
+            { // the slot is also written through p: p's write comes first, then this entry's
+              // update; the slot leaves the trace
+              if (upd)
+              {
+                double vv = tr.val[e];
+                const uint32_t cpx = (own ? 1u : 0u) + (uint32_t)__builtin_popcount(xm[e]);
+                for (uint32_t c = 0; c < cpx; ++c) vv = add_clamped(u, vv, u.dW);
+                for (uint32_t c = 0; c < tr.cnt[e]; ++c) vv = add_clamped(u, vv, de);
+                if (own) { v_alias = vv; aliased = true; }
+                for (uint32_t mm = xm[e]; mm != 0u; mm &= mm - 1u)
+                {
+                  const int k = __builtin_ctz(mm);
+                  sh_fb[k * 4 + g] = vv;
+                  sh_fbflag[k * 4 + g] = 1u;
+                }
+              }
+              tr.pos[e] = kInvalidPos;
+              tr.wt &= ~(1u << e);
+            }
+          }
+          weight *= u.ee;
+        }
+    }
+    wave_sync();
+    if (aliased)
+      v = v_alias;
+    else if (shmask != 0u && sh_fbflag[j * 4 + g] != 0u)
+      v = sh_fb[j * 4 + g];
+    else
+    {
+      v = wp;
+      for (uint32_t c = 0; c < cp; ++c) v = add_clamped(u, v, u.dW);
+    }
+  }
+  // a shared slot is kept current in the table; an exclusive one only if no trace follows
+  if (p_sh || !u.use_trace) value_store(tab, p_pos, v);
+
+  // trace_->add(p, decay) (trace.h:215-234)
+  if (u.use_trace)
+  {
+    if (u.ee < u.cut) trace_flush(tr, tab, true);          // decay below the cut: clear() first
+    if (tr.len >= kMaxTrace) status |= ST_TRACE_OVERFLOW;  // cannot happen: validated at create
+#pragma unroll
+    for (int e = kMaxTrace - 1; e > 0; --e)
+    {
+      tr.pos[e] = tr.pos[e - 1];
+      tr.val[e] = tr.val[e - 1];
+      tr.cnt[e] = tr.cnt[e - 1];
+    }
+    tr.wt = (tr.wt << 1) & ((1u << kMaxTrace) - 1u);
+    tr.pos[0] = p_pos;
+    tr.val[0] = v;
+    tr.cnt[0] = cp;
+    tr.dup = tr.dup || cp > 1u;
+    if (p_sh) tr.wt |= 1u;
+    tr.len = (tr.len < kMaxTrace) ? tr.len + 1 : kMaxTrace;
+    tr.total *= u.ee;
+    while (tr.total < u.cut && tr.len > 1)
+    {
+      tr.total /= u.ee;
+      tr.len--;
+    }
+    // entries popped off the front of the reference's deque: write their weights back
+#pragma unroll
+    for (int e = 0; e < kMaxTrace; ++e)
+      if (e >= tr.len)
+      {
+        if (tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u)) value_store(tab, tr.pos[e], tr.val[e]);
+        tr.pos[e] = kInvalidPos;
+        tr.wt &= ~(1u << e);
+      }
+  }
+}
+
+// Lookup-or-create of NP slots of one lane in one table, all first-round loads in flight
+// together; creates missing slots (parallel LDS-ranked claims, serialised fallback) and
+// resolves new cross-tiling sharing events.  sh[i]: the slot is shared between tilings.
+// on_share(mp): called in every lane of the group for each slot position that just became shared.
+template <int NP, typename OnShare>
+__device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
+                                          uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
+                                          uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, uint32_t &status, uint32_t &inserted, OnShare on_share)
+{
+  const int lane = threadIdx.x & 63;
+  Lookup lk[NP];
+  table_lookup<NP>(tab, slot, lk, w, status);
+  bool anymiss = false;
+#pragma unroll
+  for (int a = 0; a < NP; ++a) anymiss = anymiss || lk[a].miss;
+  if (__any(anymiss))
+  { // Create the missing slots.  All lookups of this call are complete, so every lane that
+    // misses into bucket B saw the same empty ways of B.  Claims are ranked in the fixed order
+    // (index, tiling) through LDS: the r-th claimant of a bucket takes its r-th empty way -- no
+    // reload, all lanes in parallel.  Equal slots claimed twice (a hash collision inside one
+    // state) or a bucket with too few empty ways fall back to the serialised path.
+    double w0[NP];
+    bool slow[NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+    {
+      sh_mb[g * (NP * 16) + a * 16 + j] = lk[a].miss ? lk[a].bucket : 0xFFFFFFFFu;
+      sh_ms[g * (NP * 16) + a * 16 + j] = slot[a];
+      w0[a] = 0;
+      slow[a] = false;
+      if (lk[a].miss) w0[a] = lazy_weight(tl0, lp, slot[a]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+      if (lk[a].miss)
+      {
+        const int me = a * 16 + j;
+        uint32_t rank = 0;
+        bool dup = false;
+        for (int k = 0; k < NP * 16; ++k)
+        {
+          const uint32_t ob = sh_mb[g * (NP * 16) + k], os = sh_ms[g * (NP * 16) + k];
+          if (ob == lk[a].bucket && k != me)
+          {
+            if (os == slot[a]) dup = true;
+            else if (k < me) rank++;
+          }
+        }
+        uint32_t e = lk[a].empty;
+        for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;      // drop the ways taken by earlier claimants
+        if (dup || e == 0u)
+          slow[a] = true;
+        else
+        {
+          lk[a].pos = (lk[a].bucket << 2) | (uint32_t)__builtin_ctz(e);
+          lk[a].kw = 0u;
+          entry_create(tab, lk[a].pos, slot[a], (uint32_t)j, w0[a]);
+          w[a] = w0[a];
+          inserted++;
+        }
+      }
+    wave_sync();
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+      if (__any(slow[a]))
+        table_insert_serial(tab, slow[a], slot[a], (uint32_t)j, w0[a], lk[a], w[a], status, inserted);
+  }
+
+  // ---- slots shared between tilings (a collision of the reference's hash across tilings,
+  // ~70 per replica and run).  A slot found with a foreign owner and no shared bit yet is a
+  // NEW sharing event: mark it in the table and tell the owner's lane, whose trace may hold
+  // the only current copy of the weight.
+  bool fresh[NP];
+  bool anyfresh = false;
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+  {
+    pos[a] = lk[a].pos;
+    const bool found = lk[a].kw != 0u;
+    const bool foreign = found && ((lk[a].kw >> kOwnerShift) & 31u) != (uint32_t)j;
+    sh[a] = found && (foreign || (lk[a].kw & kSharedBit) != 0u);
+    fresh[a] = foreign && (lk[a].kw & kSharedBit) == 0u;
+    anyfresh = anyfresh || fresh[a];
+  }
+  if (__any(anyfresh))
+  {
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+    {
+      if (fresh[a]) tab.base[pos[a] >> 2].key[pos[a] & 3u] = lk[a].kw | kSharedBit;
+      unsigned long long pend = __ballot(fresh[a]);
+      while (pend != 0ull)
+      { // one event per 16-lane group at a time
+        unsigned long long sel = 0ull;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+        {
+          unsigned long long grp = pend & (0xFFFFull << (16 * gg));
+          sel |= grp & (~grp + 1ull);
+        }
+        const bool mine = ((sel >> lane) & 1ull) != 0ull;
+        const bool grp_has = (sel & gmask) != 0ull;
+        if (mine) sh_mail[g] = pos[a];
+        wave_sync();
+        if (grp_has)
+        {
+          const uint32_t mp = sh_mail[g];
+          on_share(mp);                                   // owner side: write back, switch to write-through
+#pragma unroll
+          for (int b2 = 0; b2 < NP; ++b2)
+            if (pos[b2] == mp) sh[b2] = true;
+        }
+        wave_sync();
+        if (mine) w[a] = value_load(tab, pos[a]);         // the value the owner just wrote back
+        pend &= ~sel;
+      }
+    }
+  }
+}
+
 // in-kernel stamps (diagnostic instantiation only; cdna_hip_programming.md section 7)
 __device__ __forceinline__ unsigned long long stamp()
 {
@@ -621,8 +996,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   __shared__ uint32_t sh_ppos[4 * 16];
   __shared__ double   sh_fb[16 * 4];
   __shared__ uint32_t sh_fbflag[16 * 4];
-  __shared__ uint32_t sh_mb[4][NA * 16];       // parallel insert: claimed bucket per (action, tiling), ~0 = none
-  __shared__ uint32_t sh_ms[4][NA * 16];       //                  and the slot claiming it
+  __shared__ uint32_t sh_mb[4 * NA * 16];      // parallel insert: claimed bucket per (action, tiling), ~0 = none
+  __shared__ uint32_t sh_ms[4 * NA * 16];      //                  and the slot claiming it
   __shared__ uint32_t sh_mail[4];              // position of a slot that just became shared between tilings
 
   const int lane = threadIdx.x & 63;
@@ -645,31 +1020,20 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   uint32_t status = RS.status, rows = RS.rows, inserted = 0;
 
   const Table tab = table_of(P, 0, r);
-  const double out_min = P.lin.out_min, out_max = P.lin.out_max;
-  const bool limit = P.lin.limit != 0;
-  const double ee = P.gl;                       // pow(gamma*lambda, tau), tau = 1 (discrete_time)
-  const double cut = (P.trace_kind == GRLX_TRACE_REPLACING) ? 0.01 : 0.0001;
-  const bool use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
+  UpdateParams up;
+  up.out_min = P.lin.out_min;
+  up.out_max = P.lin.out_max;
+  up.limit = P.lin.limit != 0;
+  up.ee = P.gl;                                 // pow(gamma*lambda, tau), tau = 1 (discrete_time)
+  up.cut = (P.trace_kind == GRLX_TRACE_REPLACING) ? 0.01 : 0.0001;
+  up.use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
+  up.dW = up.dT = 0;
 
-  // Register-resident replacing trace (trace.h:208-235), newest first.  tr_val is the
-  // AUTHORITATIVE weight of the slot while it is in the trace: it is written back to the
-  // table only when the slot leaves the trace (write-back), unless the slot is shared with
-  // another tiling (bit e of tr_wt), in which case every update is also stored (write-through)
-  // so that the other lane's loads see it.
-  uint32_t tr_pos[kMaxTrace];
-  double   tr_val[kMaxTrace];
-  uint32_t tr_cnt[kMaxTrace];
-  uint32_t tr_wt = 0;
-  bool tr_dup = false;          // some entry of this lane's trace occurs twice in its projection (sticky per trial)
-#pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e) { tr_pos[e] = kInvalidPos; tr_val[e] = 0; tr_cnt[e] = 0; }
-  int    tr_len = 0;
-  int    tr_len_ref = 0;        // length as the reference reports it (its trace survives test trials)
-  double tr_total = 1.;
+  TraceRegs tr;
+  trace_init(tr);
+  int tr_len_ref = 0;           // length as the reference reports it (its trace survives test trials)
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
   if (DIAG) diag_last = stamp();
-
-  auto add_clamped = [&](double v, double d) { return limit ? clampd(v + d, out_min, out_max) : v + d; };
 
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
@@ -743,144 +1107,25 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (update) wp = value_load(tab, p_pos);                           // weights of project(s, a) as stored
         if (has_next)
         {
-          Lookup lk[NA];
-          table_lookup<NA>(tab, slot, lk, w, status);
+          bool shared_event = false;
+          table_get<NA>(tab, P.lin, TL0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, status, inserted,
+                        [&](uint32_t mp) {
+                          trace_share_event(tr, tab, mp);
+                          if (p_pos == mp) p_sh = true;
+                          shared_event = true;
+                        });
           DIAG_STAMP(7)
-          bool anymiss = false;
-#pragma unroll
-          for (int a = 0; a < NA; ++a) anymiss = anymiss || lk[a].miss;
-          if (__any(anymiss))
-          { // Create the missing slots.  All lookups of this step are complete, so every lane
-            // that misses into bucket B saw the same empty ways of B.  Claims are ranked in the
-            // fixed order (action, tiling) through LDS: the r-th claimant of a bucket takes its
-            // r-th empty way -- no reload, all lanes in parallel.  Equal slots claimed twice
-            // (a hash collision inside one state) or a bucket with too few empty ways fall back
-            // to the serialised path.
-            double w0[NA];
-            bool slow[NA];
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-            {
-              sh_mb[g][a * 16 + j] = lk[a].miss ? lk[a].bucket : 0xFFFFFFFFu;
-              sh_ms[g][a * 16 + j] = slot[a];
-              w0[a] = 0;
-              slow[a] = false;
-              if (lk[a].miss) w0[a] = lazy_weight(TL0, P.lin, slot[a]);
-            }
-            wave_sync();
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-              if (lk[a].miss)
-              {
-                const int me = a * 16 + j;
-                uint32_t rank = 0;
-                bool dup = false;
-                for (int k = 0; k < NA * 16; ++k)
-                {
-                  const uint32_t ob = sh_mb[g][k], os = sh_ms[g][k];
-                  if (ob == lk[a].bucket && k != me)
-                  {
-                    if (os == slot[a]) dup = true;
-                    else if (k < me) rank++;
-                  }
-                }
-                uint32_t e = lk[a].empty;
-                for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;      // drop the ways taken by earlier claimants
-                if (dup || e == 0u)
-                  slow[a] = true;
-                else
-                {
-                  lk[a].pos = (lk[a].bucket << 2) | (uint32_t)__builtin_ctz(e);
-                  lk[a].kw = 0u;
-                  entry_create(tab, lk[a].pos, slot[a], (uint32_t)j, w0[a]);
-                  w[a] = w0[a];
-                  inserted++;
-                }
-              }
-            wave_sync();
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-              if (__any(slow[a]))
-                table_insert_serial(tab, slow[a], slot[a], (uint32_t)j, w0[a], lk[a], w[a], status, inserted);
-          }
-
-          // ---- slots shared between tilings (a collision of the reference's hash across
-          // tilings, ~70 per replica and run).  A slot found with a foreign owner and no shared
-          // bit yet is a NEW sharing event: mark it in the table and tell the owner's lane, whose
-          // trace may hold the only current copy of the weight.
-          bool fresh[NA];
-          bool anyfresh = false;
+          if (__any(shared_event) && update) wp = value_load(tab, p_pos);
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
-            pos[a] = lk[a].pos;
-            const bool found = lk[a].kw != 0u;
-            const bool foreign = found && ((lk[a].kw >> kOwnerShift) & 31u) != (uint32_t)j;
-            sh[a] = found && (foreign || (lk[a].kw & kSharedBit) != 0u);
-            fresh[a] = foreign && (lk[a].kw & kSharedBit) == 0u;
-            anyfresh = anyfresh || fresh[a];
+            w[a] = trace_forward(tr, pos[a], w[a]);
+            SHW(a, j, g) = w[a];
           }
-          if (__any(anyfresh))
-          {
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-            {
-              if (fresh[a]) tab.base[pos[a] >> 2].key[pos[a] & 3u] = lk[a].kw | kSharedBit;
-              unsigned long long pend = __ballot(fresh[a]);
-              while (pend != 0ull)
-              { // one event per 16-lane group at a time
-                unsigned long long sel = 0ull;
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg)
-                {
-                  unsigned long long grp = pend & (0xFFFFull << (16 * gg));
-                  sel |= grp & (~grp + 1ull);
-                }
-                const bool mine = ((sel >> lane) & 1ull) != 0ull;
-                const bool grp_has = (sel & gmask) != 0ull;
-                if (mine) sh_mail[g] = pos[a];
-                wave_sync();
-                if (grp_has)
-                {
-                  const uint32_t mp = sh_mail[g];
-                  // owner side: write the cached weight back and switch the entry to write-through
-#pragma unroll
-                  for (int e = 0; e < kMaxTrace; ++e)
-                    if (tr_pos[e] == mp && !((tr_wt >> e) & 1u))
-                    {
-                      value_store(tab, mp, tr_val[e]);
-                      tr_wt |= 1u << e;
-                    }
-                  if (p_pos == mp) p_sh = true;
-#pragma unroll
-                  for (int b2 = 0; b2 < NA; ++b2)
-                    if (pos[b2] == mp) sh[b2] = true;
-                }
-                wave_sync();
-                if (mine) w[a] = value_load(tab, pos[a]);       // the value the owner just wrote back
-                pend &= ~sel;
-              }
-            }
-            if (update) wp = value_load(tab, p_pos);
-          }
-
-          // ---- forward from the trace: a slot that is in this lane's trace has its current
-          // weight in tr_val, not (yet) in the table
-#pragma unroll
-          for (int e = 0; e < kMaxTrace; ++e)
-          {
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
-              w[a] = (tr_pos[e] == pos[a]) ? tr_val[e] : w[a];
-          }
-#pragma unroll
-          for (int a = 0; a < NA; ++a) SHW(a, j, g) = w[a];
         }
         if (update)
         {
-#pragma unroll
-          for (int e = 0; e < kMaxTrace; ++e)
-            wp = (tr_pos[e] == p_pos) ? tr_val[e] : wp;
+          wp = trace_forward(tr, p_pos, wp);
           SHW(NA, j, g) = wp;
         }
         DIAG_STAMP(3)
@@ -896,7 +1141,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 #pragma unroll
               for (int k = 0; k < 16; ++k) s += SHW(a, k, g);
               s /= 16;
-              q[a] = clampd(s, out_min, out_max);
+              q[a] = clampd(s, up.out_min, up.out_max);
             }
         }
         double qsa = 0;
@@ -906,7 +1151,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 #pragma unroll
           for (int k = 0; k < 16; ++k) s += SHW(NA, k, g);
           s /= 16;
-          qsa = clampd(s, out_min, out_max);
+          qsa = clampd(s, up.out_min, up.out_max);
         }
 
         // -------- sampler (greedy.cpp:63-86, 144-218)
@@ -954,193 +1199,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             }
           }
           delta = target - qsa;
-          const double dW = P.alpha * (target - qsa);          // LinearRepresentation::write (linear.cpp:186-196)
-          const double dT = P.alpha * delta;                   // VectorConstructor(alpha_*delta)
-
-          // Aliasing between p and the trace (IndexProjection::ssub, projection.h:94-104).  Inside a
-          // lane it is a register compare.  Across lanes it needs a p that is a slot shared between
-          // tilings (only such a slot can sit in another lane's trace, or twice in p): those lanes'
-          // positions are compared through LDS -- usually none.
-          const uint32_t shmask = (uint32_t)((__ballot(p_sh) >> (16 * g)) & 0xFFFFull);
-          uint32_t cp = 1;                                     // occurrences of my slot inside p
-          double v;                                            // final weight of p's slot after this step
-          if (!__any(shmask != 0u || tr_dup))
-          { // ---- common case (no lane of the wave has a shared p, no slot occurs twice): aliasing
-            // is a register compare inside the lane; straight-line code, no exec-mask branches
-            double a_val = 0, a_de = 0;
-            bool aliased = false, a_upd = false;
-            uint32_t stmask = 0;
-            if (use_trace)
-            {
-              double weight = 1.;
-              bool upd = true;
-#pragma unroll
-              for (int e = 0; e < kMaxTrace; ++e)
-              {
-                const bool in = e < tr_len;
-                upd = upd && (!in || weight > 0.001);            // representation.h:81
-                const double de = weight * dT * ee;
-                const bool valid = in && tr_pos[e] != kInvalidPos;
-                const bool own = valid && tr_pos[e] == p_pos;
-                const double vv = add_clamped(tr_val[e], de);
-                const bool doit = valid && !own && upd;
-                tr_val[e] = doit ? vv : tr_val[e];
-                stmask |= (doit && ((tr_wt >> e) & 1u)) ? (1u << e) : 0u;
-                a_val = own ? tr_val[e] : a_val;
-                a_de = own ? de : a_de;
-                a_upd = own ? upd : a_upd;
-                aliased = aliased || own;
-                tr_pos[e] = own ? kInvalidPos : tr_pos[e];       // ssub: the slot leaves the trace
-                tr_wt = own ? (tr_wt & ~(1u << e)) : tr_wt;
-                weight = in ? weight * ee : weight;
-              }
-            }
-            // p's write first, then the aliased entry's update (if it is still being updated)
-            const double base = aliased ? a_val : wp;
-            const double v1 = add_clamped(base, dW);
-            const double v2 = add_clamped(v1, a_de);
-            v = (aliased && a_upd) ? v2 : v1;
-            if (__any(stmask != 0u))
-            {
-#pragma unroll
-              for (int e = 0; e < kMaxTrace; ++e)
-                if ((stmask >> e) & 1u) value_store(tab, tr_pos[e], tr_val[e]);   // shared slot: keep the table current
-            }
-          }
-          else
-          {
-            uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
-  #pragma unroll
-            for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
-            for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
-            {
-              const int k = __builtin_ctz(mm);
-              const uint32_t ppk = sh_ppos[g * 16 + k];
-              if (k != j)
-              {
-                if (ppk == p_pos) cp++;
-  #pragma unroll
-                for (int e = 0; e < kMaxTrace; ++e) xm[e] |= (tr_pos[e] == ppk) ? (1u << k) : 0u;
-              }
-            }
-
-            double v_alias = 0;
-            bool aliased = false;
-            if (use_trace)
-            { // trace entries, newest first (representation.h:79-83, trace.h:150-178)
-              double weight = 1.;
-              bool upd = true;
-  #pragma unroll
-              for (int e = 0; e < kMaxTrace; ++e)
-                if (e < tr_len)
-                {
-                  upd = upd && (weight > 0.001);                 // representation.h:81
-                  const double de = weight * dT * ee;
-                  if (tr_pos[e] != kInvalidPos)
-                  {
-                    const bool own = tr_pos[e] == p_pos;
-                    if (!own && xm[e] == 0u)
-                    {
-                      if (upd)
-                      { // LinearRepresentation::update (linear.cpp:198-216); a slot that occurs twice in
-                        // its projection is updated twice
-                        double vv = add_clamped(tr_val[e], de);
-                        if ((tr_wt >> e) & 1u)
-                        {
-                          for (uint32_t c = 1; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
-                          value_store(tab, tr_pos[e], vv);       // shared slot: keep the table current
-                        }
-                        tr_val[e] = vv;
-                      }
-                    }
-                    else
-                    { // the slot is also written through p: p's write comes first, then this entry's
-                      // update; the slot leaves the trace
-                      if (upd)
-                      {
-                        double vv = tr_val[e];
-                        const uint32_t cpx = (own ? 1u : 0u) + (uint32_t)__builtin_popcount(xm[e]);
-                        for (uint32_t c = 0; c < cpx; ++c) vv = add_clamped(vv, dW);
-                        for (uint32_t c = 0; c < tr_cnt[e]; ++c) vv = add_clamped(vv, de);
-                        if (own) { v_alias = vv; aliased = true; }
-                        for (uint32_t mm = xm[e]; mm != 0u; mm &= mm - 1u)
-                        {
-                          const int k = __builtin_ctz(mm);
-                          sh_fb[k * 4 + g] = vv;
-                          sh_fbflag[k * 4 + g] = 1u;
-                        }
-                      }
-                      tr_pos[e] = kInvalidPos;
-                      tr_wt &= ~(1u << e);
-                    }
-                  }
-                  weight *= ee;
-                }
-            }
-            wave_sync();
-            if (aliased)
-              v = v_alias;
-            else if (shmask != 0u && sh_fbflag[j * 4 + g] != 0u)
-              v = sh_fb[j * 4 + g];
-            else
-            {
-              v = wp;
-              for (uint32_t c = 0; c < cp; ++c) v = add_clamped(v, dW);
-            }
-          }
-          // a shared slot is kept current in the table; an exclusive one only if no trace follows
-          if (p_sh || !use_trace) value_store(tab, p_pos, v);
-
-          // trace_->add(p, decay) (trace.h:215-234)
-          if (use_trace)
-          {
-            if (ee < cut)
-            { // decay below the cut: clear() first
-#pragma unroll
-              for (int e = 0; e < kMaxTrace; ++e)
-              {
-                if (tr_pos[e] != kInvalidPos && !((tr_wt >> e) & 1u)) value_store(tab, tr_pos[e], tr_val[e]);
-                tr_pos[e] = kInvalidPos;
-              }
-              tr_wt = 0;
-              tr_len = 0;
-              tr_total = 1.;
-            }
-            if (tr_len >= kMaxTrace) status |= ST_TRACE_OVERFLOW;
-            // the entry that falls off the end of the register file (never valid: validated at create)
-#pragma unroll
-            for (int e = kMaxTrace - 1; e > 0; --e)
-            {
-              tr_pos[e] = tr_pos[e - 1];
-              tr_val[e] = tr_val[e - 1];
-              tr_cnt[e] = tr_cnt[e - 1];
-            }
-            tr_wt = (tr_wt << 1) & ((1u << kMaxTrace) - 1u);
-            tr_pos[0] = p_pos;
-            tr_val[0] = v;
-            tr_cnt[0] = cp;
-            tr_dup = tr_dup || cp > 1u;
-            if (p_sh) tr_wt |= 1u;
-            tr_len = (tr_len < kMaxTrace) ? tr_len + 1 : kMaxTrace;
-            tr_total *= ee;
-            while (tr_total < cut && tr_len > 1)
-            {
-              tr_total /= ee;
-              tr_len--;
-            }
-            // entries popped off the front of the reference's deque: write their weights back
-#pragma unroll
-            for (int e = 0; e < kMaxTrace; ++e)
-              if (e >= tr_len)
-              {
-                if (tr_pos[e] != kInvalidPos && !((tr_wt >> e) & 1u)) value_store(tab, tr_pos[e], tr_val[e]);
-                tr_pos[e] = kInvalidPos;
-                tr_wt &= ~(1u << e);
-              }
-          }
+          up.dW = P.alpha * (target - qsa);                    // LinearRepresentation::write (linear.cpp:186-196)
+          up.dT = P.alpha * delta;                             // VectorConstructor(alpha_*delta)
+          td_update_lane(tr, tab, up, p_pos, p_sh, wp, g, j, sh_ppos, sh_fb, sh_fbflag, status);
+          tr_len_ref = tr.len;
         }
 
-        if (update) tr_len_ref = tr_len;
         DIAG_STAMP(5)
         // -------- tap (debug / parity tests)
         if (tapped && !first)
@@ -1191,19 +1255,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
     // end of the trial: the trace is cleared by the next TDAgent::start (td.cpp:54); write the
     // cached weights back now so that test trials and the host see them
-    if (!test)
-    {
-#pragma unroll
-      for (int e = 0; e < kMaxTrace; ++e)
-      {
-        if (tr_pos[e] != kInvalidPos && !((tr_wt >> e) & 1u)) value_store(tab, tr_pos[e], tr_val[e]);
-        tr_pos[e] = kInvalidPos;
-      }
-      tr_wt = 0;
-      tr_dup = false;
-      tr_len = 0;
-      tr_total = 1.;
-    }
+    if (!test) trace_flush(tr, tab, true);
 
     // row of a test trial (online_learning.cpp:238-262) -- or of every trial when test_interval < 0
     if (live && (ti >= 0 ? test : 1))

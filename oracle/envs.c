@@ -4,6 +4,8 @@
  * Pendulum dynamics + swing-up task:          base/src/environments/pendulum.cpp:40-145
  * Acrobot dynamics + balancing task:         base/src/environments/acrobot.cpp:48-151
  *   (no reference test pins the acrobot: parity unpinned by reference tests)
+ * Cart-pole dynamics + swing-up task:        base/src/environments/cart_pole.cpp:58-237
+ *   (the reference's cart-pole test yaml is stale: parity unpinned by reference tests)
  *
  * All arithmetic is IEEE double in the reference's expression order with no
  * fused multiply-add (compile with -ffp-contract=off).
@@ -32,6 +34,7 @@ int orc_env_state_dims(int env)
   {
     case ORC_ENV_PENDULUM: return 3;
     case ORC_ENV_ACROBOT: return 5;
+    case ORC_ENV_CART_POLE: return 5;
     default: return -1;
   }
 }
@@ -42,6 +45,7 @@ int orc_env_obs_dims(int env)
   {
     case ORC_ENV_PENDULUM: return 2;
     case ORC_ENV_ACROBOT: return 4;
+    case ORC_ENV_CART_POLE: return 4;
     default: return -1;
   }
 }
@@ -133,6 +137,77 @@ static int acrobot_observe(const double *x, double *obs)
   return x[4] > 20;
 }
 
+/* ------------------------------------------------------------ cart-pole -- */
+static void cart_pole_eom(const orc_spec *s, const double *x, double u, double *xd)
+{ /* cart_pole.cpp:41-49 constants, :58-108 with end_stop = 1; state = [x, theta, xd, thetad, time].
+   * QUIRK reproduced on purpose: :65 reads `dtheta = state[3-2*end_stop_]`, which for
+   * end_stop = 1 is state[1] -- the ANGLE, not its rate -- so the centrifugal term uses theta^2. */
+  const double g = 9.8, mass_cart = 1.0, mass_pole = 0.1, length = 0.5;
+  const double total_mass = mass_cart + mass_pole, pole_mass_length = mass_pole * length;
+  double acc, thetaacc, costheta, sintheta, temp;
+  double theta = x[1], dtheta = x[3 - 2 * 1];
+
+  costheta = orc_m_cos(s, theta);
+  sintheta = orc_m_sin(s, theta);
+  temp = (u + pole_mass_length * dtheta * dtheta * sintheta) / total_mass;
+  thetaacc = (g * sintheta - costheta * temp) /
+             (length * ((4. / 3.) - mass_pole * costheta * costheta / total_mass));
+  acc = temp - pole_mass_length * thetaacc * costheta / total_mass;
+
+  xd[0] = x[2];
+  xd[1] = x[3];
+  xd[2] = acc;
+  xd[3] = thetaacc;
+  xd[4] = 1;
+  /* end stops, :93-105 */
+  if (x[0] > 2.4 && x[2] > 0)
+  {
+    xd[0] = 0;
+    if (acc > 0) xd[2] = 0;
+  }
+  else if (x[0] < -2.4 && x[2] < 0)
+  {
+    xd[0] = 0;
+    if (acc < 0) xd[2] = 0;
+  }
+}
+
+static int cart_pole_failed(const double *x) { return fabs(x[0]) > 2.4; }          /* :212-215 */
+
+static double cart_pole_potential(const orc_spec *s, const double *x)
+{ /* :232-238 */
+  double a = fmod(fabs(x[1]), 2 * M_PI);
+  if (a > M_PI) a -= 2 * M_PI;
+  return -2 * orc_m_sqr(s, x[0]) - 0.1 * orc_m_sqr(s, x[2]) - orc_m_sqr(s, a) - 0.1 * orc_m_sqr(s, x[3]);
+}
+
+static void cart_pole_start(const orc_spec *s, orc_exp *e, double *x)
+{ /* :155-164: one RandGen draw every episode */
+  x[0] = 0;
+  x[1] = M_PI + s->randomization * ((orc_drand48(&e->TL) * 0.1) - 0.05);
+  x[2] = 0;
+  x[3] = 0;
+  x[4] = 0;
+}
+
+static int cart_pole_observe(const orc_spec *s, const double *x, double *obs)
+{ /* :166-190 */
+  double a = fmod(x[1] + M_PI, 2 * M_PI);
+  if (a < 0) a += 2 * M_PI;
+  obs[0] = x[0];
+  obs[1] = a;
+  obs[2] = x[2];
+  obs[3] = x[3];
+  if (s->end_stop_penalty && cart_pole_failed(x)) return 2;
+  return x[4] > s->timeout ? 1 : 0;
+}
+
+static double cart_pole_evaluate(const orc_spec *s, const double *x, double action, const double *next)
+{ /* :192-201, shaping = 0 */
+  (void)x;
+  return cart_pole_potential(s, next) - s->action_penalty * orc_m_sqr(s, action / 15) * 2 - s->end_stop_penalty * cart_pole_failed(next) * 10000;
+}
+
 /* ------------------------------------------------------ generic dispatch -- */
 static void env_eom(const orc_spec *s, const double *x, double u, double *xd)
 {
@@ -140,6 +215,7 @@ static void env_eom(const orc_spec *s, const double *x, double u, double *xd)
   {
     case ORC_ENV_PENDULUM: pendulum_eom(s, x, u, xd); break;
     case ORC_ENV_ACROBOT: acrobot_eom(s, x, u, xd); break;
+    case ORC_ENV_CART_POLE: cart_pole_eom(s, x, u, xd); break;
   }
 }
 
@@ -158,6 +234,7 @@ void orc_env_start(const orc_spec *s, orc_exp *e, int test, double *x)
   {
     case ORC_ENV_PENDULUM: pendulum_start(s, e, test, x); break;
     case ORC_ENV_ACROBOT: acrobot_start(e, x); break;
+    case ORC_ENV_CART_POLE: cart_pole_start(s, e, x); break;
   }
 }
 
@@ -167,6 +244,7 @@ int orc_env_observe(const orc_spec *s, const double *x, double *obs)
   {
     case ORC_ENV_PENDULUM: return pendulum_observe(s, x, obs);
     case ORC_ENV_ACROBOT: return acrobot_observe(x, obs);
+    case ORC_ENV_CART_POLE: return cart_pole_observe(s, x, obs);
   }
   return 0;
 }
@@ -212,6 +290,7 @@ double orc_env_step(const orc_spec *s, double *state, double action,
   {
     case ORC_ENV_PENDULUM: *reward = pendulum_evaluate(s, state, action, next); break;
     case ORC_ENV_ACROBOT: *reward = !acrobot_failed(next); break;        /* acrobot.cpp:127-133 */
+    case ORC_ENV_CART_POLE: *reward = cart_pole_evaluate(s, state, action, next); break;
     default: *reward = 0;
   }
   memcpy(state, next, sizeof(double) * S);

@@ -158,6 +158,18 @@ static void project_sa(orc_exp *e, const double *obs, double action, orc_proj *p
   for (int j = 0; j < p->n; ++j) p->idx[j] = out[j];
 }
 
+static void project_obs(const orc_tile_spec *ts, const double *obs, orc_proj *p)
+{ /* TileCodingProjector::project(in) on the bare observation (actor / V-critic) */
+  uint32_t out[ORC_MAX_TILINGS];
+  if (orc_tile_project(ts, obs, out) != 0)
+  {
+    fprintf(stderr, "oracle: invalid tile coding spec\n");
+    abort();
+  }
+  p->n = ts->tilings;
+  for (int j = 0; j < p->n; ++j) p->idx[j] = out[j];
+}
+
 /* -------------------------------------------------------------- sampler -- */
 static void findmax(const double *v, int n, int *mai, int *man)
 { /* greedy.cpp:47-61 */
@@ -271,11 +283,90 @@ static double q_update(orc_exp *e, const double *prev_obs, double prev_action, d
   return delta;
 }
 
+/* -------------------------------------------------------- actor-critic ---
+ * parity unpinned by reference tests (its cart-pole AC test yaml is stale). */
+static double rand_normal(orc_exp *e, double mu, double sigma)
+{ /* Rand::getNormal, utils.h:120-125 (Box-Muller, two thread-local draws) */
+  double U1 = orc_drand48(&e->TL), U2 = orc_drand48(&e->TL);
+  return sqrt(-2 * orc_m_log(&e->spec, U1)) * orc_m_cos(&e->spec, 2 * M_PI * U2) * sigma + mu;
+}
+
+static double ac_policy_act(orc_exp *e, int test, double time, const double *obs, double *u_out)
+{ /* ActionPolicy::act(time, in, out), action.cpp:127-158.  The test policy has sigma [] => 0. */
+  const orc_spec *s = &e->spec;
+  orc_proj p;
+  project_obs(&s->actor_projector, obs, &p);
+  double out = lin_read(e, 1, &s->actor_representation, &p);          /* ActionPolicy::read, :97-110 */
+  *u_out = out;
+  if (!test)
+  {
+    if (time == 0) e->ac_noise = 0;
+    if (time == 0.) e->ac_decay = fmax(e->ac_decay * s->ac_decay_rate, s->ac_decay_min);
+    if (s->sigma)
+    {
+      e->ac_noise = (1 - s->theta) * e->ac_noise + rand_normal(e, 0., e->ac_decay * s->sigma);
+      out += e->ac_noise;
+    }
+  }
+  return fmin(fmax(out, s->action_min), s->action_max);
+}
+
+static double td_critic(orc_exp *e, const double *prev_obs, double tau, double reward, const double *obs, int has_next, orc_proj *pout)
+{ /* TDPredictor::criticize, predictors/td.cpp:68-91 */
+  const orc_spec *s = &e->spec;
+  orc_proj p, pn;
+  project_obs(&s->projector, prev_obs, &p);
+  double target = reward;
+  if (has_next)
+  {
+    project_obs(&s->projector, obs, &pn);
+    target += orc_m_powtau(s, s->gamma, tau) * lin_read(e, 0, &s->representation, &pn);
+  }
+  double delta = target - lin_read(e, 0, &s->representation, &p);
+  lin_write(e, 0, &s->representation, &p, target, s->alpha);
+  if (s->trace != ORC_TRACE_NONE)
+  {
+    double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
+    lin_update_trace(e, 0, &s->representation, &e->trace, s->alpha * delta, ee);
+    trace_add(&e->trace, s->trace, &p, ee);
+  }
+  *pout = p;
+  return delta;
+}
+
+static double ac_update(orc_exp *e, const double *prev_obs, double prev_action, double tau, double reward,
+                        const double *obs, int has_next, orc_proj *pout, orc_proj *apout)
+{ /* ActionACPredictor::update, ac.cpp:72-110 */
+  const orc_spec *s = &e->spec;
+  orc_proj ap;
+  project_obs(&s->actor_projector, prev_obs, &ap);
+  double u = lin_read(e, 1, &s->actor_representation, &ap);
+  double critique = td_critic(e, prev_obs, tau, reward, obs, has_next, pout);
+  if (s->ac_update_method == ORC_AC_PROPORTIONAL || critique > 0)
+  {
+    double delta = prev_action - u;
+    if (s->ac_update_method == ORC_AC_PROPORTIONAL)
+      delta = critique * delta;
+    if (s->ac_step_limit >= 0)
+      delta = fmin(fmax(delta, -s->ac_step_limit), s->ac_step_limit);
+    double target_u = u + delta;
+    lin_write(e, 1, &s->actor_representation, &ap, target_u, s->actor_alpha);
+  }
+  *apout = ap;
+  return critique;
+}
+
 /* ---------------------------------------------------------------- agent -- */
 typedef struct { double value; int index; double q[ORC_MAX_ACTIONS]; } act_t;
 
 static void policy_act(orc_exp *e, int test, double time, const double *obs, act_t *out)
 { /* q.cpp:143-155 (QPolicy::act with time) */
+  if (e->spec.agent == ORC_AGENT_AC)
+  {
+    out->index = 0;
+    out->value = ac_policy_act(e, test, time, obs, &out->q[0]);
+    return;
+  }
   q_values(e, obs, out->q);
   if (test)
     out->index = sample_greedy(e, out->q, e->A);
@@ -298,9 +389,17 @@ static double *table_alloc_init(orc_exp *e, const orc_tile_spec *ts, const orc_l
 orc_exp *orc_create(const orc_spec *spec, long seed)
 {
   if (orc_env_state_dims(spec->env) < 0) return NULL;             /* environments not restated yet */
-  if (spec->projector.dims != orc_env_obs_dims(spec->env) + 1) return NULL;
-  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q) return NULL;
-  if (spec->action_steps < 1 || spec->action_steps > ORC_MAX_ACTIONS) return NULL;
+  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC) return NULL;
+  if (spec->agent == ORC_AGENT_AC)
+  {
+    if (spec->projector.dims != orc_env_obs_dims(spec->env) || spec->actor_projector.dims != orc_env_obs_dims(spec->env)) return NULL;
+    if (spec->actor_projector.tilings > ORC_MAX_TILINGS) return NULL;
+  }
+  else
+  {
+    if (spec->projector.dims != orc_env_obs_dims(spec->env) + 1) return NULL;
+    if (spec->action_steps < 1 || spec->action_steps > ORC_MAX_ACTIONS) return NULL;
+  }
   if (spec->projector.tilings > ORC_MAX_TILINGS) return NULL;
 
   orc_exp *e = (orc_exp *)calloc(1, sizeof(*e));
@@ -325,8 +424,18 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
    * seeds the thread-local stream from the global lrand48() (utils.h:90-93,160-171),
    * then draws memory*outputs uniforms. */
   orc_srand48(&e->TL, (long)orc_lrand48(&e->G));
+  if (spec->agent == ORC_AGENT_AC)
+  { /* cfg/cart_pole/ac_tc.yaml order: the policy's (actor) representation first, then the
+     * critic's; both draw from the same thread-local stream; there are no samplers */
+    e->w[1] = table_alloc_init(e, &spec->actor_projector, &spec->actor_representation);
+    if (!e->w[1]) { free(e); return NULL; }
+  }
   e->w[0] = table_alloc_init(e, &spec->projector, &spec->representation);
-  if (!e->w[0]) { free(e); return NULL; }
+  if (!e->w[0]) { free(e->w[1]); free(e); return NULL; }
+  e->ac_decay = 1;
+  e->eps_decay = 1;
+  trace_clear(&e->trace);
+  if (spec->agent == ORC_AGENT_AC) return e;
   /* learning policy's sampler/epsilon_greedy, then the test policy's
    * sampler/greedy: each `new Rand()` (greedy.cpp:38-41) */
   orc_srand48(&e->S1, (long)orc_lrand48(&e->G));
@@ -373,7 +482,9 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
     }
     else
     { /* td.cpp:50-61 */
-      trace_clear(&e->trace);                                  /* predictor_->finalize(), sarsa.cpp:126-132 */
+      if (s->agent != ORC_AGENT_AC)                            /* predictor_->finalize(), sarsa.cpp:126-132;          */
+        trace_clear(&e->trace);                                /* ActionACPredictor::finalize (ac.cpp:170-173) does   */
+                                                               /* NOT reach the critic: its trace survives episodes   */
       e->time = 0;
       policy_act(e, 0, e->time, obs, &act);
       memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
@@ -386,8 +497,9 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
       double tau = orc_env_step(s, e->state, act.value, obs, &reward, &terminal);   /* :196 */
       total_reward += reward;                                                      /* :202 */
       double delta = 0;
-      orc_proj p;
+      orc_proj p, ap;
       p.n = 0;
+      ap.n = 0;
 
       if (test)
       { /* fixed.cpp:53-61 */
@@ -404,8 +516,10 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
         { /* td.cpp:76-81: update with an empty next action */
           if (s->agent == ORC_AGENT_SARSA)
             delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
-          else
+          else if (s->agent == ORC_AGENT_Q)
             delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
+          else
+            delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
         }
         else
         { /* td.cpp:63-74: act first, then update */
@@ -414,8 +528,10 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
           e->stats.trace_entries_sum += (uint64_t)e->trace.len;
           if (s->agent == ORC_AGENT_SARSA)
             delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
-          else
+          else if (s->agent == ORC_AGENT_Q)
             delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
+          else
+            delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
           memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
           e->prev_action = act.value;
           e->prev_action_index = act.index;
@@ -435,9 +551,10 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
         tp->reward = reward;
         tp->terminal = terminal;
         tp->trace_len = e->trace.len;
-        for (int a = 0; a < e->A && a < 8; ++a) tp->q[a] = act.q[a];
+        for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = act.q[a];
         tp->delta = delta;
-        for (int j = 0; j < p.n && j < 32; ++j) tp->p_idx[j] = (uint32_t)p.idx[j];
+        for (int j = 0; j < p.n && j < 16; ++j) tp->p_idx[j] = (uint32_t)p.idx[j];
+        for (int j = 0; j < ap.n && j < 16; ++j) tp->p_idx[16 + j] = (uint32_t)ap.idx[j];   /* actor projection (AC) */
       }
     } while (!terminal);
 

@@ -94,6 +94,8 @@ typedef struct {
   int    integration_steps;
   double timeout;
   double randomization;
+  int    end_stop_penalty;            /* task/cart_pole/swingup (class default 1; ac_tc.yaml: 0) */
+  int    action_penalty;              /* task/cart_pole/swingup (default 0)                      */
   /* discretizer/uniform over the action (dims = 1 for all supported envs) */
   double action_min, action_max;
   int    action_steps;
