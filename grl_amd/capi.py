@@ -41,7 +41,8 @@ class Config(C.Structure):
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double), ("ac_step_limit", C.c_double),
                 ("ac_update_method", C.c_int32),
                 ("table_log2_capacity", C.c_int32), ("max_rows", C.c_int32), ("tap_replica", C.c_int32),
-                ("tap_capacity", C.c_int32), ("reserved1", C.c_int32)]
+                ("tap_capacity", C.c_int32), ("end_stop_penalty", C.c_int32), ("action_penalty", C.c_int32),
+                ("reserved1", C.c_int32)]
 
 
 class Tap(C.Structure):
@@ -64,6 +65,7 @@ _SIGS = {
     "grlx_abi_version": (C.c_int, []),
     "grlx_device_count": (C.c_int, []),
     "grlx_config_pendulum_sarsa": (None, [_P(Config)]),
+    "grlx_config_cart_pole_ac": (None, [_P(Config)]),
     "grlx_create": (C.c_int, [_P(Config), _P(C.c_int64), _P(C.c_void_p)]),
     "grlx_destroy": (C.c_int, [C.c_void_p]),
     "grlx_run": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -67,6 +67,7 @@ int env_dims(int env, int *S, int *D)
   {
     case GRLX_ENV_PENDULUM: *S = 3; *D = 2; return GRLX_OK;
     case GRLX_ENV_ACROBOT: *S = 5; *D = 4; return GRLX_OK;
+    case GRLX_ENV_CART_POLE: *S = 5; *D = 4; return GRLX_OK;
     default: return GRLX_ERR_INVALID;
   }
 }
@@ -110,11 +111,14 @@ int make_params(const grlx_config &c, DevParams *P)
   if (c.struct_size != sizeof(grlx_config)) return fail(GRLX_ERR_INVALID, "grlx_config.struct_size %u != %zu (ABI mismatch)", c.struct_size, sizeof(grlx_config));
   int S, D;
   if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
-  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+  const bool ac = c.agent == GRLX_AGENT_AC;
+  if (ac && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
   if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");
   if (!(c.control_step >= 0.00001)) return fail(GRLX_ERR_INVALID, "model/dynamical:control_step");
   if (c.integration_steps < 1) return fail(GRLX_ERR_INVALID, "model/dynamical:integration_steps");
-  if (c.action_steps < 1 || c.action_steps > GRLX_MAX_ACTIONS) return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps (1..%d supported)", GRLX_MAX_ACTIONS);
+  if (!ac && (c.action_steps < 1 || c.action_steps > GRLX_MAX_ACTIONS)) return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps (1..%d supported)", GRLX_MAX_ACTIONS);
+  if (ac && c.trace != GRLX_TRACE_REPLACING && c.trace != GRLX_TRACE_NONE) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
   if (c.trace != GRLX_TRACE_NONE && c.trace != GRLX_TRACE_REPLACING) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
 
   P->test_interval = c.test_interval;
@@ -126,8 +130,13 @@ int make_params(const grlx_config &c, DevParams *P)
   P->timeout = c.timeout;
   P->randomization = c.randomization;
 
+  P->end_stop_penalty = c.end_stop_penalty;
+  P->action_penalty = c.action_penalty;
+  P->action_min = c.action_min;
+  P->action_max = c.action_max;
   // UniformDiscretizer::configure (uniform.cpp:60-95)
-  P->A = c.action_steps;
+  P->A = ac ? 0 : c.action_steps;
+  if (!ac)
   {
     double range = c.action_max - c.action_min;
     double delta = range / ((double)c.action_steps - 1);
@@ -139,8 +148,27 @@ int make_params(const grlx_config &c, DevParams *P)
   int rc = make_tile_params(c.projector, &P->tile);
   if (rc != GRLX_OK) return rc;
   if (P->tile.T != kLanesPerReplica) return fail(GRLX_ERR_INVALID, "projector/tile_coding:tilings must be %d on the fused path", kLanesPerReplica);
-  if (P->tile.D != D + 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution must have %d entries (observation + action)", D + 1);
+  if (!ac && P->tile.D != D + 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution must have %d entries (observation + action)", D + 1);
   make_linear_params(c.representation, 0, &P->lin);
+  if (ac)
+  { // policy/action + predictor/ac/action: actor table first in the yaml, then the critic's (ac_tc.yaml:36-65)
+    if (P->tile.D != D) return fail(GRLX_ERR_INVALID, "critic projector/tile_coding:resolution must have %d entries (observation)", D);
+    rc = make_tile_params(c.actor_projector, &P->tile_actor);
+    if (rc != GRLX_OK) return rc;
+    if (P->tile_actor.T != kLanesPerReplica) return fail(GRLX_ERR_INVALID, "actor projector/tile_coding:tilings must be %d on the fused path", kLanesPerReplica);
+    if (P->tile_actor.D != D) return fail(GRLX_ERR_INVALID, "actor projector/tile_coding:resolution must have %d entries (observation)", D);
+    make_linear_params(c.actor_representation, 0, &P->lin_actor);
+    P->lin.draws_before = (uint64_t)c.actor_projector.memory;         // both tables draw from one thread-local stream
+    P->actor_alpha = c.actor_alpha;
+    P->sigma = c.sigma;
+    P->theta = c.theta;
+    P->ac_decay_rate = c.ac_decay_rate;
+    P->ac_decay_min = c.ac_decay_min;
+    P->ac_step_limit = c.ac_step_limit;
+    P->ac_update_method = c.ac_update_method;
+    if (c.ac_update_method != 0 && c.ac_update_method != 1) return fail(GRLX_ERR_INVALID, "predictor/ac/action:update_method");
+    if (!(c.action_min < c.action_max)) return fail(GRLX_ERR_INVALID, "policy/action:{output_min,output_max}");
+  }
 
   P->epsilon = c.epsilon;
   P->decay_rate = c.decay_rate;
@@ -173,6 +201,8 @@ struct grlx_ctx {
   uint32_t     *tap_count = nullptr;
   uint64_t     *scratch = nullptr;        // 8 x u64
   unsigned long long *diag = nullptr;
+  uint32_t     *trace_state = nullptr;
+  int          n_tables = 1;
   int64_t      trials_run = 0;
 };
 
@@ -240,6 +270,47 @@ void grlx_config_pendulum_sarsa(grlx_config *c)
   c->tap_capacity = 0;
 }
 
+void grlx_config_cart_pole_ac(grlx_config *c)
+{ // the reference's cfg/cart_pole/ac_tc.yaml
+  grlx_config_pendulum_sarsa(c);
+  c->env = GRLX_ENV_CART_POLE;
+  c->control_step = 0.05;
+  c->integration_steps = 5;
+  c->timeout = 9.99;
+  c->randomization = 0;
+  c->end_stop_penalty = 0;
+  c->action_penalty = 0;
+  c->action_min = -15;
+  c->action_max = 15;
+  c->action_steps = 0;
+  c->agent = GRLX_AGENT_AC;
+  const double res[4] = {2.5, 0.157075, 2.5, 1.57075}, wrap[4] = {0, 6.283, 0, 0};
+  grlx_tile_spec *ts[2] = {&c->projector, &c->actor_projector};
+  for (int t = 0; t < 2; ++t)
+  {
+    memset(ts[t], 0, sizeof(grlx_tile_spec));
+    ts[t]->tilings = 16;
+    ts[t]->memory = 8388608;
+    ts[t]->dims = 4;
+    for (int i = 0; i < 4; ++i) { ts[t]->resolution[i] = res[i]; ts[t]->wrapping[i] = wrap[i]; }
+  }
+  c->actor_representation.init_min = 0;
+  c->actor_representation.init_max = 1;
+  c->actor_representation.output_min = -15;       // output_min/max: task action_min/max
+  c->actor_representation.output_max = 15;
+  c->actor_representation.limit = 1;
+  c->alpha = 0.2; c->gamma = 0.97; c->lambda = 0.65;   // predictor/critic/td
+  c->trace = GRLX_TRACE_REPLACING;
+  c->actor_alpha = 0.01;                          // predictor/ac/action:alpha
+  c->sigma = 5;
+  c->theta = 1;
+  c->ac_decay_rate = 1;
+  c->ac_decay_min = 0;
+  c->ac_update_method = 0;                        // proportional
+  c->ac_step_limit = -1;
+  c->table_log2_capacity = 18;
+}
+
 int grlx_env_dims(int env, int *state_dims, int *obs_dims)
 {
   int S, D;
@@ -272,7 +343,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_replica = cfg->tap_replica;
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
 
-  const size_t n_tables = 1;
+  const size_t n_tables = cfg->agent == GRLX_AGENT_AC ? 2 : 1;
+  ctx->n_tables = (int)n_tables;
   const size_t table_bytes = ((size_t)N * n_tables * sizeof(Entry)) << logC;
 #define CTX_TRY(expr)                                                                        \
   do {                                                                                       \
@@ -294,6 +366,14 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));
   CTX_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
+  if (cfg->agent == GRLX_AGENT_AC)
+  { // the critic's trace survives launches: positions live here, all entries invalid at first
+    const size_t words = (size_t)N * 16 * kMaxTrace * 2;
+    CTX_TRY(hipMalloc((void **)&ctx->trace_state, words * sizeof(uint32_t)));
+    std::vector<uint32_t> init(words, 0u);
+    for (size_t i = 0; i < words; i += 2) init[i] = kInvalidPos;
+    CTX_TRY(hipMemcpy(ctx->trace_state, init.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   if (P.tap_capacity > 0)
   {
     CTX_TRY(hipMalloc((void **)&ctx->taps, sizeof(grlx_tap) * (size_t)P.tap_capacity));
@@ -305,7 +385,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   //   srand48(seed) -> representation reset: thread-local Rand seeded by global lrand48 #1,
   //   memory*outputs uniforms drawn -> learning sampler Rand (global #2) -> test sampler Rand (global #3).
   std::vector<ReplicaState> hs((size_t)N);
-  const uint64_t table_draws = (uint64_t)cfg->projector.memory;        // outputs = 1
+  uint64_t table_draws = (uint64_t)cfg->projector.memory;              // outputs = 1
+  if (cfg->agent == GRLX_AGENT_AC) table_draws += (uint64_t)cfg->actor_projector.memory;
   for (int r = 0; r < N; ++r)
   {
     ReplicaState &s = hs[(size_t)r];
@@ -321,6 +402,9 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
     s.G = G;
     s.eps_decay = 1;
     s.ac_decay = 1;
+    s.tr_len = 0;
+    s.tr_total = 1;
+    if (cfg->agent == GRLX_AGENT_AC) s.G = h_next(h_seed((long)seeds[r]));   // no samplers: only the thread-local seed is drawn
   }
   CTX_TRY(hipMemcpy(ctx->states, hs.data(), sizeof(ReplicaState) * (size_t)N, hipMemcpyHostToDevice));
 #undef CTX_TRY
@@ -331,6 +415,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.row_steps = ctx->row_steps;
   P.row_trial = ctx->row_trial;
   P.taps = ctx->taps;
+  P.trace_state = ctx->trace_state;
   P.tap_count = ctx->tap_count;
   ctx->P = P;
   *out = ctx;
@@ -349,6 +434,7 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->tap_count);
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->diag);
+  (void)hipFree(ctx->trace_state);
   delete ctx;
   return GRLX_OK;
 }
@@ -381,7 +467,10 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n_trials == 0) return GRLX_OK;
-  HIP_TRY(launch_rollout(ctx->P, n_trials, (hipStream_t)stream));
+  if (ctx->cfg.agent == GRLX_AGENT_AC)
+    HIP_TRY(launch_rollout_ac(ctx->P, n_trials, (hipStream_t)stream));
+  else
+    HIP_TRY(launch_rollout(ctx->P, n_trials, (hipStream_t)stream));
   ctx->trials_run += n_trials;
   return GRLX_OK;
 }
@@ -466,7 +555,7 @@ int grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4])
 
 int grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used)
 {
-  if (!ctx || !n_slots_used || table != 0 || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!ctx || !n_slots_used || table < 0 || table >= ctx->n_tables || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   ReplicaState s;
   HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
   *n_slots_used = s.n_slots[table];
@@ -487,7 +576,7 @@ int grlx_read_taps(grlx_ctx *ctx, grlx_tap *out, int cap, int *n)
 
 int grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out)
 {
-  if (!ctx || !slots || !out || n < 0 || table != 0 || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!ctx || !slots || !out || n < 0 || table < 0 || table >= ctx->n_tables || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n == 0) return GRLX_OK;
   DevBuf ds, dout;
   HIP_TRY(ds.alloc(sizeof(uint32_t) * (size_t)n));
@@ -549,13 +638,14 @@ int grlx_env_step(const grlx_config *cfg, double *state, const double *action, i
 static int table_op(grlx_ctx *ctx, int table, int op, const int32_t *replica, const uint32_t *idx, int n,
                     const double *arg, double alpha, double *out)
 {
-  if (!ctx || !replica || !idx || n < 0 || table != 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!ctx || !replica || !idx || n < 0 || table < 0 || table >= ctx->n_tables) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n == 0) return GRLX_OK;
   for (int i = 0; i < n; ++i)
     if (replica[i] < 0 || replica[i] >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "replica index out of range");
   const int T = ctx->P.tile.T;
+  const uint32_t mem = (uint32_t)(table == 1 ? ctx->P.tile_actor.memory : ctx->P.tile.memory);
   for (size_t i = 0; i < (size_t)n * (size_t)T; ++i)
-    if (idx[i] != 0xFFFFFFFFu && idx[i] >= (uint32_t)ctx->P.tile.memory) return fail(GRLX_ERR_INVALID, "slot index out of range");
+    if (idx[i] != 0xFFFFFFFFu && idx[i] >= mem) return fail(GRLX_ERR_INVALID, "slot index out of range");
   DevBuf dr, di, da, dout;
   HIP_TRY(dr.alloc(sizeof(int32_t) * (size_t)n));
   HIP_TRY(di.alloc(sizeof(uint32_t) * (size_t)n * T));

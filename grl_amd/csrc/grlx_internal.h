@@ -41,6 +41,10 @@ struct __attribute__((aligned(16))) ReplicaState {
   uint32_t n_slots[2];          // occupied table slots
   uint32_t status;
   uint32_t rows;                // test rows written
+  // actor-critic: the critic's trace survives episodes and launches (ac.cpp:170-173)
+  int32_t  tr_len;
+  int32_t  pad0;
+  double   tr_total;
 };
 
 struct TileParams {
@@ -65,6 +69,14 @@ struct DevParams {
   TileParams   tile;
   LinearParams lin;
   double   epsilon, decay_rate, decay_min, alpha, gamma, gl;   // gl = gamma*lambda
+  // actor-critic (policy/action + predictor/ac/action); table 0 = critic, table 1 = actor
+  TileParams   tile_actor;
+  LinearParams lin_actor;
+  double   actor_alpha, sigma, theta, ac_decay_rate, ac_decay_min, ac_step_limit;
+  int32_t  ac_update_method;
+  double   action_min, action_max;
+  int32_t  end_stop_penalty, action_penalty;                   // task/cart_pole/swingup
+  uint32_t *trace_state;                                       // [replica][16 lanes][kMaxTrace][2]: pos, cnt | wt << 16
   // sparse tables: table t of replica r starts at tables + ((t*n_replicas + r) << logC)
   Entry   *tables;
   uint32_t logC;
@@ -84,6 +96,7 @@ struct DevParams {
 // ---------------------------------------------------------------------------
 // launchers implemented in grlx_kernels.hip
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream);
+hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);

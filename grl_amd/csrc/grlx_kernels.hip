@@ -495,6 +495,73 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
   }
 };
 
+// dynamics/cart_pole (end_stop = 1) + task/cart_pole/swingup (cart_pole.cpp:41-237);
+// state = [x, theta, xd, thetad, time].  parity unpinned by reference tests.
+template <> struct Env<GRLX_ENV_CART_POLE> {
+  static constexpr int S = 5, D = 4;
+  __device__ static __forceinline__ void eom(const double *x, double u, double *xd)
+  { // cart_pole.cpp:58-108.  QUIRK reproduced on purpose: :65 reads dtheta = state[3-2*end_stop_],
+    // which for end_stop = 1 is state[1] -- the ANGLE, not its rate.
+    const double g = 9.8, mass_cart = 1.0, mass_pole = 0.1, length = 0.5;
+    const double total_mass = mass_cart + mass_pole, pole_mass_length = mass_pole * length;
+    const double theta = x[1], dtheta = x[3 - 2 * 1];
+    double costheta, sintheta;
+    psincos(theta, sintheta, costheta);
+    const double temp = (u + pole_mass_length * dtheta * dtheta * sintheta) / total_mass;
+    const double thetaacc = (g * sintheta - costheta * temp) /
+                            (length * ((4. / 3.) - mass_pole * costheta * costheta / total_mass));
+    const double acc = temp - pole_mass_length * thetaacc * costheta / total_mass;
+    xd[0] = x[2];
+    xd[1] = x[3];
+    xd[2] = acc;
+    xd[3] = thetaacc;
+    xd[4] = 1;
+    if (x[0] > 2.4 && x[2] > 0)
+    { // end stops, :93-105
+      xd[0] = 0;
+      if (acc > 0) xd[2] = 0;
+    }
+    else if (x[0] < -2.4 && x[2] < 0)
+    {
+      xd[0] = 0;
+      if (acc < 0) xd[2] = 0;
+    }
+  }
+  __device__ static __forceinline__ bool failed(const double *x) { return __builtin_fabs(x[0]) > 2.4; }   // :212-215
+  __device__ static __forceinline__ double potential(const double *x)
+  { // :232-238
+    double a = pfmod(__builtin_fabs(x[1]), GRLX_2PI);
+    if (a > GRLX_PI) a -= GRLX_2PI;
+    return -2 * (x[0] * x[0]) - 0.1 * (x[2] * x[2]) - (a * a) - 0.1 * (x[3] * x[3]);
+  }
+  __device__ static __forceinline__ void start(const DevParams &P, int, uint64_t &TL, uint64_t &, double *x)
+  { // :155-164
+    TL = lcg_next(TL);
+    const double r = lcg_double(TL);
+    x[0] = 0;
+    x[1] = GRLX_PI + P.randomization * ((r * 0.1) - 0.05);
+    x[2] = 0; x[3] = 0; x[4] = 0;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return a; }                  // Task::actuate default (environment.h:94)
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[1]) < 0x1p19; }
+  __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
+  { // :166-190
+    double a = pfmod(x[1] + GRLX_PI, GRLX_2PI);
+    if (a < 0) a += GRLX_2PI;
+    obs[0] = x[0];
+    obs[1] = a;
+    obs[2] = x[2];
+    obs[3] = x[3];
+    if (P.end_stop_penalty && failed(x)) return 2;
+    return x[4] > P.timeout ? 1 : 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &P, const double *, double action, const double *next)
+  { // :192-201, shaping = 0
+    const double a15 = action / 15;
+    return potential(next) - P.action_penalty * (a15 * a15) * 2 - P.end_stop_penalty * (failed(next) ? 1 : 0) * 10000;
+  }
+};
+
 // DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps.
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
@@ -1304,6 +1371,354 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   if (live && j == 0) RS.status = st;
 }
 
+// ------------------------------------------------------ actor-critic rollout ---
+// agent/td { policy: mapping/policy/action, predictor: predictor/ac/action { critic:
+// predictor/critic/td } } with agent/fixed for test trials (cfg/cart_pole/ac_tc.yaml).
+// Table 0 = critic V(s) with the register trace, table 1 = actor u(s) (no trace: plain
+// read-modify-write).  Lane j = tiling j of both projectors.  References:
+//   ActionPolicy::act        base/src/policies/action.cpp:127-158
+//   ActionACPredictor::update base/src/predictors/ac.cpp:72-110
+//   TDPredictor::criticize    base/src/predictors/td.cpp:68-91
+//   Rand::getNormal           base/include/grl/utils.h:120-125
+// Quirk kept: ActionACPredictor::finalize (ac.cpp:170-173) does not reach the critic, so the
+// critic's trace is NOT cleared at episode start; it survives test trials and launches.
+template <int T>
+__device__ __forceinline__ uint32_t tile_slot_obs(const TileParams &tp, const double *obs, int D, int j)
+{
+  uint32_t h = 449u ^ (uint32_t)(D + 1);
+  for (int i = 0; i < D; ++i) h = murmur_mix(h, tile_coord<T>(tp, i, tile_quant(tp, i, obs[i]), j));
+  h = murmur_mix(h, j);
+  return murmur_final(h) % (uint32_t)tp.memory;
+}
+
+#define SHA(row, k, g) sh_w[(((row) * 16 + (k)) << 2) + (g)]
+
+template <int ENV>
+__global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trials)
+{
+  constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
+  __shared__ double   sh_w[4 * 16 * 4];        // rows: actor(s'), critic(s'), actor(s), critic(s)
+  __shared__ uint32_t sh_ppos[4 * 16];
+  __shared__ uint32_t sh_apos[4 * 16];
+  __shared__ double   sh_fb[16 * 4];
+  __shared__ uint32_t sh_fbflag[16 * 4];
+  __shared__ uint32_t sh_mb[4 * 16];
+  __shared__ uint32_t sh_ms[4 * 16];
+  __shared__ uint32_t sh_mail[4];
+
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  const int r_raw = blockIdx.x * kReplicasPerWave + g;
+  const bool live = r_raw < P.n_replicas;
+  const int r = live ? r_raw : 0;
+  const bool tapped = live && (r == P.tap_replica);
+  const unsigned long long gmask = 0xFFFFull << (16 * g);
+
+  ReplicaState &RS = P.states[r];
+  double x[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) x[i] = RS.x[i];
+  uint64_t G = RS.G, TL = RS.TL;
+  const uint64_t TL0 = RS.TL0;
+  double ac_decay = RS.ac_decay, ac_noise = RS.ac_noise;
+  int64_t tt = RS.tt, ss = RS.ss;
+  uint64_t test_steps = RS.test_steps;
+  uint32_t status = RS.status, rows = RS.rows, ins_c = 0, ins_a = 0;
+
+  const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
+  UpdateParams up;
+  up.out_min = P.lin.out_min;
+  up.out_max = P.lin.out_max;
+  up.limit = P.lin.limit != 0;
+  up.ee = P.gl;
+  up.cut = 0.01;
+  up.use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
+  up.dW = up.dT = 0;
+  const double a_min = P.lin_actor.out_min, a_max = P.lin_actor.out_max;
+  const bool a_limit = P.lin_actor.limit != 0;
+
+  // restore the critic's trace: positions from HBM, weights from the (current) table
+  TraceRegs tr;
+  trace_init(tr);
+  uint32_t *ts = P.trace_state + ((size_t)r * 16 + (size_t)j) * kMaxTrace * 2;
+  if (live && up.use_trace)
+  {
+    tr.len = RS.tr_len;
+    tr.total = RS.tr_total;
+#pragma unroll
+    for (int e = 0; e < kMaxTrace; ++e)
+    {
+      tr.pos[e] = ts[e * 2];
+      const uint32_t cw = ts[e * 2 + 1];
+      tr.cnt[e] = cw & 0xFFFFu;
+      if (cw >> 16) tr.wt |= 1u << e;
+      tr.dup = tr.dup || tr.cnt[e] > 1u;
+      if (tr.pos[e] != kInvalidPos) tr.val[e] = value_load(tabC, tr.pos[e]);
+    }
+  }
+
+  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  {
+    const int ti = P.test_interval;
+    const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
+    double obs[D], reward = 0, total_reward = 0;
+    int terminal = 0;
+    bool running = live;
+    if (live)
+    {
+      Env<ENV>::start(P, test, TL, G, x);
+      Env<ENV>::observe(P, x, obs);
+    }
+    double time = 0, action = 0;
+    uint32_t p_pos = kInvalidPos, p_slot = 0, ap_pos = kInvalidPos, ap_slot = 0;
+    bool p_sh = false, ap_sh = false;
+    bool first = true;
+
+    for (;;)
+    {
+      if (!__any(running)) break;
+      if (running)
+      {
+        if (!first)
+        {
+          env_step<ENV>(P, x, action, obs, reward, terminal, status);
+          total_reward += reward;
+          time += 1;
+        }
+        const bool has_next = first || terminal != 2;
+        const bool update = !first && !test;
+        const bool need_critic = has_next && !test;
+
+        uint32_t slotA[1] = {0}, slotC[1] = {0}, posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
+        double wA[1] = {0}, wC[1] = {0};
+        bool shA[1] = {false}, shC[1] = {false};
+        if (has_next)
+        {
+          slotA[0] = tile_slot_obs<T>(P.tile_actor, obs, D, j);
+          slotC[0] = tile_slot_obs<T>(P.tile, obs, D, j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        double wap = 0, wpc = 0;
+        if (update)
+        {
+          wap = value_load(tabA, ap_pos);                // actor weights of project(prev_obs), current
+          wpc = value_load(tabC, p_pos);                 // critic weights of project(prev_obs), as stored
+        }
+        if (has_next)
+        {
+          table_get<1>(tabA, P.lin_actor, TL0, slotA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, status, ins_a,
+                       [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
+        }
+        if (need_critic)
+        {
+          bool shared_event = false;
+          table_get<1>(tabC, P.lin, TL0, slotC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, status, ins_c,
+                       [&](uint32_t mp) {
+                         trace_share_event(tr, tabC, mp);
+                         if (p_pos == mp) p_sh = true;
+                         shared_event = true;
+                       });
+          if (__any(shared_event) && update) wpc = value_load(tabC, p_pos);
+          wC[0] = trace_forward(tr, posC[0], wC[0]);
+        }
+        if (update) wpc = trace_forward(tr, p_pos, wpc);
+        SHA(0, j, g) = wA[0];
+        SHA(1, j, g) = wC[0];
+        SHA(2, j, g) = wap;
+        SHA(3, j, g) = wpc;
+        sh_ppos[g * 16 + j] = p_pos;
+        sh_apos[g * 16 + j] = ap_pos;
+        sh_fbflag[j * 4 + g] = 0u;
+        wave_sync();
+        double sums[4];
+#pragma unroll
+        for (int row = 0; row < 4; ++row)
+        { // LinearRepresentation::read (linear.cpp:136-184): serial sum, mean
+          double s = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) s += SHA(row, k, g);
+          sums[row] = s / 16;
+        }
+        const double u_next = clampd(sums[0], a_min, a_max);           // actor at s'
+        const double v_next = clampd(sums[1], up.out_min, up.out_max); // critic at s'
+        const double u_prev = clampd(sums[2], a_min, a_max);           // actor at s (before its update)
+        const double v_prev = clampd(sums[3], up.out_min, up.out_max); // critic at s
+
+        // -------- policy (ActionPolicy::act, action.cpp:127-158)
+        double a_next = 0;
+        if (has_next)
+        {
+          double out = u_next;
+          if (!test)
+          {
+            if (time == 0) ac_noise = 0;
+            if (time == 0.) ac_decay = fmax(ac_decay * P.ac_decay_rate, P.ac_decay_min);
+            if (P.sigma != 0)
+            { // Rand::getNormal(0, decay*sigma): two thread-local draws (utils.h:120-125)
+              TL = lcg_next(TL);
+              const double U1 = lcg_double(TL);
+              TL = lcg_next(TL);
+              const double U2 = lcg_double(TL);
+              const double sg = ac_decay * P.sigma;
+              const double nrm = __builtin_sqrt(-2 * plog(U1)) * pcos(2 * GRLX_PI * U2) * sg + 0.;
+              ac_noise = (1 - P.theta) * ac_noise + nrm;
+              out += ac_noise;
+            }
+          }
+          a_next = fmin(fmax(out, P.action_min), P.action_max);
+        }
+
+        // -------- predictor (ActionACPredictor::update, ac.cpp:72-110)
+        double delta = 0;
+        if (update)
+        {
+          // critic: TDPredictor::criticize (td.cpp:68-91)
+          double target = reward;
+          if (has_next) target += P.gamma * v_next;
+          delta = target - v_prev;
+          up.dW = P.alpha * (target - v_prev);
+          up.dT = P.alpha * delta;
+          td_update_lane(tr, tabC, up, p_pos, p_sh, wpc, g, j, sh_ppos, sh_fb, sh_fbflag, status);
+          // actor
+          if (P.ac_update_method == 0 || delta > 0)
+          {
+            double du = action - u_prev;                          // transition.prev_action - u
+            if (P.ac_update_method == 0) du = delta * du;
+            if (P.ac_step_limit >= 0) du = fmin(fmax(du, -P.ac_step_limit), P.ac_step_limit);
+            const double target_u = u_prev + du;
+            const double dA = P.actor_alpha * (target_u - u_prev);    // LinearRepresentation::write
+            uint32_t cpa = 1;                                         // a slot that occurs twice is updated twice
+            const uint32_t amask = (uint32_t)((__ballot(ap_sh) >> (16 * g)) & 0xFFFFull);
+            for (uint32_t mm = amask; mm != 0u; mm &= mm - 1u)
+            {
+              const int k = __builtin_ctz(mm);
+              if (k != j && sh_apos[g * 16 + k] == ap_pos) cpa++;
+            }
+            double nv = wap;
+            for (uint32_t c = 0; c < cpa; ++c) nv = a_limit ? clampd(nv + dA, a_min, a_max) : nv + dA;
+            value_store(tabA, ap_pos, nv);
+          }
+        }
+
+        // -------- tap
+        if (tapped && !first)
+        {
+          uint32_t n = *P.tap_count;
+          if (n < (uint32_t)P.tap_capacity)
+          {
+            grlx_tap *tp = &P.taps[n];
+            tp->p_idx[j] = update ? p_slot : 0u;
+            tp->p_idx[16 + j] = update ? ap_slot : 0u;
+            if (j == 0)
+            {
+              tp->test = test;
+              tp->action_index = 0;
+              tp->terminal = terminal;
+              tp->trace_len = tr.len;
+              for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
+              tp->action = has_next ? a_next : action;
+              tp->reward = reward;
+              tp->delta = delta;
+              for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
+              tp->q[0] = has_next ? u_next : 0.;
+            }
+          }
+          wave_sync();
+          if (j == 0) *P.tap_count = n + 1u;
+        }
+
+        if (!first)
+        {
+          if (test) test_steps++;
+          else ss++;
+        }
+        if (has_next)
+        {
+          action = a_next;
+          ap_pos = posA[0]; ap_slot = slotA[0]; ap_sh = shA[0];
+          if (need_critic) { p_pos = posC[0]; p_slot = slotC[0]; p_sh = shC[0]; }
+        }
+        if (!first && terminal) running = false;
+        first = false;
+      }
+    }
+
+    // end of a learning trial: make the table current (test trials and the host read it); the
+    // entries themselves stay -- the reference never clears the critic's trace
+    if (!test) trace_flush(tr, tabC, false);
+
+    if (live && (ti >= 0 ? test : 1))
+    {
+      if (rows < (uint32_t)P.max_rows)
+      {
+        if (j == 0)
+        {
+          size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
+          P.row_reward[at] = total_reward;
+          P.row_steps[at] = ss;
+          P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
+        }
+        rows++;
+      }
+      else
+        status |= ST_ROWS_FULL;
+    }
+  }
+
+  // persist the critic's trace (weights are in the table already)
+  trace_flush(tr, tabC, false);
+  if (live && up.use_trace)
+  {
+#pragma unroll
+    for (int e = 0; e < kMaxTrace; ++e)
+    {
+      ts[e * 2] = tr.pos[e];
+      ts[e * 2 + 1] = (tr.cnt[e] & 0xFFFFu) | (((tr.wt >> e) & 1u) << 16);
+    }
+  }
+  uint32_t ic = ins_c, ia = ins_a;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) { ic += __shfl_xor(ic, off, 16); ia += __shfl_xor(ia, off, 16); }
+  if (live && j == 0)
+  {
+#pragma unroll
+    for (int i = 0; i < S; ++i) RS.x[i] = x[i];
+    RS.G = G;
+    RS.TL = TL;
+    RS.ac_decay = ac_decay;
+    RS.ac_noise = ac_noise;
+    RS.tt = tt;
+    RS.ss = ss;
+    RS.test_steps = test_steps;
+    RS.n_slots[0] += ic;
+    RS.n_slots[1] += ia;
+    RS.rows = rows;
+    RS.tr_len = tr.len;
+    RS.tr_total = tr.total;
+  }
+  uint32_t st = status;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+  if (live && j == 0) RS.status = st;
+}
+
+hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream)
+{
+  int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  switch (P.env)
+  {
+    case GRLX_ENV_CART_POLE:
+      hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      break;
+    case GRLX_ENV_PENDULUM:
+      hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_PENDULUM>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
 {
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
@@ -1319,6 +1734,7 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 3)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 5)
   GRLX_LAUNCH(GRLX_ENV_ACROBOT, 3)
+  GRLX_LAUNCH(GRLX_ENV_CART_POLE, 3)
 #undef GRLX_LAUNCH
   return hipErrorInvalidValue;
 }
@@ -1380,6 +1796,10 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
       hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_ACROBOT>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
                          obs_dev, reward_dev, terminal_dev, err_dev);
       break;
+    case GRLX_ENV_CART_POLE:
+      hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_CART_POLE>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
+                         obs_dev, reward_dev, terminal_dev, err_dev);
+      break;
     default:
       return hipErrorInvalidValue;
   }
@@ -1405,14 +1825,15 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
     const bool valid = act && slot != 0xFFFFFFFFu;     // invalid_index(): skipped by update (linear.cpp:207)
     double w = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    table_probe(tab, P.lin, P.states[r].TL0, valid, slot, pos, w, status, inserted);
+    const LinearParams &lp = table == 1 ? P.lin_actor : P.lin;
+    table_probe(tab, lp, P.states[r].TL0, valid, slot, pos, w, status, inserted);
     sh[lane] = w;
     shp[lane] = valid ? pos : kInvalidPos;
     wave_sync();
     double s = 0;
     for (int k = 0; k < Tn; ++k) s += sh[k];
     s /= Tn;
-    s = clampd(s, P.lin.out_min, P.lin.out_max);
+    s = clampd(s, lp.out_min, lp.out_max);
     if (op == 0)
     {
       if (lane == 0) out[i] = s;
@@ -1428,7 +1849,7 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
         for (int k = lane + 1; k < Tn; ++k) last = last && (shp[k] != pos);
         double v = w;
         for (uint32_t cc = 0; cc < c; ++cc)
-          v = P.lin.limit ? clampd(v + d, P.lin.out_min, P.lin.out_max) : v + d;
+          v = lp.limit ? clampd(v + d, lp.out_min, lp.out_max) : v + d;
         if (last) value_store(tab, pos, v);
       }
     }
@@ -1459,7 +1880,7 @@ __global__ void get_weights_kernel(DevParams P, int table, int replica, const ui
   const Table tab = table_of(P, table, replica);
   uint32_t slot = slots[i];
   uint32_t b = table_home(tab, slot);
-  double v = lazy_weight(P.states[replica].TL0, P.lin, slot);
+  double v = lazy_weight(P.states[replica].TL0, table == 1 ? P.lin_actor : P.lin, slot);
   for (int it = 0; it < kMaxProbe; ++it)
   {
     const BucketRegs br = bucket_load(tab, b);

@@ -20,6 +20,17 @@ def pendulum_sarsa_config(n_replicas=1, **overrides) -> capi.Config:
     return cfg
 
 
+def cart_pole_ac_config(n_replicas=1, **overrides) -> capi.Config:
+    """Config of the reference's cfg/cart_pole/ac_tc.yaml (actor-critic over two tile-coded tables)."""
+    lib = capi.load()
+    cfg = capi.Config()
+    lib.grlx_config_cart_pole_ac(C.byref(cfg))
+    cfg.n_replicas = n_replicas
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
 def _ptr(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
 

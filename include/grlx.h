@@ -98,6 +98,9 @@ typedef struct {
   int32_t  max_rows;                  /* test rows reserved per replica                          */
   int32_t  tap_replica;               /* -1: off; else record per-step taps of that replica      */
   int32_t  tap_capacity;
+  /* task/cart_pole/swingup (cart_pole.cpp:110-130); class defaults 1 / 0, cfg/cart_pole/ac_tc.yaml: 0 / 0 */
+  int32_t  end_stop_penalty;
+  int32_t  action_penalty;
   int32_t  reserved1;
 } grlx_config;
 
@@ -118,6 +121,8 @@ int  grlx_device_count(void);
 
 /* Fill *cfg with the values of the reference's tests/pendulum-sarsa-tc.yaml. */
 void grlx_config_pendulum_sarsa(grlx_config *cfg);
+/* Fill *cfg with the values of the reference's cfg/cart_pole/ac_tc.yaml (actor-critic, two tables). */
+void grlx_config_cart_pole_ac(grlx_config *cfg);
 
 /* Replaces: Configurator::instantiate of the experiment subtree (configurable.cpp:603-715)
  * for n_replicas deep clones (multi.cpp:49-59) after `srand48(seeds[r])`

@@ -33,3 +33,28 @@ def acrobot(grlx, n, agent=1, **over):
     spec.action_min, spec.action_max, spec.action_steps = -1.0, 1.0, 3
     _set_tile(spec.projector, 16, 8388608, res, wrap)
     return cfg, spec
+
+
+def cart_pole_ac(grlx, n, **over):
+    """cfg/cart_pole/ac_tc.yaml: dynamics/cart_pole + task/cart_pole/swingup, mapping/policy/action,
+    predictor/ac/action with a predictor/critic/td critic; two 8,388,608-slot tables."""
+    cfg = grlx.cart_pole_ac_config(n, **over)
+    spec = ob.pendulum_sarsa_spec()
+    spec.env, spec.agent = 1, ob.AGENT_AC
+    spec.control_step, spec.integration_steps, spec.timeout, spec.randomization = 0.05, 5, 9.99, 0.0
+    spec.end_stop_penalty, spec.action_penalty = cfg.end_stop_penalty, cfg.action_penalty
+    spec.action_min, spec.action_max, spec.action_steps = -15.0, 15.0, 0
+    res, wrap = [2.5, 0.157075, 2.5, 1.57075], [0, 6.283, 0, 0]
+    for ts in (spec.projector, spec.actor_projector):
+        for i in range(8):
+            ts.resolution[i] = 0.0
+            ts.wrapping[i] = 0.0
+        _set_tile(ts, 16, 8388608, res, wrap)
+    ar = spec.actor_representation
+    ar.init_min, ar.init_max, ar.output_min, ar.output_max, ar.limit = 0.0, 1.0, -15.0, 15.0, 1
+    spec.actor_alpha, spec.sigma, spec.theta = 0.01, 5.0, 1.0
+    spec.ac_decay_rate, spec.ac_decay_min, spec.ac_update_method, spec.ac_step_limit = 1.0, 0.0, 0, -1.0
+    for k, v in over.items():
+        if hasattr(spec, k) and k not in ("tap_replica", "tap_capacity"):
+            setattr(spec, k, v)
+    return cfg, spec

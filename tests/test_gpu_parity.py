@@ -371,3 +371,74 @@ def test_acrobot_fused_bit_exact(grlx, agent):
                 except AssertionError as ex:
                     raise AssertionError(f"step {i}: {ex}")
     r.close()
+
+
+# ------------------------------------------------- cart-pole, actor-critic ---
+def test_cart_pole_env_step_bit_exact(grlx):
+    from tests import configs
+    for esp in (0, 1):
+        cfg, spec = configs.cart_pole_ac(grlx, 1, end_stop_penalty=esp, action_penalty=esp)
+        rng = np.random.default_rng(13 + esp)
+        n = 4000
+        state = np.stack([rng.uniform(-2.6, 2.6, n), rng.uniform(-20, 20, n), rng.uniform(-8, 8, n),
+                          rng.uniform(-15, 15, n), rng.uniform(0, 9.97, n)], axis=1)
+        action = rng.uniform(-15, 15, n)
+        for _ in range(3):
+            gs, gobs, grew, gterm = grlx.runner.env_step(cfg, state, action)
+            os_, oobs, orew, oterm = ob.env_step(spec, state, action)
+            assert_bit_equal(gs, os_, "state"); assert_bit_equal(gobs, oobs, "obs"); assert_bit_equal(grew, orew, "reward")
+            assert (gterm == oterm).all()
+            state = gs
+        if esp:
+            assert 2 in set(np.unique(gterm))
+
+
+def test_device_log_sqrt_for_box_muller(grlx, oracle):
+    """Rand::getNormal (utils.h:120-125) = sqrt(-2 log U1) cos(2 pi U2): log on drand48 values k * 2^-48"""
+    rng = np.random.default_rng(17)
+    u = np.concatenate([rng.integers(1, 1 << 48, 200000).astype(np.float64) * 2.0 ** -48, [2.0 ** -48, 1 - 2.0 ** -48, 0.5]])
+    got = grlx.runner.device_math(2, u)
+    want = np.array([oracle.orc_plog(float(v)) for v in u])
+    assert_bit_equal(got, want, "plog on uniform draws")
+    assert_bit_equal(grlx.runner.device_math(4, -2 * want), np.sqrt(-2 * want), "sqrt")
+
+
+@pytest.mark.parametrize("over", [dict(), dict(end_stop_penalty=1, ac_update_method=1, ac_step_limit=0.5)])
+def test_actor_critic_fused_bit_exact(grlx, over):
+    """cfg/cart_pole/ac_tc.yaml semantics: every step of one replica (actor and critic tile indices,
+    actor output, noisy action, reward, TD error, trace length -- the critic trace is never cleared),
+    rows / RNG / state / sampled weights of both tables of all replicas; four launches."""
+    from tests import configs
+    seeds = [31, 32, 33, 34, 35]
+    trials, cap = 24, 6000
+    cfg, spec = configs.cart_pole_ac(grlx, len(seeds), tap_replica=1, tap_capacity=cap, **over)
+    r = grlx.Runner(cfg, seeds)
+    for n in (5, 7, 1, 11):
+        r.run(n)
+    r.sync()
+    rng = np.random.default_rng(19)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, otaps = e.run(trials, tap_cap=cap)
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns seed {seed}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        assert_bit_equal(r.env_state(k), e.state(), "env state")
+        if k == 1:
+            gtaps = r.taps()
+            assert len(gtaps) == len(otaps) and len(otaps) > 1000
+            for i, (gt, ot) in enumerate(zip(gtaps, otaps)):
+                try:
+                    assert list(gt.p_idx[16:32]) == list(ot.p_idx[16:32])
+                    _compare_taps(gt, ot, A=1, D=4)
+                except AssertionError as ex:
+                    raise AssertionError(f"step {i}: {ex}")
+            touched = np.unique(np.array([list(tp.p_idx[:16]) for tp in otaps if not tp.test]).ravel()).astype(np.uint32)
+            touched_a = np.unique(np.array([list(tp.p_idx[16:32]) for tp in otaps if not tp.test]).ravel()).astype(np.uint32)
+            assert_bit_equal(r.weights(k, touched, table=0), e.weights(touched, table=0), "critic weights touched")
+            assert_bit_equal(r.weights(k, touched_a, table=1), e.weights(touched_a, table=1), "actor weights touched")
+        slots = rng.integers(0, 8388608, 2000).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots, table=0), e.weights(slots, table=0), "critic weights")
+        assert_bit_equal(r.weights(k, slots, table=1), e.weights(slots, table=1), "actor weights")
+    r.close()
