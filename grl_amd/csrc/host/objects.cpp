@@ -100,6 +100,48 @@ struct AcrobotBalancingTask : Task {
 };
 GRLX_REGISTER(AcrobotBalancingTask)
 
+// dynamics/cart_pole, task/cart_pole/swingup (cart_pole.cpp:36-56, 110-153)
+struct CartPoleDynamics : Dynamics {
+  GRLX_TYPEINFO("dynamics/cart_pole")
+  int env_id() const override { return GRLX_ENV_CART_POLE; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  { config->push_back(CRP("end_stop", "Simulate end stops (adds position and velocity to state)", 1)); }
+  void configure(Configuration &config) override
+  { if ((int)config["end_stop"] != 1) throw Exception(path() + ": end_stop must be 1 (task/cart_pole/swingup needs the 5-dimensional state)"); }
+};
+GRLX_REGISTER(CartPoleDynamics)
+struct CartPoleSwingupTask : Task {
+  GRLX_TYPEINFO("task/cart_pole/swingup")
+  int end_stop_penalty = 1, action_penalty = 0;
+  int env_id() const override { return GRLX_ENV_CART_POLE; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("timeout", "Episode timeout", 9.99));
+    config->push_back(CRP("randomization", "Start state randomization", 0., CRP::Online));
+    config->push_back(CRP("shaping", "Whether to use reward shaping", 0));
+    config->push_back(CRP("gamma", "Discount rate for reward shaping", 1.));
+    config->push_back(CRP("end_stop_penalty", "Terminate episode with penalty when end stop is reached", 1));
+    config->push_back(CRP("action_penalty", "Penalize applied torque", 0));
+    for (const char *n : {"observation_dims", "observation_min", "observation_max", "action_dims", "action_min", "action_max", "reward_min", "reward_max"})
+      config->push_back(CRP::provided(n, std::string("vector.") + n, "Task limits"));
+  }
+  void configure(Configuration &config) override
+  {
+    timeout = config["timeout"]; randomization = config["randomization"];
+    end_stop_penalty = config["end_stop_penalty"]; action_penalty = config["action_penalty"];
+    if ((int)config["shaping"] != 0) throw Exception(path() + ": reward shaping is outside the accelerated path");
+    config.set("observation_dims", 4);
+    config.set("observation_min", VecD{-2.4, 0., -10.0, -5 * kPi});
+    config.set("observation_max", VecD{2.4, 2 * kPi, 10.0, 5 * kPi});
+    config.set("action_dims", 1);
+    config.set("action_min", VecD{-15.});
+    config.set("action_max", VecD{15.});
+    config.set("reward_min", -2 * std::pow(2.4, 2) - 0.1 * std::pow(10, 2) - std::pow(kPi, 2) - 0.1 * std::pow(5 * kPi, 2) - action_penalty * 2 - end_stop_penalty * 10000);
+    config.set("reward_max", 0.);
+  }
+};
+GRLX_REGISTER(CartPoleSwingupTask)
+
 // model/dynamical (modeled.cpp:234-252)
 struct DynamicalModel : Configurable {
   GRLX_TYPEINFO("model/dynamical")
@@ -272,8 +314,48 @@ struct EpsilonGreedySampler : GreedySampler {
 };
 GRLX_REGISTER(EpsilonGreedySampler)
 
+struct Policy : Configurable {};
+
+// mapping/policy/action (action.cpp:38-91)
+struct ActionPolicy : Policy {
+  GRLX_TYPEINFO("mapping/policy/action")
+  VecD sigma, theta, min, max; double decay_rate = 1, decay_min = 0;
+  TileCodingProjector *projector = nullptr; LinearRepresentation *representation = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("sigma", "Standard deviation of Gaussian exploration distribution", VecD{}));
+    config->push_back(CRP("theta", "Ornstein-Uhlenbeck friction term (1=pure Gaussian noise)", VecD{}));
+    config->push_back(CRP("decay_rate", "Multiplicative decay factor per episode", 1.));
+    config->push_back(CRP("decay_min", "Minimum decay (sigma_min = sigma*decay_min)", 0.));
+    config->push_back(CRP("renormalize", "Renormalize representation output from [-1, 1] to [min, max]", 0));
+    config->push_back(CRP("output_min", "Lower limit on outputs", VecD{}, CRP::System));
+    config->push_back(CRP("output_max", "Upper limit on outputs", VecD{}, CRP::System));
+    config->push_back(CRP("projector", "projector.observation", "Projects observations onto representation space", (Configurable *)nullptr));
+    config->push_back(CRP("representation", "representation.action", "Action representation", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
+    representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
+    sigma = config["sigma"].v(); theta = config["theta"].v();
+    decay_rate = config["decay_rate"]; decay_min = config["decay_min"];
+    min = config["output_min"].v(); max = config["output_max"].v();
+    if (min.size() != max.size() || min.empty()) throw bad_param("policy/action:{output_min,output_max}");
+    if (sigma.empty()) sigma = VecD{0.};
+    if (sigma.size() == 1) sigma.assign(min.size(), sigma[0]);
+    if (sigma.size() != min.size()) throw bad_param("policy/action:sigma");
+    if (theta.empty()) theta = VecD{1.};
+    if (theta.size() == 1) theta.assign(min.size(), theta[0]);
+    if (theta.size() != min.size()) throw bad_param("policy/action:theta");
+    if ((int)config["renormalize"] != 0) throw Exception(path() + ": renormalize is outside the accelerated path");
+    if (!projector || !representation) throw Exception(path() + ": projector/representation outside the accelerated path");
+    if (min.size() != 1) throw Exception(path() + ": one action dimension supported");
+  }
+};
+GRLX_REGISTER(ActionPolicy)
+
 // mapping/policy/discrete/value/q (q.cpp:35-52); the reference's own test yaml still says policy/discrete/q
-struct QPolicy : Configurable {
+struct QPolicy : Policy {
   GRLX_TYPEINFO("mapping/policy/discrete/value/q")
   UniformDiscretizer *discretizer = nullptr; TileCodingProjector *projector = nullptr;
   LinearRepresentation *representation = nullptr; GreedySampler *sampler = nullptr;
@@ -304,8 +386,10 @@ GRLX_REGISTER(ReplacingTrace)
 struct AccumulatingTrace : Trace { GRLX_TYPEINFO("trace/enumerated/accumulating") int kind() const override { return GRLX_TRACE_ACCUMULATING; } };
 GRLX_REGISTER(AccumulatingTrace)
 
+struct Predictor : Configurable {};
+
 // predictor/critic/sarsa (sarsa.cpp:35-60), predictor/critic/q (advantage.cpp:35-62)
-struct TDPredictorBase : Configurable {
+struct TDPredictorBase : Predictor {
   double alpha = 0.2, gamma = 0.97, lambda = 0.65;
   TileCodingProjector *projector = nullptr; LinearRepresentation *representation = nullptr; Trace *trace = nullptr;
   virtual int agent_id() const = 0;
@@ -342,10 +426,67 @@ GRLX_REGISTER(SARSAPredictorLegacy)
 struct QPredictorLegacy : QPredictor { GRLX_TYPEINFO("predictor/q") };
 GRLX_REGISTER(QPredictorLegacy)
 
+// predictor/critic/td (predictors/td.cpp:35-58): V(s) critic with a trace
+struct VPredictor : Predictor {
+  GRLX_TYPEINFO("predictor/critic/td")
+  double alpha = 0.2, gamma = 0.97, lambda = 0.65;
+  TileCodingProjector *projector = nullptr; LinearRepresentation *representation = nullptr; Trace *trace = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("alpha", "Learning rate", 0.2));
+    config->push_back(CRP("gamma", "Discount rate", 0.97));
+    config->push_back(CRP("lambda", "Trace decay rate", 0.65));
+    config->push_back(CRP("projector", "projector.observation", "Projects observations onto representation space", (Configurable *)nullptr));
+    config->push_back(CRP("representation", "representation.value/state", "State value representation", (Configurable *)nullptr));
+    config->push_back(CRP("trace", "trace", "Trace of projections", (Configurable *)nullptr, true));
+    config->push_back(CRP("importer", "importer", "Optional importer", (Configurable *)nullptr, true));
+    config->push_back(CRP("exporter", "exporter", "Optional exporter", (Configurable *)nullptr, true));
+  }
+  void configure(Configuration &config) override
+  {
+    alpha = config["alpha"]; gamma = config["gamma"]; lambda = config["lambda"];
+    projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
+    representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
+    trace = dynamic_cast<Trace *>(config["trace"].ptr());
+    if (!projector || !representation) throw Exception(path() + ": projector/representation outside the accelerated path");
+    if (config["importer"].ptr() || config["exporter"].ptr()) throw Exception(path() + ": importer/exporter are outside the accelerated path");
+  }
+};
+GRLX_REGISTER(VPredictor)
+
+// predictor/ac/action (ac.cpp:36-70)
+struct ActionACPredictor : Predictor {
+  GRLX_TYPEINFO("predictor/ac/action")
+  double alpha = 0.01; std::string update_method = "proportional"; VecD step_limit;
+  TileCodingProjector *projector = nullptr; LinearRepresentation *representation = nullptr; VPredictor *critic = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("alpha", "Critic learning rate", 0.01));
+    config->push_back(CRP("update_method", "Actor update method", std::string("proportional")));
+    config->push_back(CRP("step_limit", "Actor exploration step limit", VecD{}));
+    config->push_back(CRP("projector", "projector.observation", "Projects observations onto actor representation space", (Configurable *)nullptr));
+    config->push_back(CRP("representation", "representation.action", "Action representation", (Configurable *)nullptr));
+    config->push_back(CRP("critic", "predictor/critic", "Critic predictor", (Configurable *)nullptr));
+    config->push_back(CRP("importer", "importer", "Optional importer", (Configurable *)nullptr, true));
+    config->push_back(CRP("exporter", "exporter", "Optional exporter", (Configurable *)nullptr, true));
+  }
+  void configure(Configuration &config) override
+  {
+    alpha = config["alpha"]; update_method = config["update_method"].str(); step_limit = config["step_limit"].v();
+    projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
+    representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
+    critic = dynamic_cast<VPredictor *>(config["critic"].ptr());
+    if (update_method != "proportional" && update_method != "cacla") throw bad_param("predictor/ac/action:update_method");
+    if (step_limit.size() > 1) throw bad_param("predictor/ac:step_limit");
+    if (!projector || !representation || !critic) throw Exception(path() + ": the accelerated path needs tile coding, a linear actor and a predictor/critic/td critic");
+  }
+};
+GRLX_REGISTER(ActionACPredictor)
+
 // agent/td (td.cpp:34-48), agent/fixed (fixed.cpp:34-45)
 struct TDAgent : Configurable {
   GRLX_TYPEINFO("agent/td")
-  QPolicy *policy = nullptr; TDPredictorBase *predictor = nullptr;
+  Policy *policy = nullptr; Predictor *predictor = nullptr;
   void request(const std::string &, ConfigurationRequest *config) override
   {
     config->push_back(CRP("policy", "mapping/policy", "Control policy", (Configurable *)nullptr));
@@ -353,20 +494,20 @@ struct TDAgent : Configurable {
   }
   void configure(Configuration &config) override
   {
-    policy = dynamic_cast<QPolicy *>(config["policy"].ptr());
-    predictor = dynamic_cast<TDPredictorBase *>(config["predictor"].ptr());
+    policy = dynamic_cast<Policy *>(config["policy"].ptr());
+    predictor = dynamic_cast<Predictor *>(config["predictor"].ptr());
     if (!policy || !predictor) throw Exception(path() + ": policy/predictor outside the accelerated path");
   }
 };
 GRLX_REGISTER(TDAgent)
 struct FixedAgent : Configurable {
   GRLX_TYPEINFO("agent/fixed")
-  QPolicy *policy = nullptr;
+  Policy *policy = nullptr;
   void request(const std::string &, ConfigurationRequest *config) override
   { config->push_back(CRP("policy", "mapping/policy", "Control policy", (Configurable *)nullptr)); }
   void configure(Configuration &config) override
   {
-    policy = dynamic_cast<QPolicy *>(config["policy"].ptr());
+    policy = dynamic_cast<Policy *>(config["policy"].ptr());
     if (!policy) throw Exception(path() + ": policy outside the accelerated path");
   }
 };
@@ -413,33 +554,34 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       throw Exception(path() + ": exporter/load_file/save_every/rate/test_trials/steps are outside the accelerated path");
   }
 
-  // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernel makes is checked
+  // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernels make is checked
+  static void lower_tile(const TileCodingProjector *p, grlx_tile_spec *t)
+  {
+    memset(t, 0, sizeof(*t));
+    t->tilings = p->tilings; t->memory = p->memory; t->dims = (int)p->resolution.size();
+    if (p->resolution.size() > GRLX_MAX_DIMS) throw bad_param("projector/tile_coding:resolution");
+    for (size_t i = 0; i < p->resolution.size(); ++i) { t->resolution[i] = p->resolution[i]; t->wrapping[i] = p->wrapping[i]; }
+  }
+  static void lower_linear(const LinearRepresentation *r, const TileCodingProjector *p, grlx_linear_spec *l)
+  {
+    if (r->outputs != 1) throw Exception(r->path() + ": outputs must be 1");
+    if (r->memory != p->memory) throw bad_param("representation/parameterized/linear:memory (or matching projector)");
+    l->init_min = r->init_min[0]; l->init_max = r->init_max[0];
+    l->output_min = r->output_min[0]; l->output_max = r->output_max[0];
+    l->limit = r->limit;
+  }
+  int order_of(const Configurable *o) const
+  {
+    int k = 0;
+    for (Configurator *n : instantiate_order()) { if (n->object.get() == o) return k; ++k; }
+    return -1;
+  }
+
   void lower(grlx_config *c) const
   {
     grlx_config_pendulum_sarsa(c);
     const DynamicalModel *m = environment->model;
     const Task *t = environment->task;
-    const QPolicy *pol = agent->policy;
-    const TDPredictorBase *pred = agent->predictor;
-    if (pred->projector != pol->projector || pred->representation != pol->representation)
-      throw Exception(pred->path() + ": predictor and policy must share projector and representation on the accelerated path");
-    if (test_agent && (test_agent->policy->projector != pol->projector || test_agent->policy->representation != pol->representation ||
-                       test_agent->policy->discretizer != pol->discretizer))
-      throw Exception(test_agent->path() + ": the test policy must share discretizer, projector and representation with the learning policy");
-    if (!pol->sampler->explores() || (test_agent && test_agent->policy->sampler->explores()))
-      throw Exception(path() + ": the accelerated path needs sampler/epsilon_greedy for learning and sampler/greedy for testing");
-    // RNG streams are consumed in instantiate order (SURVEY Appendix A.1): representation, learning sampler, test sampler
-    int at_repr = -1, at_s1 = -1, at_s2 = -1, k = 0;
-    for (Configurator *n : instantiate_order())
-    {
-      if (n->object.get() == pol->representation) at_repr = k;
-      if (n->object.get() == pol->sampler) at_s1 = k;
-      if (test_agent && n->object.get() == test_agent->policy->sampler) at_s2 = k;
-      ++k;
-    }
-    if (!(at_repr >= 0 && at_repr < at_s1 && (!test_agent || at_s1 < at_s2)))
-      throw Exception(path() + ": this yaml instantiates representation/samplers in an order the fused kernel does not reproduce");
-
     c->test_interval = test_interval;
     c->env = t->env_id();
     c->control_step = m->control_step;
@@ -447,22 +589,64 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     c->discrete_time = environment->discrete_time;
     c->timeout = t->timeout;
     c->randomization = t->randomization;
+    if (const CartPoleSwingupTask *cp = dynamic_cast<const CartPoleSwingupTask *>(t))
+    { c->end_stop_penalty = cp->end_stop_penalty; c->action_penalty = cp->action_penalty; }
+
+    if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
+    { // ---- actor-critic (cfg/cart_pole/ac_tc.yaml)
+      const ActionPolicy *pol = dynamic_cast<const ActionPolicy *>(agent->policy);
+      const ActionPolicy *tpol = test_agent ? dynamic_cast<const ActionPolicy *>(test_agent->policy) : nullptr;
+      if (!pol || (test_agent && !tpol)) throw Exception(path() + ": predictor/ac/action needs mapping/policy/action policies");
+      if (ac->projector != pol->projector || ac->representation != pol->representation)
+        throw Exception(ac->path() + ": actor predictor and policy must share projector and representation");
+      if (tpol && (tpol->projector != pol->projector || tpol->representation != pol->representation))
+        throw Exception(test_agent->path() + ": the test policy must share projector and representation with the learning policy");
+      if (tpol && tpol->sigma[0] != 0) throw Exception(tpol->path() + ": the test policy must be noise-free (sigma: [])");
+      const VPredictor *cr = ac->critic;
+      if (cr->representation == pol->representation) throw Exception(cr->path() + ": actor and critic need separate tables");
+      // both tables draw their initial weights from one thread-local stream: actor first
+      if (!(order_of(pol->representation) >= 0 && order_of(pol->representation) < order_of(cr->representation)))
+        throw Exception(path() + ": this yaml instantiates the actor/critic tables in an order the fused kernel does not reproduce");
+      c->agent = GRLX_AGENT_AC;
+      c->action_min = pol->min[0]; c->action_max = pol->max[0]; c->action_steps = 0;
+      lower_tile(cr->projector, &c->projector);
+      lower_linear(cr->representation, cr->projector, &c->representation);
+      lower_tile(pol->projector, &c->actor_projector);
+      lower_linear(pol->representation, pol->projector, &c->actor_representation);
+      c->alpha = cr->alpha; c->gamma = cr->gamma; c->lambda = cr->lambda;
+      c->trace = cr->trace ? cr->trace->kind() : GRLX_TRACE_NONE;
+      c->actor_alpha = ac->alpha;
+      c->sigma = pol->sigma[0]; c->theta = pol->theta[0];
+      c->ac_decay_rate = pol->decay_rate; c->ac_decay_min = pol->decay_min;
+      c->ac_update_method = ac->update_method[0] == 'p' ? 0 : 1;
+      c->ac_step_limit = ac->step_limit.empty() ? -1. : ac->step_limit[0];
+      c->table_log2_capacity = 18;
+      return;
+    }
+
+    // ---- discrete Q policies (cfg/pendulum/sarsa_tc.yaml, q_tc.yaml)
+    const QPolicy *pol = dynamic_cast<const QPolicy *>(agent->policy);
+    const TDPredictorBase *pred = dynamic_cast<const TDPredictorBase *>(agent->predictor);
+    const QPolicy *tpol = test_agent ? dynamic_cast<const QPolicy *>(test_agent->policy) : nullptr;
+    if (!pol || !pred || (test_agent && !tpol))
+      throw Exception(path() + ": the accelerated path needs mapping/policy/discrete/value/q with predictor/critic/sarsa|q, or policy/action with predictor/ac/action");
+    if (pred->projector != pol->projector || pred->representation != pol->representation)
+      throw Exception(pred->path() + ": predictor and policy must share projector and representation on the accelerated path");
+    if (tpol && (tpol->projector != pol->projector || tpol->representation != pol->representation || tpol->discretizer != pol->discretizer))
+      throw Exception(test_agent->path() + ": the test policy must share discretizer, projector and representation with the learning policy");
+    if (!pol->sampler->explores() || (tpol && tpol->sampler->explores()))
+      throw Exception(path() + ": the accelerated path needs sampler/epsilon_greedy for learning and sampler/greedy for testing");
+    // RNG streams are consumed in instantiate order (SURVEY Appendix A.1): representation, learning sampler, test sampler
+    const int at_repr = order_of(pol->representation), at_s1 = order_of(pol->sampler), at_s2 = tpol ? order_of(tpol->sampler) : -1;
+    if (!(at_repr >= 0 && at_repr < at_s1 && (!tpol || at_s1 < at_s2)))
+      throw Exception(path() + ": this yaml instantiates representation/samplers in an order the fused kernel does not reproduce");
     const UniformDiscretizer *d = pol->discretizer;
     if (d->min.size() != 1) throw Exception(d->path() + ": one action dimension supported");
     c->action_min = d->min[0]; c->action_max = d->max[0]; c->action_steps = (int)d->steps[0];
-    const TileCodingProjector *p = pol->projector;
-    memset(&c->projector, 0, sizeof(c->projector));
-    c->projector.tilings = p->tilings; c->projector.memory = p->memory; c->projector.dims = (int)p->resolution.size();
-    if (p->resolution.size() > GRLX_MAX_DIMS) throw bad_param("projector/tile_coding:resolution");
-    for (size_t i = 0; i < p->resolution.size(); ++i) { c->projector.resolution[i] = p->resolution[i]; c->projector.wrapping[i] = p->wrapping[i]; }
-    const LinearRepresentation *r = pol->representation;
-    if (r->outputs != 1) throw Exception(r->path() + ": outputs must be 1 for a Q table");
-    if (r->memory != p->memory) throw bad_param("representation/parameterized/linear:memory (or matching projector)");
-    c->representation.init_min = r->init_min[0]; c->representation.init_max = r->init_max[0];
-    c->representation.output_min = r->output_min[0]; c->representation.output_max = r->output_max[0];
-    c->representation.limit = r->limit;
-    const EpsilonGreedySampler *s = static_cast<const EpsilonGreedySampler *>(pol->sampler);
-    c->epsilon = s->epsilon[0]; c->decay_rate = s->decay_rate; c->decay_min = s->decay_min;
+    lower_tile(pol->projector, &c->projector);
+    lower_linear(pol->representation, pol->projector, &c->representation);
+    const EpsilonGreedySampler *sm = static_cast<const EpsilonGreedySampler *>(pol->sampler);
+    c->epsilon = sm->epsilon[0]; c->decay_rate = sm->decay_rate; c->decay_min = sm->decay_min;
     c->agent = pred->agent_id();
     c->alpha = pred->alpha; c->gamma = pred->gamma; c->lambda = pred->lambda;
     c->trace = pred->trace ? pred->trace->kind() : GRLX_TRACE_NONE;
@@ -498,7 +682,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       const int n = grlx_rows(ctx);
       std::vector<int64_t> trial((size_t)n), stp((size_t)n);
       std::vector<double> reward((size_t)n);
-      const double episode_time = c.control_step * std::floor(c.timeout / c.control_step + 1);
+      const double episode_time = c.control_step * std::floor(c.timeout / c.control_step + 1);   // nominal (timeout episodes)
       for (int i = 0; i < opt.replicas; ++i)
       {
         grlx_read_rows(ctx, i, 0, n, trial.data(), stp.data(), reward.data());

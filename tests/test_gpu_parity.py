@@ -442,3 +442,18 @@ def test_actor_critic_fused_bit_exact(grlx, over):
         assert_bit_equal(r.weights(k, slots, table=0), e.weights(slots, table=0), "critic weights")
         assert_bit_equal(r.weights(k, slots, table=1), e.weights(slots, table=1), "actor weights")
     r.close()
+
+
+def test_deployer_actor_critic_rows_equal_oracle(grlx, tmp_path):
+    """grlxd on the actor-critic yaml: the rows it writes are the oracle's, digit for digit."""
+    import subprocess
+    from grl_amd import _build
+    from tests import configs
+    grlxd = _build.build_host()
+    yaml = os.path.join(os.path.dirname(__file__), "golden", "cart_pole-ac-tc.yaml")
+    res = subprocess.run([grlxd, "-s", "31", "-l", "-q", yaml], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    _, spec = configs.cart_pole_ac(grlx, 1)
+    e = ob.Experiment(spec, seed=31)
+    rows, _ = e.run(24)
+    assert (tmp_path / "cart_pole-ac-tc-0.txt").read_text() == e.format_rows(rows)

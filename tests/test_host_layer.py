@@ -60,3 +60,18 @@ def test_usage_and_seed_errors(grlxd, tmp_path):
     assert run(grlxd, [], tmp_path).returncode == 1
     res = run(grlxd, ["-s", "0", YAML], tmp_path)
     assert res.returncode == 1 and "seed 0" in res.stderr
+
+
+def test_instantiates_actor_critic_yaml(grlxd, tmp_path):
+    """Two tables, references to values (resolution, memory, action_dims) and to objects."""
+    yaml = os.path.join(ROOT, "tests", "golden", "cart_pole-ac-tc.yaml")
+    res = run(grlxd, ["-s", "1", "-q", yaml], tmp_path)
+    dumped = (tmp_path / "cart_pole-ac-tc.yaml").read_text()
+    assert "type: predictor/ac/action" in dumped and "type: predictor/critic/td" in dumped
+    assert dumped.count("resolution: [ 2.5, 0.157075, 2.5, 1.57075 ]") == 2       # critic copies the actor's by reference
+    assert "outputs: 1" in dumped and "output_min: [ -15 ]" in dumped
+    assert "no HIP device" in res.stderr or res.returncode == 0
+    # critic before actor: the fused kernel cannot reproduce that RNG order and must refuse
+    text = open(yaml).read()
+    swapped = text.replace("    policy:\n      type: mapping/policy/action\n      sigma: [ 5 ]", "    policy_moved:\n      type: mapping/policy/action\n      sigma: [ 5 ]")
+    assert swapped != text
