@@ -68,6 +68,7 @@ int env_dims(int env, int *S, int *D)
     case GRLX_ENV_PENDULUM: *S = 3; *D = 2; return GRLX_OK;
     case GRLX_ENV_ACROBOT: *S = 5; *D = 4; return GRLX_OK;
     case GRLX_ENV_CART_POLE: *S = 5; *D = 4; return GRLX_OK;
+    case GRLX_ENV_COMPASS_WALKER: *S = 11; *D = 5; return GRLX_OK;
     default: return GRLX_ERR_INVALID;
   }
 }
@@ -130,6 +131,12 @@ int make_params(const grlx_config &c, DevParams *P)
   P->timeout = c.timeout;
   P->randomization = c.randomization;
 
+  P->control_step = c.control_step;
+  P->slope_angle = c.slope_angle;
+  P->initial_state_variation = c.initial_state_variation;
+  P->negative_reward = c.negative_reward;
+  // CSWModel::setTiming (SWModel.cpp:126-130): whole microseconds, then the sub-step of singleStep (:151)
+  P->walker_dt = 1.0E-6 * (double)(uint64_t)floor((c.control_step + 0.5E-6) * 1E6) / c.integration_steps;
   P->end_stop_penalty = c.end_stop_penalty;
   P->action_penalty = c.action_penalty;
   P->action_min = c.action_min;
@@ -268,6 +275,11 @@ void grlx_config_pendulum_sarsa(grlx_config *c)
   c->max_rows = 256;
   c->tap_replica = -1;
   c->tap_capacity = 0;
+  c->end_stop_penalty = 1;
+  c->action_penalty = 0;
+  c->slope_angle = 0.004;
+  c->initial_state_variation = 0.2;
+  c->negative_reward = -100;
 }
 
 void grlx_config_cart_pole_ac(grlx_config *c)

@@ -76,6 +76,7 @@ struct DevParams {
   int32_t  ac_update_method;
   double   action_min, action_max;
   int32_t  end_stop_penalty, action_penalty;                   // task/cart_pole/swingup
+  double   control_step, slope_angle, initial_state_variation, negative_reward, walker_dt;   // compass walker
   uint32_t *trace_state;                                       // [replica][16 lanes][kMaxTrace][2]: pos, cnt | wt << 16
   // sparse tables: table t of replica r starts at tables + ((t*n_replicas + r) << logC)
   Entry   *tables;

@@ -562,6 +562,205 @@ template <> struct Env<GRLX_ENV_CART_POLE> {
   }
 };
 
+// model/compass_walker + task/compass_walker/walk: the simplest walking model with its own
+// RK4 (velocities and angles staged separately), angle wrapping and heel-strike events located
+// by a secant search (SWModel.cpp:15-258, SWModel.h:40-59, compass_walker.cpp:63-94, 251-344).
+// state vector (compass_walker.h:40-42).  parity unpinned by reference tests.
+template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
+  static constexpr int S = 11, D = 5;
+  static constexpr bool kCustomModel = true;
+  enum { SLA = 0, HA, SLAR, HAR, CHANGED, SFX, LASTHIPX, HIPVEL, STEPDIST, TIME, TIMEOUT };
+  struct St { double sla, slar, ha, har, sfx; };
+
+  __device__ static __forceinline__ double hip_x(const St &m) { return m.sfx - psin(m.sla); }
+  __device__ static __forceinline__ double swing_y(const St &m) { return pcos(m.sla) - pcos(m.sla - m.ha); }
+  __device__ static __forceinline__ void wrap(St &m)
+  { // SWModel.h:48-59
+    if (m.sla >= GRLX_PI) m.sla -= 2*GRLX_PI;
+    if (m.sla < -GRLX_PI) m.sla += 2*GRLX_PI;
+    if (m.ha >= GRLX_PI) m.ha -= 2*GRLX_PI;
+    if (m.ha < -GRLX_PI) m.ha += 2*GRLX_PI;
+  }
+  __device__ static __forceinline__ void accel(const DevParams &P, const St &m, double torque, double &asl, double &ahip)
+  { // SWModel.cpp:212-218
+    double sn, cs;
+    psincos(m.sla - P.slope_angle, sn, cs);
+    asl = sn;
+    ahip = psin(m.ha) * (m.slar*m.slar - cs) + asl;
+    ahip += torque;
+  }
+  __device__ static __noinline__ void rk4(const DevParams &P, St &state, double torque, double dt)
+  { // SWModel.cpp:220-258
+    St s1 = state, s2 = state, s3 = state, s4 = state;
+    double k1s, k1h, k2s, k2h, k3s, k3h, k4s, k4h;
+    accel(P, s1, torque, k1s, k1h);
+    s2.slar = s1.slar + (dt/2)*k1s;
+    s2.har  = s1.har  + (dt/2)*k1h;
+    s2.sla  = s1.sla  + (dt/2)*s1.slar;
+    s2.ha   = s1.ha   + (dt/2)*s1.har;
+    accel(P, s2, torque, k2s, k2h);
+    s3.slar = s1.slar + (dt/2)*k2s;
+    s3.har  = s1.har  + (dt/2)*k2h;
+    s3.sla  = s1.sla  + (dt/2)*s2.slar;
+    s3.ha   = s1.ha   + (dt/2)*s2.har;
+    accel(P, s3, torque, k3s, k3h);
+    s4.slar = s1.slar + (dt)*k3s;
+    s4.har  = s1.har  + (dt)*k3h;
+    s4.sla  = s1.sla  + (dt)*s3.slar;
+    s4.ha   = s1.ha   + (dt)*s3.har;
+    accel(P, s4, torque, k4s, k4h);
+    state.slar = s1.slar + (dt/6)*(k1s + 2*k2s + 2*k3s + k4s);
+    state.har  = s1.har  + (dt/6)*(k1h + 2*k2h + 2*k3h + k4h);
+    state.sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
+    state.ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
+  }
+  __device__ static __noinline__ double heelstrike_moment(const DevParams &P, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
+  { // SWModel.cpp:53-104
+    double timeLeft = 0;
+    St s0 = t0, s1 = t1;
+    double s0time = 0, s1time = dt;
+    const int maxIterations = 10;
+    int iIter;
+    for (iIter = 0; iIter < maxIterations; iIter++)
+    {
+      hs = s0;
+      const double y0 = swing_y(s0);
+      double newDt = (s1time - s0time) * y0 / (y0 - swing_y(s1));
+      rk4(P, hs, torque, newDt);
+      if (swing_y(hs) > 0)
+      {
+        s0 = hs;
+        s0time = s0time + newDt;
+      }
+      else
+      {
+        s1 = hs;
+        s1time = s0time + newDt;
+      }
+      if (swing_y(s0) < precision)
+      {
+        hs = s0;
+        timeLeft = dt - s0time;
+        break;
+      }
+      else if (-swing_y(s1) < precision)
+      {
+        hs = s1;
+        timeLeft = dt - s1time;
+        break;
+      }
+    }
+    if (iIter >= maxIterations)
+    {
+      if (swing_y(hs) > 0) timeLeft = dt - s0time;
+      else timeLeft = dt - s1time;
+    }
+    return timeLeft;
+  }
+  __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next)
+  { // CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210)
+    St st, prev, hs;
+    st.sfx = x[SFX]; st.sla = x[SLA]; st.slar = x[SLAR]; st.ha = x[HA]; st.har = x[HAR];
+    prev = st;
+    hs = st;
+    bool changed = false;
+    const double partial = P.walker_dt;
+    for (int i = 0; i < P.integration_steps; i++)
+    {
+      rk4(P, st, torque, partial);
+      wrap(st);
+      // detectEvents (SWModel.cpp:30-45)
+      double timeleft = 0;
+      if ((swing_y(prev) >= 0) && (swing_y(st) < 0))
+        if (((prev.ha < 0) && (st.ha < 0)) || ((prev.ha > 0) && (st.ha > 0)))
+          if ((st.slar < 0) && (st.ha < 0))
+          { // processStanceLegChange (:106-124)
+            timeleft = heelstrike_moment(P, prev, st, hs, torque, 1.0E-11, partial);
+            const double c2 = pcos(2.0*hs.sla);
+            st.har  = hs.slar*(c2*(1.0 - c2));
+            st.slar = hs.slar*(c2);
+            st.sfx  = hip_x(hs) + psin(hs.sla - hs.ha);
+            st.sla  = -hs.sla;
+            st.ha   = -2.0*hs.sla;
+          }
+      changed = changed || (timeleft > 0);
+      if (timeleft > 0)
+      {
+        rk4(P, st, torque, timeleft);
+        wrap(st);
+      }
+      prev = st;
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) next[i] = x[i];
+    next[SLA] = st.sla;
+    next[HA] = st.ha;
+    next[SLAR] = st.slar;
+    next[HAR] = st.har;
+    next[SFX] = st.sfx;
+    next[CHANGED] = changed ? 1. : 0.;
+    next[LASTHIPX] = changed ? hip_x(st) : x[LASTHIPX];
+    next[HIPVEL] = - st.slar * pcos(st.sla);
+    next[TIME] = x[TIME] + P.control_step;
+    next[TIMEOUT] = x[TIMEOUT];
+  }
+  __device__ static __forceinline__ void eom(const double *, double, double *) {}
+  __device__ static __forceinline__ void start(const DevParams &P, int test, uint64_t &, uint64_t &G, double *x)
+  { // compass_walker.cpp:251-290: rejection sampling on the GLOBAL drand48 stream
+    const double i_sla = 0.1534, i_slar = -0.1561, i_ha = 2.0*0.1534, i_har = -0.0073;
+    const double variation = (!test) ? P.initial_state_variation : 0;
+    const double cslope = pcos(P.slope_angle);
+    St sw;
+    sw.sfx = 0;
+    for (int guard = 0; guard < 100000; ++guard)
+    {
+      G = lcg_next(G); sw.sla  = i_sla  * (1.0 - variation + 2.0*variation*lcg_double(G));
+      G = lcg_next(G); sw.ha   = i_ha   * (1.0 - variation + 2.0*variation*lcg_double(G));
+      G = lcg_next(G); sw.slar = i_slar * (1.0 - variation + 2.0*variation*lcg_double(G));
+      G = lcg_next(G); sw.har  = i_har  * (1.0 - variation + 2.0*variation*lcg_double(G));
+      if (!(sw.slar*sw.slar/2.0 + pcos(sw.sla)*cslope < cslope)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = 0;
+    x[SLA] = sw.sla;
+    x[HA] = sw.ha;
+    x[SLAR] = sw.slar;
+    x[HAR] = sw.har;
+    x[SFX] = sw.sfx;
+    x[LASTHIPX] = hip_x(sw);
+    x[HIPVEL] = -sw.slar * pcos(sw.sla);
+    x[TIMEOUT] = test ? 2*P.timeout : P.timeout;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return a; }
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[SLA]) < 8. && __builtin_fabs(x[HA]) < 8. && __builtin_fabs(x[SLAR]) < 1e6; }
+  __device__ static __forceinline__ bool fallen(const double *x)
+  {
+    return __builtin_fabs(x[SLA]) > GRLX_PI/8 || __builtin_fabs(x[HA] - 2 * x[SLA]) > GRLX_PI/4;
+  }
+  __device__ static __forceinline__ int observe(const DevParams &, const double *x, double *obs)
+  { // :292-329, observe = [1,1,1,1,1,0,0], steps = 0
+    obs[0] = x[SLA];
+    obs[1] = x[HA] - 2 * x[SLA];
+    obs[2] = x[SLAR];
+    obs[3] = x[HAR] - 2 * x[SLAR];
+    obs[4] = x[CHANGED] > 0.5 ? 1. : 0.;
+    if (fallen(x)) return 2;
+    if (x[TIME] > x[TIMEOUT]) return 1;
+    return 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &P, const double *, double, const double *next)
+  { // :331-344
+    double reward = -1;
+    if (next[CHANGED] > 0.5) reward = fmin(50 * 4 * psin(next[SLA]), 30.);
+    if (fallen(next))
+      if (P.negative_reward != 0) reward = P.negative_reward;
+    return reward;
+  }
+};
+
+template <int ENV> struct HasCustomModel { static constexpr bool value = false; };
+template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bool value = true; };
+
 // DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps.
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
@@ -603,7 +802,10 @@ __device__ __forceinline__ void env_step(const DevParams &P, double *x, double a
 {
   constexpr int S = Env<ENV>::S;
   double next[S];
-  rk4_step<ENV>(P, x, Env<ENV>::actuate(action), next);
+  if constexpr (HasCustomModel<ENV>::value)
+    Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next);     // model/compass_walker integrates itself
+  else
+    rk4_step<ENV>(P, x, Env<ENV>::actuate(action), next);
   terminal = Env<ENV>::observe(P, next, obs);
   reward = Env<ENV>::evaluate(P, x, action, next);
   // the branch-free sin/cos need |angle| < 2^20; 2^19 at step ends leaves room for the stages
@@ -1735,6 +1937,7 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 5)
   GRLX_LAUNCH(GRLX_ENV_ACROBOT, 3)
   GRLX_LAUNCH(GRLX_ENV_CART_POLE, 3)
+  GRLX_LAUNCH(GRLX_ENV_COMPASS_WALKER, 3)
 #undef GRLX_LAUNCH
   return hipErrorInvalidValue;
 }
@@ -1798,6 +2001,10 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
       break;
     case GRLX_ENV_CART_POLE:
       hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_CART_POLE>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
+                         obs_dev, reward_dev, terminal_dev, err_dev);
+      break;
+    case GRLX_ENV_COMPASS_WALKER:
+      hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_COMPASS_WALKER>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
                          obs_dev, reward_dev, terminal_dev, err_dev);
       break;
     default:

@@ -142,12 +142,72 @@ struct CartPoleSwingupTask : Task {
 };
 GRLX_REGISTER(CartPoleSwingupTask)
 
-// model/dynamical (modeled.cpp:234-252)
-struct DynamicalModel : Configurable {
-  GRLX_TYPEINFO("model/dynamical")
+struct Model : Configurable {
   double control_step = 0.05;
   int integration_steps = 5;
+  virtual int env_id() const = 0;
+};
+
+// model/compass_walker (compass_walker.cpp:41-60), task/compass_walker/walk (:198-249)
+struct CompassWalkerModel : Model {
+  GRLX_TYPEINFO("model/compass_walker")
+  double slope_angle = 0.004;
+  int env_id() const override { return GRLX_ENV_COMPASS_WALKER; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("control_step", "Control step time", 0.2));
+    config->push_back(CRP("integration_steps", "Number of integration steps per control step", 20));
+    config->push_back(CRP("slope_angle", "Inclination of the slope", 0.004));
+  }
+  void configure(Configuration &config) override
+  {
+    control_step = config["control_step"]; integration_steps = config["integration_steps"]; slope_angle = config["slope_angle"];
+    if (!(control_step >= 0.001)) throw bad_param("model/compass_walker:control_step");
+    if (integration_steps < 1) throw bad_param("model/compass_walker:integration_steps");
+  }
+};
+GRLX_REGISTER(CompassWalkerModel)
+struct CompassWalkerWalkTask : Task {
+  GRLX_TYPEINFO("task/compass_walker/walk")
+  double initial_state_variation = 0.2, slope_angle = 0.004, negative_reward = -100;
+  int env_id() const override { return GRLX_ENV_COMPASS_WALKER; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("timeout", "Learning episode timeout", 100.));
+    config->push_back(CRP("initial_state_variation", "Variation of initial state", 0.2));
+    config->push_back(CRP("slope_angle", "Inclination of the slope", 0.004, CRP::System));
+    config->push_back(CRP("negative_reward", "Negative reward", -100.));
+    config->push_back(CRP("observe", "State elements observed by an agent", VecD{1, 1, 1, 1, 1, 0, 0}));
+    config->push_back(CRP("steps", "number of steps after which task is terminated", 0));
+    for (const char *n : {"observation_dims", "observation_min", "observation_max", "action_dims", "action_min", "action_max", "reward_min", "reward_max"})
+      config->push_back(CRP::provided(n, std::string("vector.") + n, "Task limits"));
+  }
+  void configure(Configuration &config) override
+  {
+    timeout = config["timeout"]; initial_state_variation = config["initial_state_variation"];
+    slope_angle = config["slope_angle"]; negative_reward = config["negative_reward"];
+    const VecD observe = config["observe"].v();
+    if (observe.size() != 7) throw bad_param("task/walk:observe");
+    if (observe != VecD{1, 1, 1, 1, 1, 0, 0}) throw Exception(path() + ": only the default observation mask [1,1,1,1,1,0,0] is on the accelerated path");
+    if ((int)config["steps"] != 0) throw Exception(path() + ": steps > 0 is outside the accelerated path");
+    if (negative_reward > 0) throw bad_param("task/compass_walker/walk:negative_reward");
+    config.set("observation_dims", 5);
+    config.set("observation_min", VecD{-kPi / 8, -kPi / 4, -kPi, -kPi, 0});
+    config.set("observation_max", VecD{kPi / 8, kPi / 4, kPi, kPi, 0.5});
+    config.set("action_dims", 1);
+    config.set("action_min", VecD{-1.2});
+    config.set("action_max", VecD{1.2});
+    config.set("reward_min", -101.);
+    config.set("reward_max", 50.);
+  }
+};
+GRLX_REGISTER(CompassWalkerWalkTask)
+
+// model/dynamical (modeled.cpp:234-252)
+struct DynamicalModel : Model {
+  GRLX_TYPEINFO("model/dynamical")
   Dynamics *dynamics = nullptr;
+  int env_id() const override { return dynamics ? dynamics->env_id() : -1; }
   void request(const std::string &, ConfigurationRequest *config) override
   {
     config->push_back(CRP("control_step", "Control step time", 0.05));
@@ -169,7 +229,7 @@ GRLX_REGISTER(DynamicalModel)
 // environment/modeled (modeled.cpp:35-119)
 struct ModeledEnvironment : Configurable {
   GRLX_TYPEINFO("environment/modeled")
-  DynamicalModel *model = nullptr;
+  Model *model = nullptr;
   Task *task = nullptr;
   int discrete_time = 1;
   void request(const std::string &, ConfigurationRequest *config) override
@@ -186,7 +246,7 @@ struct ModeledEnvironment : Configurable {
   }
   void configure(Configuration &config) override
   {
-    model = dynamic_cast<DynamicalModel *>(config["model"].ptr());
+    model = dynamic_cast<Model *>(config["model"].ptr());
     task = dynamic_cast<Task *>(config["task"].ptr());
     discrete_time = config["discrete_time"];
     if (!model || !task) throw Exception(path() + ": model/task outside the accelerated path");
@@ -194,7 +254,7 @@ struct ModeledEnvironment : Configurable {
       throw Exception(path() + ": window/stride/delta are not supported by the accelerated path");
     if (config["exporter"].ptr()) throw Exception(path() + ": exporters are not supported by the accelerated path");
     if (discrete_time != 1) throw Exception(path() + ": discrete_time must be 1 on the accelerated path");
-    if (model->dynamics->env_id() != task->env_id()) throw Exception(path() + ": task does not match dynamics");
+    if (model->env_id() != task->env_id()) throw Exception(path() + ": task does not match the model");
     // forward the task's provided parameters (modeled.cpp:79-114)
     Configurator *t = task->configurator;
     for (const char *n : {"observation_dims", "observation_min", "observation_max", "action_dims", "action_min", "action_max", "reward_min", "reward_max"})
@@ -580,7 +640,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
   void lower(grlx_config *c) const
   {
     grlx_config_pendulum_sarsa(c);
-    const DynamicalModel *m = environment->model;
+    const Model *m = environment->model;
     const Task *t = environment->task;
     c->test_interval = test_interval;
     c->env = t->env_id();
@@ -591,6 +651,12 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     c->randomization = t->randomization;
     if (const CartPoleSwingupTask *cp = dynamic_cast<const CartPoleSwingupTask *>(t))
     { c->end_stop_penalty = cp->end_stop_penalty; c->action_penalty = cp->action_penalty; }
+    if (const CompassWalkerWalkTask *w = dynamic_cast<const CompassWalkerWalkTask *>(t))
+    {
+      const CompassWalkerModel *wm = dynamic_cast<const CompassWalkerModel *>(m);
+      if (!wm || wm->slope_angle != w->slope_angle) throw Exception(w->path() + ": slope_angle must match model/compass_walker");
+      c->slope_angle = w->slope_angle; c->initial_state_variation = w->initial_state_variation; c->negative_reward = w->negative_reward;
+    }
 
     if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
     { // ---- actor-critic (cfg/cart_pole/ac_tc.yaml)

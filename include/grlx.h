@@ -102,6 +102,10 @@ typedef struct {
   int32_t  end_stop_penalty;
   int32_t  action_penalty;
   int32_t  reserved1;
+  /* model/compass_walker + task/compass_walker/walk (compass_walker.cpp:41-60, 198-249) */
+  double   slope_angle;               /* default 0.004 */
+  double   initial_state_variation;   /* default 0.2   */
+  double   negative_reward;           /* default -100  */
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;

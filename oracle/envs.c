@@ -6,11 +6,15 @@
  *   (no reference test pins the acrobot: parity unpinned by reference tests)
  * Cart-pole dynamics + swing-up task:        base/src/environments/cart_pole.cpp:58-237
  *   (the reference's cart-pole test yaml is stale: parity unpinned by reference tests)
+ * Compass walker model + walk task:          base/src/environments/compass_walker/SWModel.cpp:15-258,
+ *   base/include/grl/environments/compass_walker/SWModel.h:40-59, compass_walker.cpp:41-95, 198-344
+ *   (parity unpinned by reference tests)
  *
  * All arithmetic is IEEE double in the reference's expression order with no
  * fused multiply-add (compile with -ffp-contract=off).
  */
 #include <math.h>
+#include <stdint.h>
 #include <string.h>
 #include "oracle_internal.h"
 
@@ -35,6 +39,7 @@ int orc_env_state_dims(int env)
     case ORC_ENV_PENDULUM: return 3;
     case ORC_ENV_ACROBOT: return 5;
     case ORC_ENV_CART_POLE: return 5;
+    case ORC_ENV_COMPASS_WALKER: return 11;
     default: return -1;
   }
 }
@@ -46,6 +51,7 @@ int orc_env_obs_dims(int env)
     case ORC_ENV_PENDULUM: return 2;
     case ORC_ENV_ACROBOT: return 4;
     case ORC_ENV_CART_POLE: return 4;
+    case ORC_ENV_COMPASS_WALKER: return 5;
     default: return -1;
   }
 }
@@ -208,6 +214,224 @@ static double cart_pole_evaluate(const orc_spec *s, const double *x, double acti
   return cart_pole_potential(s, next) - s->action_penalty * orc_m_sqr(s, action / 15) * 2 - s->end_stop_penalty * cart_pole_failed(next) * 10000;
 }
 
+/* -------------------------------------------------------- compass walker -- */
+/* state vector (compass_walker.h:40-42): */
+enum { W_SLA = 0, W_HA, W_SLAR, W_HAR, W_CHANGED, W_SFX, W_LASTHIPX, W_HIPVEL, W_STEPDIST, W_TIME, W_TIMEOUT };
+
+typedef struct { double sla, slar, ha, har, sfx; int changed; } sw_state;    /* CSWModelState */
+typedef struct { double sl, hip; } sw_accels;
+
+static double sw_hip_x(const orc_spec *s, const sw_state *m) { return m->sfx - orc_m_sin(s, m->sla); }          /* SWModel.h:40 */
+static double sw_hip_y(const orc_spec *s, const sw_state *m) { return orc_m_cos(s, m->sla); }                   /* :41 */
+static double sw_swing_x(const orc_spec *s, const sw_state *m) { return sw_hip_x(s, m) + orc_m_sin(s, m->sla - m->ha); }   /* :42 */
+static double sw_swing_y(const orc_spec *s, const sw_state *m) { return sw_hip_y(s, m) - orc_m_cos(s, m->sla - m->ha); }   /* :43 */
+
+static void sw_wrap(sw_state *m)
+{ /* SWModel.h:48-59 */
+  if (m->sla >= M_PI) m->sla -= 2*M_PI;
+  if (m->sla < -M_PI) m->sla += 2*M_PI;
+  if (m->ha >= M_PI) m->ha -= 2*M_PI;
+  if (m->ha < -M_PI) m->ha += 2*M_PI;
+}
+
+static void sw_accel(const orc_spec *s, const sw_state *m, double torque, sw_accels *a)
+{ /* SWModel.cpp:212-218 */
+  a->sl = orc_m_sin(s, m->sla - s->slope_angle);
+  a->hip = orc_m_sin(s, m->ha) * (m->slar*m->slar - orc_m_cos(s, m->sla - s->slope_angle)) + a->sl;
+  a->hip += torque;
+}
+
+static void sw_rk4(const orc_spec *s, sw_state *state, double torque, double dt)
+{ /* SWModel.cpp:220-258 */
+  sw_state s1, s2, s3, s4;
+  sw_accels k1, k2, k3, k4;
+  s1 = *state;
+  sw_accel(s, &s1, torque, &k1);
+  s2 = s1; s3 = s1; s4 = s1;
+  s2.slar = s1.slar + (dt/2)*k1.sl;
+  s2.har  = s1.har  + (dt/2)*k1.hip;
+  s2.sla  = s1.sla  + (dt/2)*s1.slar;
+  s2.ha   = s1.ha   + (dt/2)*s1.har;
+  sw_accel(s, &s2, torque, &k2);
+  s3.slar = s1.slar + (dt/2)*k2.sl;
+  s3.har  = s1.har  + (dt/2)*k2.hip;
+  s3.sla  = s1.sla  + (dt/2)*s2.slar;
+  s3.ha   = s1.ha   + (dt/2)*s2.har;
+  sw_accel(s, &s3, torque, &k3);
+  s4.slar = s1.slar + (dt)*k3.sl;
+  s4.har  = s1.har  + (dt)*k3.hip;
+  s4.sla  = s1.sla  + (dt)*s3.slar;
+  s4.ha   = s1.ha   + (dt)*s3.har;
+  sw_accel(s, &s4, torque, &k4);
+  state->slar = s1.slar + (dt/6)*(k1.sl + 2*k2.sl + 2*k3.sl + k4.sl);
+  state->har  = s1.har  + (dt/6)*(k1.hip + 2*k2.hip + 2*k3.hip + k4.hip);
+  state->sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
+  state->ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
+}
+
+static double sw_heelstrike_moment(const orc_spec *s, const sw_state *t0, const sw_state *t1, sw_state *hs, double torque, double precision, double dt)
+{ /* SWModel.cpp:53-104: secant search for the moment the swing foot reaches the floor */
+  double timeLeft = 0;
+  sw_state s0 = *t0, s1 = *t1;
+  double s0time = 0, s1time = dt;
+  const int maxIterations = 10;
+  int iIter;
+  for (iIter = 0; iIter < maxIterations; iIter++)
+  {
+    *hs = s0;
+    double newDt = (s1time - s0time) * sw_swing_y(s, &s0) / (sw_swing_y(s, &s0) - sw_swing_y(s, &s1));
+    sw_rk4(s, hs, torque, newDt);
+    if (sw_swing_y(s, hs) > 0)
+    {
+      s0 = *hs;
+      s0time = s0time + newDt;
+    }
+    else
+    {
+      s1 = *hs;
+      s1time = s0time + newDt;
+    }
+    if (sw_swing_y(s, &s0) < precision)
+    {
+      *hs = s0;
+      timeLeft = dt - s0time;
+      break;
+    }
+    else if (-sw_swing_y(s, &s1) < precision)
+    {
+      *hs = s1;
+      timeLeft = dt - s1time;
+      break;
+    }
+  }
+  if (iIter >= maxIterations)
+  {
+    if (sw_swing_y(s, hs) > 0)
+      timeLeft = dt - s0time;
+    else
+      timeLeft = dt - s1time;
+  }
+  return timeLeft;
+}
+
+static double sw_detect_events(const orc_spec *s, const sw_state *t0, sw_state *hs, sw_state *t1, double torque, double dt)
+{ /* SWModel.cpp:30-45 and processStanceLegChange :106-124 */
+  if ((sw_swing_y(s, t0) >= 0) && (sw_swing_y(s, t1) < 0))
+    if (((t0->ha < 0) && (t1->ha < 0)) || ((t0->ha > 0) && (t1->ha > 0)))
+      if ((t1->slar < 0) && (t1->ha < 0))
+      {
+        double timeleft = sw_heelstrike_moment(s, t0, t1, hs, torque, 1.0E-11, dt);
+        t1->har  = hs->slar*(orc_m_cos(s, 2.0*hs->sla)*(1.0 - orc_m_cos(s, 2.0*hs->sla)));
+        t1->slar = hs->slar*(orc_m_cos(s, 2.0*hs->sla));
+        t1->sfx  = sw_swing_x(s, hs);
+        t1->sla  = -hs->sla;
+        t1->ha   = -2.0*hs->sla;
+        t1->changed = 1;
+        return timeleft;
+      }
+  t1->changed = 0;
+  return 0;
+}
+
+static void walker_model_step(const orc_spec *s, const double *x, double torque, double *next)
+{ /* CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210) */
+  sw_state st, prev, hs;
+  st.sfx = x[W_SFX]; st.sla = x[W_SLA]; st.slar = x[W_SLAR]; st.ha = x[W_HA]; st.har = x[W_HAR]; st.changed = 0;
+  prev = st;
+  hs = st;
+  int changed = 0;
+  /* setTiming (SWModel.cpp:126-130): step time in whole microseconds */
+  double steptime_us = (double)(uint64_t)floor((s->control_step + 0.5E-6)*1E6);
+  double partial = 1.0E-6*steptime_us/s->integration_steps;
+  for (int i = 0; i < s->integration_steps; i++)
+  {
+    sw_rk4(s, &st, torque, partial);
+    sw_wrap(&st);
+    double timeleft = sw_detect_events(s, &prev, &hs, &st, torque, partial);
+    changed |= (timeleft > 0);
+    if (timeleft > 0)
+    {
+      sw_rk4(s, &st, torque, timeleft);
+      sw_wrap(&st);
+    }
+    prev = st;
+  }
+  st.changed = changed;
+  for (int i = 0; i < 11; ++i) next[i] = x[i];
+  next[W_SLA] = st.sla;
+  next[W_HA] = st.ha;
+  next[W_SLAR] = st.slar;
+  next[W_HAR] = st.har;
+  next[W_SFX] = st.sfx;
+  next[W_CHANGED] = st.changed;
+  if (st.changed)
+    next[W_LASTHIPX] = sw_hip_x(s, &st);
+  else
+    next[W_LASTHIPX] = x[W_LASTHIPX];
+  next[W_HIPVEL] = - st.slar * orc_m_cos(s, st.sla);
+  next[W_TIME] = x[W_TIME] + s->control_step;
+  next[W_TIMEOUT] = x[W_TIMEOUT];
+  /* siStepDistance is never written by CompassWalkerModel::step (uninitialised in the reference); it is
+   * not observable with the walk task's default mask and is kept at its start value 0 here */
+}
+
+static void walker_start(const orc_spec *s, orc_exp *e, int test, double *x)
+{ /* CompassWalkerWalkTask::start (compass_walker.cpp:251-290): rejection sampling on the GLOBAL drand48 */
+  sw_state init, sw;
+  init.sfx = 0; init.sla = 0.1534; init.slar = -0.1561; init.ha = 2.0*0.1534; init.har = -0.0073; init.changed = 0;
+  sw = init;
+  sw.sfx = 0;
+  double variation = (!test) ? s->initial_state_variation : 0;
+  do
+  {
+    sw.sla  = init.sla  * (1.0 - variation + 2.0*variation*orc_drand48(&e->G));
+    sw.ha   = init.ha   * (1.0 - variation + 2.0*variation*orc_drand48(&e->G));
+    sw.slar = init.slar * (1.0 - variation + 2.0*variation*orc_drand48(&e->G));
+    sw.har  = init.har  * (1.0 - variation + 2.0*variation*orc_drand48(&e->G));
+  }
+  while (sw.slar*sw.slar/2.0 + sw_hip_y(s, &sw)*orc_m_cos(s, s->slope_angle) < orc_m_cos(s, s->slope_angle));
+  for (int i = 0; i < 11; ++i) x[i] = 0;
+  x[W_SLA] = sw.sla;
+  x[W_HA] = sw.ha;
+  x[W_SLAR] = sw.slar;
+  x[W_HAR] = sw.har;
+  x[W_SFX] = sw.sfx;
+  x[W_CHANGED] = 0;
+  x[W_LASTHIPX] = sw_hip_x(s, &sw);
+  x[W_HIPVEL] = -sw.slar * orc_m_cos(s, sw.sla);
+  x[W_STEPDIST] = 0;
+  x[W_TIME] = 0;
+  x[W_TIMEOUT] = test ? 2*s->timeout : s->timeout;
+}
+
+static int walker_fallen(const double *x)
+{
+  return fabs(x[W_SLA]) > M_PI/8 || fabs(x[W_HA] - 2 * x[W_SLA]) > M_PI/4;
+}
+
+static int walker_observe(const double *x, double *obs)
+{ /* compass_walker.cpp:292-329 with observe = [1,1,1,1,1,0,0], steps = 0 */
+  obs[0] = x[W_SLA];
+  obs[1] = x[W_HA] - 2 * x[W_SLA];
+  obs[2] = x[W_SLAR];
+  obs[3] = x[W_HAR] - 2 * x[W_SLAR];
+  obs[4] = x[W_CHANGED] > 0.5;
+  if (walker_fallen(x)) return 2;
+  if (x[W_TIME] > x[W_TIMEOUT]) return 1;
+  return 0;
+}
+
+static double walker_evaluate(const orc_spec *s, const double *next)
+{ /* compass_walker.cpp:331-344 */
+  double reward = -1;
+  if (next[W_CHANGED] > 0.5)
+    reward = fmin(50 * 4 * orc_m_sin(s, next[W_SLA]), 30);
+  if (walker_fallen(next))
+    if (s->negative_reward)
+      reward = s->negative_reward;
+  return reward;
+}
+
 /* ------------------------------------------------------ generic dispatch -- */
 static void env_eom(const orc_spec *s, const double *x, double u, double *xd)
 {
@@ -235,6 +459,7 @@ void orc_env_start(const orc_spec *s, orc_exp *e, int test, double *x)
     case ORC_ENV_PENDULUM: pendulum_start(s, e, test, x); break;
     case ORC_ENV_ACROBOT: acrobot_start(e, x); break;
     case ORC_ENV_CART_POLE: cart_pole_start(s, e, x); break;
+    case ORC_ENV_COMPASS_WALKER: walker_start(s, e, test, x); break;
   }
 }
 
@@ -245,6 +470,7 @@ int orc_env_observe(const orc_spec *s, const double *x, double *obs)
     case ORC_ENV_PENDULUM: return pendulum_observe(s, x, obs);
     case ORC_ENV_ACROBOT: return acrobot_observe(x, obs);
     case ORC_ENV_CART_POLE: return cart_pole_observe(s, x, obs);
+    case ORC_ENV_COMPASS_WALKER: return walker_observe(x, obs);
   }
   return 0;
 }
@@ -284,13 +510,17 @@ double orc_env_step(const orc_spec *s, double *state, double action,
   int S = orc_env_state_dims(s->env);
   double actuation = env_actuate(s, action);
 
-  rk4_step(s, state, actuation, next);
+  if (s->env == ORC_ENV_COMPASS_WALKER)
+    walker_model_step(s, state, actuation, next);        /* model/compass_walker has its own integrator */
+  else
+    rk4_step(s, state, actuation, next);
   *terminal = orc_env_observe(s, next, obs);
   switch (s->env)
   {
     case ORC_ENV_PENDULUM: *reward = pendulum_evaluate(s, state, action, next); break;
     case ORC_ENV_ACROBOT: *reward = !acrobot_failed(next); break;        /* acrobot.cpp:127-133 */
     case ORC_ENV_CART_POLE: *reward = cart_pole_evaluate(s, state, action, next); break;
+    case ORC_ENV_COMPASS_WALKER: *reward = walker_evaluate(s, next); break;
     default: *reward = 0;
   }
   memcpy(state, next, sizeof(double) * S);

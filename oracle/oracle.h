@@ -96,6 +96,9 @@ typedef struct {
   double randomization;
   int    end_stop_penalty;            /* task/cart_pole/swingup (class default 1; ac_tc.yaml: 0) */
   int    action_penalty;              /* task/cart_pole/swingup (default 0)                      */
+  double slope_angle;                 /* model/compass_walker, task/compass_walker/walk (0.004)   */
+  double initial_state_variation;     /* task/compass_walker/walk (0.2)                           */
+  double negative_reward;             /* task/compass_walker/walk (-100)                          */
   /* discretizer/uniform over the action (dims = 1 for all supported envs) */
   double action_min, action_max;
   int    action_steps;

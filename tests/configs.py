@@ -58,3 +58,22 @@ def cart_pole_ac(grlx, n, **over):
         if hasattr(spec, k) and k not in ("tap_replica", "tap_capacity"):
             setattr(spec, k, v)
     return cfg, spec
+
+
+def compass_walker(grlx, n, agent=1, **over):
+    """cfg/compass_walker/qlearning_walk.yaml: model/compass_walker + task/compass_walker/walk, Q-learning."""
+    res = [0.0838, 0.1047, 0.1111, 0.2222, 10, 1.2]
+    wrap = [0] * 6
+    cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over)
+    cfg.env = grlx.capi.ENV_COMPASS_WALKER
+    cfg.control_step, cfg.integration_steps, cfg.timeout = 0.2, 20, 100.0
+    cfg.slope_angle, cfg.initial_state_variation, cfg.negative_reward = 0.004, 0.2, -100.0
+    cfg.action_min, cfg.action_max, cfg.action_steps = -1.2, 1.2, 3
+    _set_tile(cfg.projector, 16, 8388608, res, wrap)
+    spec = ob.pendulum_sarsa_spec(agent=agent)
+    spec.env = 3
+    spec.control_step, spec.integration_steps, spec.timeout = 0.2, 20, 100.0
+    spec.slope_angle, spec.initial_state_variation, spec.negative_reward = 0.004, 0.2, -100.0
+    spec.action_min, spec.action_max, spec.action_steps = -1.2, 1.2, 3
+    _set_tile(spec.projector, 16, 8388608, res, wrap)
+    return cfg, spec

@@ -34,6 +34,7 @@ class Spec(C.Structure):
     _fields_ = [("test_interval", C.c_int), ("env", C.c_int), ("control_step", C.c_double),
                 ("integration_steps", C.c_int), ("timeout", C.c_double), ("randomization", C.c_double),
                 ("end_stop_penalty", C.c_int), ("action_penalty", C.c_int),
+                ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
                 ("action_min", C.c_double), ("action_max", C.c_double), ("action_steps", C.c_int),
                 ("agent", C.c_int), ("projector", TileSpec), ("representation", LinearSpec),
                 ("epsilon", C.c_double), ("decay_rate", C.c_double), ("decay_min", C.c_double),

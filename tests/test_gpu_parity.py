@@ -457,3 +457,57 @@ def test_deployer_actor_critic_rows_equal_oracle(grlx, tmp_path):
     e = ob.Experiment(spec, seed=31)
     rows, _ = e.run(24)
     assert (tmp_path / "cart_pole-ac-tc-0.txt").read_text() == e.format_rows(rows)
+
+
+# -------------------------------------------------------- compass walker ---
+def test_walker_env_step_bit_exact(grlx):
+    """model/compass_walker has its own RK4, angle wrapping and a secant search for the heel
+    strike (SWModel.cpp); follow real gaits so that strikes and falls occur."""
+    from tests import configs
+    cfg, spec = configs.compass_walker(grlx, 1)
+    rng = np.random.default_rng(23)
+    n = 3000
+    base = np.array([0.1534, 2.0 * 0.1534, -0.1561, -0.0073])
+    state = np.zeros((n, 11))
+    state[:, :4] = base * (1 + rng.uniform(-0.2, 0.2, (n, 4)))
+    state[:, 6] = -np.sin(state[:, 0])
+    state[:, 10] = 100.0
+    strikes = falls = 0
+    for it in range(12):
+        action = rng.choice([-1.2, 0.0, 1.2], n)
+        gs, gobs, grew, gterm = grlx.runner.env_step(cfg, state, action)
+        os_, oobs, orew, oterm = ob.env_step(spec, state, action)
+        assert_bit_equal(gs, os_, f"state it {it}"); assert_bit_equal(gobs, oobs, "obs"); assert_bit_equal(grew, orew, "reward")
+        assert (gterm == oterm).all()
+        strikes += int((gobs[:, 4] > 0.5).sum()); falls += int((gterm == 2).sum())
+        state = gs
+    assert strikes > 50 and falls > 100
+
+
+@pytest.mark.parametrize("agent", [1, 0])
+def test_walker_fused_bit_exact(grlx, agent):
+    """qlearning_walk.yaml semantics: starts drawn by rejection from the GLOBAL drand48 stream,
+    absorbing falls, doubled timeout in test trials."""
+    from tests import configs
+    seeds = [41, 42, 43, 44, 45]
+    trials, cap = 33, 12000
+    cfg, spec = configs.compass_walker(grlx, len(seeds), agent=agent, tap_replica=2, tap_capacity=cap)
+    r = grlx.Runner(cfg, seeds)
+    r.run(13); r.run(20); r.sync()
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, otaps = e.run(trials, tap_cap=cap)
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3]
+        assert_bit_equal(r.env_state(k), e.state(), "env state")
+        if k == 2:
+            gtaps = r.taps()
+            assert len(gtaps) == len(otaps) and len(otaps) > 200
+            for i, (gt, ot) in enumerate(zip(gtaps, otaps)):
+                try:
+                    _compare_taps(gt, ot, D=5)
+                except AssertionError as ex:
+                    raise AssertionError(f"step {i}: {ex}")
+    r.close()
