@@ -33,7 +33,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the HIP extension")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("GRLX_EXTRA_FLAGS", "").split()       # experiments only; the default build uses FLAGS
+    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

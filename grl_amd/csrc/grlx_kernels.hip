@@ -81,11 +81,42 @@ __device__ inline uint64_t lcg_jump(uint64_t x, uint64_t n)
   return x;
 }
 
+// the same jump with the table staged in LDS (rollout kernels: slot creation is frequent early in
+// learning and the table's eight loads are the latency of lazy_weight)
+__device__ __forceinline__ void jump_table_to_lds(uint64_t *sh_jump)
+{
+  const uint64_t *src = reinterpret_cast<const uint64_t *>(&d_jump);
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh_jump[i] = src[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ uint64_t lcg_jump_lds(const uint64_t *sh_jump, uint64_t x, uint64_t n)
+{
+  uint64_t a[4], c[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+  {
+    const uint32_t b = (uint32_t)(n >> (8 * w)) & 0xFFu;
+    a[w] = sh_jump[w * 256 + b];
+    c[w] = sh_jump[1024 + w * 256 + b];
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) x = (a[w] * x + c[w]) & kMask48;
+  if (n >> 32) x = lcg_step_pow2(x, (n >> 32) << 32);
+  return x;
+}
+
 // value the reference's dense initialisation gives `slot` (linear.cpp:117-120:
 // params_[ii] = rand->getUniform(init_min, init_max) in index order)
 __device__ inline double lazy_weight(uint64_t tl0, const LinearParams &lp, uint32_t slot)
 {
   uint64_t x = lcg_next(lcg_jump(tl0, lp.draws_before + (uint64_t)slot));
+  return lp.init_min + lcg_double(x) * lp.init_range;
+}
+
+__device__ __forceinline__ double lazy_weight_lds(const uint64_t *sh_jump, uint64_t tl0, const LinearParams &lp, uint32_t slot)
+{
+  uint64_t x = lcg_next(lcg_jump_lds(sh_jump, tl0, lp.draws_before + (uint64_t)slot));
   return lp.init_min + lcg_double(x) * lp.init_range;
 }
 
@@ -1126,7 +1157,8 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
 template <int NP, typename OnShare>
 __device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
                                           uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
-                                          uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, uint32_t &status, uint32_t &inserted, OnShare on_share)
+                                          uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
+                                          uint32_t &status, uint32_t &inserted, OnShare on_share)
 {
   const int lane = threadIdx.x & 63;
   Lookup lk[NP];
@@ -1142,14 +1174,16 @@ __device__ __forceinline__ void table_get(const Table &tab, const LinearParams &
     // state) or a bucket with too few empty ways fall back to the serialised path.
     double w0[NP];
     bool slow[NP];
+    uint32_t claims[NP];                                  // lanes of my group that claim a bucket, per index
 #pragma unroll
     for (int a = 0; a < NP; ++a)
     {
       sh_mb[g * (NP * 16) + a * 16 + j] = lk[a].miss ? lk[a].bucket : 0xFFFFFFFFu;
       sh_ms[g * (NP * 16) + a * 16 + j] = slot[a];
+      claims[a] = (uint32_t)((__ballot(lk[a].miss) >> (16 * g)) & 0xFFFFull);
       w0[a] = 0;
       slow[a] = false;
-      if (lk[a].miss) w0[a] = lazy_weight(tl0, lp, slot[a]);
+      if (lk[a].miss) w0[a] = lazy_weight_lds(sh_jump, tl0, lp, slot[a]);
     }
     wave_sync();
 #pragma unroll
@@ -1159,15 +1193,18 @@ __device__ __forceinline__ void table_get(const Table &tab, const LinearParams &
         const int me = a * 16 + j;
         uint32_t rank = 0;
         bool dup = false;
-        for (int k = 0; k < NP * 16; ++k)
-        {
-          const uint32_t ob = sh_mb[g * (NP * 16) + k], os = sh_ms[g * (NP * 16) + k];
-          if (ob == lk[a].bucket && k != me)
-          {
-            if (os == slot[a]) dup = true;
-            else if (k < me) rank++;
+#pragma unroll
+        for (int a2 = 0; a2 < NP; ++a2)
+          for (uint32_t mm = claims[a2]; mm != 0u; mm &= mm - 1u)
+          { // only the (index, tiling) pairs that actually claim something
+            const int k = a2 * 16 + __builtin_ctz(mm);
+            const uint32_t ob = sh_mb[g * (NP * 16) + k], os = sh_ms[g * (NP * 16) + k];
+            if (ob == lk[a].bucket && k != me)
+            {
+              if (os == slot[a]) dup = true;
+              else if (k < me) rank++;
+            }
           }
-        }
         uint32_t e = lk[a].empty;
         for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;      // drop the ways taken by earlier claimants
         if (dup || e == 0u)
@@ -1268,6 +1305,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   __shared__ uint32_t sh_mb[4 * NA * 16];      // parallel insert: claimed bucket per (action, tiling), ~0 = none
   __shared__ uint32_t sh_ms[4 * NA * 16];      //                  and the slot claiming it
   __shared__ uint32_t sh_mail[4];              // position of a slot that just became shared between tilings
+  __shared__ uint64_t sh_jump[2048];           // LCG jump table (lazy weight initialisation)
+  jump_table_to_lds(sh_jump);
 
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
@@ -1377,7 +1416,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (has_next)
         {
           bool shared_event = false;
-          table_get<NA>(tab, P.lin, TL0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, status, inserted,
+          table_get<NA>(tab, P.lin, TL0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
                         [&](uint32_t mp) {
                           trace_share_event(tr, tab, mp);
                           if (p_pos == mp) p_sh = true;
@@ -1607,6 +1646,8 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
   __shared__ uint32_t sh_mb[4 * 16];
   __shared__ uint32_t sh_ms[4 * 16];
   __shared__ uint32_t sh_mail[4];
+  __shared__ uint64_t sh_jump[2048];
+  jump_table_to_lds(sh_jump);
 
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
@@ -1708,13 +1749,13 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         }
         if (has_next)
         {
-          table_get<1>(tabA, P.lin_actor, TL0, slotA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, status, ins_a,
+          table_get<1>(tabA, P.lin_actor, TL0, slotA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
                        [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
         }
         if (need_critic)
         {
           bool shared_event = false;
-          table_get<1>(tabC, P.lin, TL0, slotC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, status, ins_c,
+          table_get<1>(tabC, P.lin, TL0, slotC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
                        [&](uint32_t mp) {
                          trace_share_event(tr, tabC, mp);
                          if (p_pos == mp) p_sh = true;
