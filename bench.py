@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-log2", type=int, default=17)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,8 +78,8 @@ def main():
     import grl_amd
     from grl_amd import parallel
 
-    torch.cuda.set_device(local_rank)
-    parallel.init_distributed("nccl")
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    parallel.init_distributed(args.backend)
 
     n = args.replicas
     total_steps = args.steps + args.warmup

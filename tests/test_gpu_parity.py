@@ -511,3 +511,62 @@ def test_walker_fused_bit_exact(grlx, agent):
                 except AssertionError as ex:
                     raise AssertionError(f"step {i}: {ex}")
     r.close()
+
+
+def test_bench_two_ranks_share_the_replica_range(grlx):
+    """bench.py launched as the driver launches it (torch.distributed.run, one process per rank);
+    on this one-GPU box both ranks use the same device and gloo stands in for RCCL."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--replicas", "256", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["env_steps_per_step"] == 2 * 256 * 1100
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+# ------------------------------------------------ BASELINE.json full sizes ---
+def _check_sampled_replicas(grlx, r, spec, seeds, sample, trials):
+    for k in sample:
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+
+
+@pytest.mark.parametrize("name,n,trials", [("pendulum", 4096, 44), ("cart_pole_ac", 16384, 22), ("compass_walker", 8192, 22), ("acrobot", 8192, 33)])
+def test_full_size_batches(grlx, name, n, trials):
+    """The replica counts BASELINE.json quotes (configs[1..3], per-GPU share of configs[3]): replicas are
+    independent, so ANY replica of the big batch must equal the scalar oracle run with its seed
+    (first, last, and some in between), and no replica may raise a status flag."""
+    from tests import configs
+    make = {"pendulum": configs.pendulum, "cart_pole_ac": configs.cart_pole_ac, "compass_walker": configs.compass_walker,
+            "acrobot": configs.acrobot}[name]
+    cfg, spec = make(grlx, n)
+    seeds = np.arange(1, n + 1)
+    r = grlx.Runner(cfg, seeds)
+    r.run(trials // 2); r.run(trials - trials // 2)
+    r.sync()                                                   # raises if any replica flagged an error
+    learn, test = r.step_counts()
+    assert learn > 0 and test > 0
+    _check_sampled_replicas(grlx, r, spec, seeds, [0, 1, n // 3, n - 2, n - 1], trials)
+    # the device-side curve statistics see every replica exactly once
+    torch = pytest.importorskip("torch")
+    rows = r.n_rows()
+    out = torch.zeros((rows, 3), dtype=torch.float64, device="cuda")
+    r.curve_stats(out.data_ptr(), 0, rows, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (out[:, 2].cpu().numpy() == n).all()
+    assert np.isfinite(out.cpu().numpy()).all()
+    r.close()
