@@ -36,6 +36,19 @@ BYTES_PER_TEST_STEP = 384                 # A*T 8-byte reads
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 
+def measured_traffic(n_replicas: int):
+    """HBM-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
+    inside this process); only valid for the configuration it was measured on, else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        if t.get("replicas") == n_replicas and t.get("trials_per_launch") == TRIALS_PER_STEP:
+            return float(t["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(budget_s: float = 12.0):
     """The oracle (validated against the reference's golden curve) on ONE host core:
     replica seed 1, the same trial mix, for about `budget_s` seconds of CPU work."""
@@ -146,7 +159,7 @@ def main():
                        "replicas_per_gpu": n, "trials_per_step": TRIALS_PER_STEP, "env_steps_per_step": env_steps_per_step * world,
                        "tilings": 16, "memory": 8388608, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "kernel": "rollout_kernel<pendulum,3>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
