@@ -880,12 +880,22 @@ __device__ __forceinline__ int tie_break(const double (&v)[NA], double best, int
   return res;
 }
 
+__device__ __forceinline__ double   in_reg(double v)   { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t in_reg(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ bool     in_reg(bool v)     { uint32_t t = v ? 1u : 0u; asm volatile("" : "+v"(t)); return t != 0u; }
+
+// arr[idx] for a register array: every candidate is pinned in a register first, otherwise the
+// compiler rewrites the select chain as a dynamically indexed load from a stack copy (scratch memory)
 template <typename Tv, int NA>
 __device__ __forceinline__ Tv pick(const Tv (&arr)[NA], int idx)
 {
-  Tv v = arr[0];
+  Tv v = in_reg(arr[0]);
 #pragma unroll
-  for (int a = 1; a < NA; ++a) v = (a == idx) ? arr[a] : v;
+  for (int a = 1; a < NA; ++a)
+  {
+    const Tv c = in_reg(arr[a]);
+    v = (a == idx) ? c : v;
+  }
   return v;
 }
 
@@ -1222,7 +1232,16 @@ __device__ __forceinline__ void table_get(const Table &tab, const LinearParams &
 #pragma unroll
     for (int a = 0; a < NP; ++a)
       if (__any(slow[a]))
-        table_insert_serial(tab, slow[a], slot[a], (uint32_t)j, w0[a], lk[a], w[a], status, inserted);
+      { // out-of-line and rare: work on copies so that nothing of the hot path has its address taken
+        Lookup tmp = lk[a];
+        double tv = w[a];
+        uint32_t tst = 0, tins = 0;
+        table_insert_serial(tab, slow[a], slot[a], (uint32_t)j, w0[a], tmp, tv, tst, tins);
+        lk[a] = tmp;
+        w[a] = tv;
+        status |= tst;
+        inserted += tins;
+      }
   }
 
   // ---- slots shared between tilings (a collision of the reference's hash across tilings,
