@@ -599,6 +599,17 @@ int grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slot
   return GRLX_OK;
 }
 
+int grlx_export_weights(grlx_ctx *ctx, int table, int replica, double *out)
+{
+  if (!ctx || !out || table < 0 || table >= ctx->n_tables || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  const size_t memory = (size_t)(table == 1 ? ctx->P.tile_actor.memory : ctx->P.tile.memory);
+  DevBuf dout;
+  HIP_TRY(dout.alloc(sizeof(double) * memory));
+  HIP_TRY(launch_export_weights(ctx->P, table, replica, dout.as<double>(), nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * memory, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
 int grlx_project(const grlx_tile_spec *spec, const double *in, int n, uint32_t *out)
 {
   if (!spec || !in || !out || n < 0) return fail(GRLX_ERR_INVALID, "bad argument");

@@ -103,6 +103,7 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);
 hipError_t launch_table_op(const DevParams &P, int table, int op, const int32_t *replica_dev, const uint32_t *idx_dev, int n,
                            const double *arg_dev, double alpha, double *out_dev, hipStream_t stream);
+hipError_t launch_export_weights(const DevParams &P, int table, int replica, double *out_dev, hipStream_t stream);
 hipError_t launch_get_weights(const DevParams &P, int table, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
 hipError_t launch_math(int op, const double *x, const double *y, int n, double *out, hipStream_t stream);
 hipError_t launch_rand48_at(uint64_t x0, const uint64_t *skip, int n, double *out, hipStream_t stream);

@@ -997,9 +997,28 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   const uint32_t shmask = (uint32_t)((__ballot(p_sh) >> (16 * g)) & 0xFFFFull);
   uint32_t cp = 1;                                     // occurrences of my slot inside p
   double v;                                            // final weight of p's slot after this step
-  if (!__any(shmask != 0u || tr.dup))
-  { // ---- common case (no lane of the wave has a shared p, no slot occurs twice): aliasing
-    // is a register compare inside the lane; straight-line code, no exec-mask branches
+  uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
+#pragma unroll
+  for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
+  bool cross = tr.dup;                                 // does this lane see an alias that crosses lanes?
+  if (__any(shmask != 0u))
+  { // some lane's p is a shared slot: compare those few positions (usually one) with my trace and my p
+    for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
+    {
+      const int k = __builtin_ctz(mm);
+      const uint32_t ppk = sh_ppos[g * 16 + k];
+      if (k != j)
+      {
+        if (ppk == p_pos) { cp++; cross = true; }
+#pragma unroll
+        for (int e = 0; e < kMaxTrace; ++e)
+          if (e < tr.len && tr.pos[e] == ppk) { xm[e] |= 1u << k; cross = true; }
+      }
+    }
+  }
+  if (!__any(cross))
+  { // ---- common case: no alias crosses lanes in this wave; aliasing is a register compare inside
+    // the lane; straight-line code, no exec-mask branches
     double a_val = 0, a_de = 0;
     bool aliased = false, a_upd = false;
     uint32_t stmask = 0;
@@ -1041,21 +1060,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
     }
   }
   else
-  { // ---- general case
-    uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
-#pragma unroll
-    for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
-    for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
-    {
-      const int k = __builtin_ctz(mm);
-      const uint32_t ppk = sh_ppos[g * 16 + k];
-      if (k != j)
-      {
-        if (ppk == p_pos) cp++;
-#pragma unroll
-        for (int e = 0; e < kMaxTrace; ++e) xm[e] |= (tr.pos[e] == ppk) ? (1u << k) : 0u;
-      }
-    }
+  { // ---- general case: some alias crosses lanes (a slot shared between tilings is involved)
     double v_alias = 0;
     bool aliased = false;
     if (u.use_trace)
@@ -2158,6 +2163,38 @@ __global__ void get_weights_kernel(DevParams P, int table, int replica, const ui
     b = (b + 1u) & tab.bmask;
   }
   out[i] = v;
+}
+
+// dense export of a table: out[slot] for every reference slot (grid-stride)
+__global__ void export_weights_kernel(DevParams P, int table, int replica, double *out)
+{
+  const Table tab = table_of(P, table, replica);
+  const LinearParams &lp = table == 1 ? P.lin_actor : P.lin;
+  const uint32_t memory = (uint32_t)(table == 1 ? P.tile_actor.memory : P.tile.memory);
+  const uint64_t tl0 = P.states[replica].TL0;
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < memory; slot += gridDim.x * blockDim.x)
+  {
+    uint32_t b = table_home(tab, slot);
+    double v = 0;
+    bool found = false;
+    for (int it = 0; it < kMaxProbe; ++it)
+    {
+      const BucketRegs br = bucket_load(tab, b);
+      uint32_t empty;
+      const int way = bucket_find(br.k, slot, empty);
+      if (way >= 0) { v = (way == 0) ? br.v[0] : (way == 1) ? br.v[1] : (way == 2) ? br.v[2] : br.v[3]; found = true; break; }
+      if (empty != 0u) break;
+      b = (b + 1u) & tab.bmask;
+    }
+    if (!found) v = lazy_weight(tl0, lp, slot);
+    out[slot] = v;
+  }
+}
+
+hipError_t launch_export_weights(const DevParams &P, int table, int replica, double *out_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(export_weights_kernel, dim3(2048), dim3(256), 0, stream, P, table, replica, out_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_get_weights(const DevParams &P, int table, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream)

@@ -3,6 +3,7 @@
 // conditions; `experiment/online_learning` lowers the instantiated graph to a grlx_config
 // and runs it on the GPU through the C ABI (include/grlx.h).  Nothing here computes the
 // algorithm on the CPU: a graph the fused kernels do not implement is refused.
+#include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -610,8 +611,10 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     if (test_interval >= 0 && !config["test_agent"].ptr()) throw bad_param("experiment/online_learning:test_agent");   // :100-101
     if (!environment || !agent || (config["test_agent"].ptr() && !test_agent))
       throw Exception(path() + ": the accelerated path needs environment/modeled, agent/td and agent/fixed");
-    if (config["exporter"].ptr() || !load_file.empty() || save_every != "never" || (int)config["rate"] != 0 || test_trials != 1 || steps != 0)
-      throw Exception(path() + ": exporter/load_file/save_every/rate/test_trials/steps are outside the accelerated path");
+    if (save_every != "never" && save_every != "run")
+      throw Exception(path() + ": save_every must be never or run on the accelerated path (test/trial would stop the device every episode)");
+    if (config["exporter"].ptr() || !load_file.empty() || (int)config["rate"] != 0 || test_trials != 1 || steps != 0)
+      throw Exception(path() + ": exporter/load_file/rate/test_trials/steps are outside the accelerated path (a dense 64 MiB policy cannot be loaded into the sparse tables)");
   }
 
   // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernels make is checked
@@ -771,6 +774,32 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
           if (i == 0 && opt.print_rows) std::cout << oss.str() << std::endl;
         }
         if (i == 0) curve = reward;
+      }
+      // Save policy every run (online_learning.cpp:294-302 -> ParameterizedRepresentation {action: save},
+      // representation.h:201-229): raw double[memory] to <output>-run<rr>-<config path with '/'->'_'>.dat
+      if (save_every == "run" && !output.empty())
+      {
+        std::vector<const Configurable *> reprs;          // table 0 = Q / critic, table 1 = actor
+        if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
+        { reprs.push_back(ac->critic->representation); reprs.push_back(ac->representation); }
+        else
+          reprs.push_back(dynamic_cast<const QPolicy *>(agent->policy)->representation);
+        for (size_t tb = 0; tb < reprs.size(); ++tb)
+          for (int i = 0; i < opt.replicas; ++i)
+          {
+            const int memory = tb == 1 ? c.actor_projector.memory : c.projector.memory;
+            std::vector<double> dense((size_t)memory);
+            if (grlx_export_weights(ctx, (int)tb, i, dense.data()) != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
+            std::string cfg_path = reprs[tb]->path();
+            std::replace(cfg_path.begin(), cfg_path.end(), '/', '_');
+            std::ostringstream name;
+            name << output << "-run" << rr;
+            if (opt.replicas > 1) name << "@" << i;
+            name << "-" << cfg_path << ".dat";
+            std::ofstream f(name.str(), std::ios::binary);
+            if (!f) { log(1, "Could not open '" + name.str() + "' for writing"); continue; }
+            f.write(reinterpret_cast<const char *>(dense.data()), (std::streamsize)(dense.size() * sizeof(double)));
+          }
       }
       uint64_t learn = 0, test = 0;
       grlx_step_counts(ctx, &learn, &test);

@@ -117,6 +117,13 @@ class Runner:
         capi.check(self.lib.grlx_get_weights(self._ctx, table, replica, _ptr(slots, C.c_uint32), slots.size, _ptr(out, C.c_double)))
         return out
 
+    def export_weights(self, replica: int, table: int = 0):
+        """Dense double[memory] parameter vector, as grl's .dat files hold it (representation.h:201-229)."""
+        t = self.cfg.actor_projector if table == 1 else self.cfg.projector
+        out = np.zeros(t.memory, np.float64)
+        capi.check(self.lib.grlx_export_weights(self._ctx, table, replica, _ptr(out, C.c_double)))
+        return out
+
     def table_load(self, replica: int, table: int = 0) -> int:
         n = C.c_uint32()
         capi.check(self.lib.grlx_table_load(self._ctx, table, replica, C.byref(n)))

@@ -171,6 +171,10 @@ int  grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4] /* G, TL, S1, S2 *
  * representation.h:201-263): current weights of the given reference slots. */
 int  grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out);
 int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used);
+/* Replaces ParameterizedRepresentation's {action: save} (representation.h:201-229): the DENSE
+ * parameter vector double[memory] of one replica's table, little-endian as grl's .dat files hold it
+ * (untouched slots carry their lazily computed initial value).  out: host buffer of `memory` doubles. */
+int  grlx_export_weights(grlx_ctx *ctx, int table, int replica, double *out);
 int  grlx_read_taps(grlx_ctx *ctx, grlx_tap *out, int cap, int *n);
 
 /* --- fine-grained batched operators (host pointers; each call copies in, runs a

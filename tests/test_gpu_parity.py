@@ -570,3 +570,23 @@ def test_full_size_batches(grlx, name, n, trials):
     assert (out[:, 2].cpu().numpy() == n).all()
     assert np.isfinite(out.cpu().numpy()).all()
     r.close()
+
+
+def test_dat_policy_export_matches_dense_table(grlx, tmp_path):
+    """save_every: run writes grl's raw .dat parameter files (representation.h:201-229): 8,388,608 doubles
+    that must equal the oracle's dense table bit for bit -- the file a real grl build could load."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    y = tmp_path / "save.yaml"
+    y.write_text(text.replace("save_every: never", "save_every: run").replace("trials: 2000", "trials: 33"))
+    res = subprocess.run([grlxd, "-s", "7", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    f = tmp_path / "pendulum-sarsa-tc-run0-experiment_agent_policy_representation.dat"
+    got = np.fromfile(f, dtype="<f8")
+    e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=7)
+    e.run(33)
+    dense = np.ctypeslib.as_array(e.L.orc_weights(e.h, 0), shape=(8388608,))
+    assert got.shape == (8388608,)
+    assert_bit_equal(got, dense, ".dat parameters")
