@@ -13,7 +13,7 @@ MAX_DIMS, MAX_STATE, MAX_ACTIONS = 8, 12, 8
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TABLE_FULL, ERR_DOMAIN, ERR_ROWS_FULL, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7
 ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER = 0, 1, 2, 3
-AGENT_SARSA, AGENT_Q, AGENT_AC = 0, 1, 2
+AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA = 0, 1, 2, 3
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
 

@@ -112,7 +112,7 @@ int make_params(const grlx_config &c, DevParams *P)
   if (c.struct_size != sizeof(grlx_config)) return fail(GRLX_ERR_INVALID, "grlx_config.struct_size %u != %zu (ABI mismatch)", c.struct_size, sizeof(grlx_config));
   int S, D;
   if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
-  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC && c.agent != GRLX_AGENT_EXPECTED_SARSA) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
   const bool ac = c.agent == GRLX_AGENT_AC;
   if (ac && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
   if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");

@@ -1488,10 +1488,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
         // -------- sampler (greedy.cpp:63-86, 144-218)
         int a_next = 0;
+        int mai = 0, man = 1;
+        double best = 0;
         if (has_next)
         {
-          int mai, man;
-          double best;
           findmax<NA>(q, mai, man, best);
           if (test)
           {
@@ -1522,6 +1522,20 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           {
             if (P.agent == GRLX_AGENT_SARSA)
               target += P.gamma * pick<double, NA>(q, a_next);
+            else if (P.agent == GRLX_AGENT_EXPECTED_SARSA)
+            { // QPolicy::value (q.cpp:60-73) = sum_a Q(s',a) * EpsilonGreedySampler::distribution (greedy.cpp:220-238)
+              const double de = eps_decay * P.epsilon;
+              double v = 0;
+#pragma unroll
+              for (int kk = 0; kk < NA; ++kk)
+              {
+                double d = (q[kk] == best) ? 1. / man : 0.;
+                if (d == 1) d = 1 - de;
+                d += de / NA;
+                v += q[kk] * d;
+              }
+              target += P.gamma * v;
+            }
             else
             {
               double v = -__builtin_inf();

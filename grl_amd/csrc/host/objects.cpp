@@ -481,6 +481,23 @@ struct SARSAPredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/sarsa"
 GRLX_REGISTER(SARSAPredictor)
 struct QPredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/q") int agent_id() const override { return GRLX_AGENT_Q; } };
 GRLX_REGISTER(QPredictor)
+// predictor/critic/expected_sarsa (sarsa.cpp:134-165): the target policy must be the learning policy
+struct ExpectedSARSAPredictor : TDPredictorBase {
+  GRLX_TYPEINFO("predictor/critic/expected_sarsa")
+  Configurable *target_policy = nullptr;
+  int agent_id() const override { return GRLX_AGENT_EXPECTED_SARSA; }
+  void request(const std::string &role, ConfigurationRequest *config) override
+  {
+    TDPredictorBase::request(role, config);
+    config->push_back(CRP("policy", "mapping/policy/discrete/value", "Value based target policy", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    TDPredictorBase::configure(config);
+    target_policy = config["policy"].ptr();
+  }
+};
+GRLX_REGISTER(ExpectedSARSAPredictor)
 // names from before the reference's predictor/critic/* rename, still used by its tests/pendulum-sarsa-tc.yaml
 struct SARSAPredictorLegacy : SARSAPredictor { GRLX_TYPEINFO("predictor/sarsa") };
 GRLX_REGISTER(SARSAPredictorLegacy)
@@ -701,6 +718,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       throw Exception(path() + ": the accelerated path needs mapping/policy/discrete/value/q with predictor/critic/sarsa|q, or policy/action with predictor/ac/action");
     if (pred->projector != pol->projector || pred->representation != pol->representation)
       throw Exception(pred->path() + ": predictor and policy must share projector and representation on the accelerated path");
+    if (const ExpectedSARSAPredictor *es = dynamic_cast<const ExpectedSARSAPredictor *>(pred))
+      if (es->target_policy != pol) throw Exception(es->path() + ": the target policy must be the agent's own policy on the accelerated path");
     if (tpol && (tpol->projector != pol->projector || tpol->representation != pol->representation || tpol->discretizer != pol->discretizer))
       throw Exception(test_agent->path() + ": the test policy must share discretizer, projector and representation with the learning policy");
     if (!pol->sampler->explores() || (tpol && tpol->sampler->explores()))

@@ -40,7 +40,8 @@ enum { GRLX_ENV_PENDULUM = 0,        /* dynamics/pendulum + task/pendulum/swingu
        GRLX_ENV_COMPASS_WALKER = 3   /* sandbox/compass_walker (walk task)          (compass_walker.cpp) */ };
 enum { GRLX_AGENT_SARSA = 0,         /* agent/td + policy/discrete/q + predictor/critic/sarsa (sarsa.cpp)     */
        GRLX_AGENT_Q = 1,             /* ... + predictor/critic/q (advantage.cpp:71-110)                       */
-       GRLX_AGENT_AC = 2             /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */ };
+       GRLX_AGENT_AC = 2,            /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */
+       GRLX_AGENT_EXPECTED_SARSA = 3 /* ... + predictor/critic/expected_sarsa (sarsa.cpp:167-194)              */ };
 enum { GRLX_TRACE_NONE = 0, GRLX_TRACE_REPLACING = 1, GRLX_TRACE_ACCUMULATING = 2 };   /* trace.h:208-263 */
 
 #define GRLX_MAX_DIMS 8

@@ -254,6 +254,47 @@ static double sarsa_update(orc_exp *e, const double *prev_obs, double prev_actio
   return delta;
 }
 
+static double expected_value(orc_exp *e, const double *obs)
+{ /* QPolicy::value (q.cpp:60-73) with EpsilonGreedySampler::distribution (greedy.cpp:220-238) over
+   * GreedySampler::distribution (:88-99), scalar epsilon */
+  double q[ORC_MAX_ACTIONS], dist[ORC_MAX_ACTIONS], v = 0;
+  int mai, man;
+  q_values(e, obs, q);
+  findmax(q, e->A, &mai, &man);
+  for (int i = 0; i < e->A; ++i)
+    dist[i] = (q[i] == q[mai]) ? 1. / man : 0.;
+  for (int i = 0; i < e->A; ++i)
+  {
+    if (dist[i] == 1)
+      dist[i] = 1 - e->eps_decay * e->spec.epsilon;
+    dist[i] += e->eps_decay * e->spec.epsilon / e->A;
+  }
+  for (int i = 0; i < e->A; ++i)
+    v += q[i] * dist[i];
+  return v;
+}
+
+static double expected_sarsa_update(orc_exp *e, const double *prev_obs, double prev_action, double tau,
+                                    double reward, const double *obs, int has_action, orc_proj *pout)
+{ /* ExpectedSARSAPredictor::criticize, sarsa.cpp:167-194.  parity unpinned by reference tests. */
+  const orc_spec *s = &e->spec;
+  orc_proj p;
+  project_sa(e, prev_obs, prev_action, &p);
+  double target = reward;
+  if (has_action)
+    target += orc_m_powtau(s, s->gamma, tau) * expected_value(e, obs);
+  double delta = target - lin_read(e, 0, &s->representation, &p);
+  lin_write(e, 0, &s->representation, &p, target, s->alpha);
+  if (s->trace != ORC_TRACE_NONE)
+  {
+    double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
+    lin_update_trace(e, 0, &s->representation, &e->trace, s->alpha * delta, ee);
+    trace_add(&e->trace, s->trace, &p, ee);
+  }
+  *pout = p;
+  return delta;
+}
+
 static double q_update(orc_exp *e, const double *prev_obs, double prev_action, double tau,
                        double reward, const double *obs, int has_action, orc_proj *pout)
 { /* advantage.cpp:71-110 (QPredictor::criticize).  parity unpinned by reference tests. */
@@ -389,7 +430,7 @@ static double *table_alloc_init(orc_exp *e, const orc_tile_spec *ts, const orc_l
 orc_exp *orc_create(const orc_spec *spec, long seed)
 {
   if (orc_env_state_dims(spec->env) < 0) return NULL;             /* environments not restated yet */
-  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC) return NULL;
+  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC && spec->agent != ORC_AGENT_EXPECTED_SARSA) return NULL;
   if (spec->agent == ORC_AGENT_AC)
   {
     if (spec->projector.dims != orc_env_obs_dims(spec->env) || spec->actor_projector.dims != orc_env_obs_dims(spec->env)) return NULL;
@@ -518,6 +559,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
           else if (s->agent == ORC_AGENT_Q)
             delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
+          else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
+            delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
           else
             delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
         }
@@ -530,6 +573,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
           else if (s->agent == ORC_AGENT_Q)
             delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
+          else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
+            delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
           else
             delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
           memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);

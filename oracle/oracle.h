@@ -64,7 +64,7 @@ enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };
 
 /* ---------------------------------------------------------------- spec -- */
 enum { ORC_ENV_PENDULUM = 0, ORC_ENV_CART_POLE = 1, ORC_ENV_ACROBOT = 2, ORC_ENV_COMPASS_WALKER = 3 };
-enum { ORC_AGENT_SARSA = 0, ORC_AGENT_Q = 1, ORC_AGENT_AC = 2 };
+enum { ORC_AGENT_SARSA = 0, ORC_AGENT_Q = 1, ORC_AGENT_AC = 2, ORC_AGENT_EXPECTED_SARSA = 3 };
 enum { ORC_TRACE_NONE = 0, ORC_TRACE_REPLACING = 1, ORC_TRACE_ACCUMULATING = 2 };
 enum { ORC_AC_PROPORTIONAL = 0, ORC_AC_CACLA = 1 };
 

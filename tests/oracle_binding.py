@@ -16,7 +16,7 @@ LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 MAX_DIMS, MAX_STATE = 8, 12
 MATH_LIBM, MATH_PORTABLE = 0, 1
 ENV_PENDULUM = 0
-AGENT_SARSA, AGENT_Q, AGENT_AC = 0, 1, 2
+AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA = 0, 1, 2, 3
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
 

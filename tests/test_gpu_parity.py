@@ -207,7 +207,7 @@ def _compare_taps(gt, ot, A=3, D=2):
     assert gt.trace_len == ot.trace_len
 
 
-@pytest.mark.parametrize("agent", [0, 1])
+@pytest.mark.parametrize("agent", [0, 1, 3])
 def test_fused_steps_bit_exact(grlx, agent):
     """Every step of the first 23 trials (learning + 2 test trials) of one replica: tile
     indices, Q-values, chosen actions, rewards, TD errors, trace lengths."""
