@@ -479,10 +479,18 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n_trials == 0) return GRLX_OK;
-  if (ctx->cfg.agent == GRLX_AGENT_AC)
-    HIP_TRY(launch_rollout_ac(ctx->P, n_trials, (hipStream_t)stream));
-  else
-    HIP_TRY(launch_rollout(ctx->P, n_trials, (hipStream_t)stream));
+  // One launch per <= kTrialsPerLaunch trials: replica state (and the actor-critic trace) persists in
+  // HBM between launches, so results do not depend on the chunking (tested), and no single kernel
+  // runs for minutes (compass walker: up to 1000 steps per episode).
+  const int kTrialsPerLaunch = 32;
+  for (int done = 0; done < n_trials; done += kTrialsPerLaunch)
+  {
+    const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
+    if (ctx->cfg.agent == GRLX_AGENT_AC)
+      HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream));
+    else
+      HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream));
+  }
   ctx->trials_run += n_trials;
   return GRLX_OK;
 }
@@ -530,13 +538,12 @@ int grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count, int64_t *tr
   if (!ctx || replica < 0 || replica >= ctx->P.n_replicas || first < 0 || count < 0 || first + count > ctx->P.max_rows)
     return fail(GRLX_ERR_INVALID, "bad argument");
   const size_t N = (size_t)ctx->P.n_replicas;
-  for (int i = 0; i < count; ++i)
-  {
-    size_t at = (size_t)(first + i) * N + (size_t)replica;
-    if (reward) HIP_TRY(hipMemcpy(&reward[i], ctx->row_reward + at, sizeof(double), hipMemcpyDeviceToHost));
-    if (steps) HIP_TRY(hipMemcpy(&steps[i], ctx->row_steps + at, sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (trial) HIP_TRY(hipMemcpy(&trial[i], ctx->row_trial + at, sizeof(int64_t), hipMemcpyDeviceToHost));
-  }
+  if (count == 0) return GRLX_OK;
+  // rows are stored [row][replica]: one strided copy per column
+  const size_t at = (size_t)first * N + (size_t)replica;
+  if (reward) HIP_TRY(hipMemcpy2D(reward, sizeof(double), ctx->row_reward + at, N * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));
+  if (steps) HIP_TRY(hipMemcpy2D(steps, sizeof(int64_t), ctx->row_steps + at, N * sizeof(int64_t), sizeof(int64_t), (size_t)count, hipMemcpyDeviceToHost));
+  if (trial) HIP_TRY(hipMemcpy2D(trial, sizeof(int64_t), ctx->row_trial + at, N * sizeof(int64_t), sizeof(int64_t), (size_t)count, hipMemcpyDeviceToHost));
   return GRLX_OK;
 }
 
