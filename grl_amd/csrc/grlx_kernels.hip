@@ -915,17 +915,20 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 struct TraceRegs {
   uint32_t pos[kMaxTrace];
   double   val[kMaxTrace];
-  uint32_t cnt[kMaxTrace];
+  uint32_t cnt2;                // occurrences of the slot in its projection minus 1, two bits per entry
   uint32_t wt;
   bool     dup;                 // some entry occurs twice in its projection (sticky until cleared)
   int      len;
   double   total;
 };
 
+__device__ __forceinline__ uint32_t trace_cnt(const TraceRegs &tr, int e) { return ((tr.cnt2 >> (2 * e)) & 3u) + 1u; }
+
 __device__ __forceinline__ void trace_init(TraceRegs &tr)
 {
 #pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e) { tr.pos[e] = kInvalidPos; tr.val[e] = 0; tr.cnt[e] = 0; }
+  for (int e = 0; e < kMaxTrace; ++e) { tr.pos[e] = kInvalidPos; tr.val[e] = 0; }
+  tr.cnt2 = 0;
   tr.wt = 0;
   tr.dup = false;
   tr.len = 0;
@@ -997,9 +1000,6 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   const uint32_t shmask = (uint32_t)((__ballot(p_sh) >> (16 * g)) & 0xFFFFull);
   uint32_t cp = 1;                                     // occurrences of my slot inside p
   double v;                                            // final weight of p's slot after this step
-  uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
-#pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
   bool cross = tr.dup;                                 // does this lane see an alias that crosses lanes?
   if (__any(shmask != 0u))
   { // some lane's p is a shared slot: compare those few positions (usually one) with my trace and my p
@@ -1009,10 +1009,10 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
       const uint32_t ppk = sh_ppos[g * 16 + k];
       if (k != j)
       {
-        if (ppk == p_pos) { cp++; cross = true; }
+        if (ppk == p_pos) cross = true;
 #pragma unroll
         for (int e = 0; e < kMaxTrace; ++e)
-          if (e < tr.len && tr.pos[e] == ppk) { xm[e] |= 1u << k; cross = true; }
+          if (e < tr.len && tr.pos[e] == ppk) cross = true;
       }
     }
   }
@@ -1061,6 +1061,20 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   }
   else
   { // ---- general case: some alias crosses lanes (a slot shared between tilings is involved)
+    uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
+#pragma unroll
+    for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
+    for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
+    {
+      const int k = __builtin_ctz(mm);
+      const uint32_t ppk = sh_ppos[g * 16 + k];
+      if (k != j)
+      {
+        if (ppk == p_pos) cp++;
+#pragma unroll
+        for (int e = 0; e < kMaxTrace; ++e) xm[e] |= (e < tr.len && tr.pos[e] == ppk) ? (1u << k) : 0u;
+      }
+    }
     double v_alias = 0;
     bool aliased = false;
     if (u.use_trace)
@@ -1084,7 +1098,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
                 double vv = add_clamped(u, tr.val[e], de);
                 if ((tr.wt >> e) & 1u)
                 {
-                  for (uint32_t c = 1; c < tr.cnt[e]; ++c) vv = add_clamped(u, vv, de);
+                  for (uint32_t c = 1; c < trace_cnt(tr, e); ++c) vv = add_clamped(u, vv, de);
                   value_store(tab, tr.pos[e], vv);
                 }
                 tr.val[e] = vv;
@@ -1098,7 +1112,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
                 double vv = tr.val[e];
                 const uint32_t cpx = (own ? 1u : 0u) + (uint32_t)__builtin_popcount(xm[e]);
                 for (uint32_t c = 0; c < cpx; ++c) vv = add_clamped(u, vv, u.dW);
-                for (uint32_t c = 0; c < tr.cnt[e]; ++c) vv = add_clamped(u, vv, de);
+                for (uint32_t c = 0; c < trace_cnt(tr, e); ++c) vv = add_clamped(u, vv, de);
                 if (own) { v_alias = vv; aliased = true; }
                 for (uint32_t mm = xm[e]; mm != 0u; mm &= mm - 1u)
                 {
@@ -1138,12 +1152,13 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
     {
       tr.pos[e] = tr.pos[e - 1];
       tr.val[e] = tr.val[e - 1];
-      tr.cnt[e] = tr.cnt[e - 1];
     }
     tr.wt = (tr.wt << 1) & ((1u << kMaxTrace) - 1u);
+    tr.cnt2 = (tr.cnt2 << 2) & ((1u << (2 * kMaxTrace)) - 1u);
     tr.pos[0] = p_pos;
     tr.val[0] = v;
-    tr.cnt[0] = cp;
+    if (cp > 4u) status |= ST_TRACE_OVERFLOW;              // more than four tilings on one slot: not representable
+    tr.cnt2 |= (cp - 1u) & 3u;
     tr.dup = tr.dup || cp > 1u;
     if (p_sh) tr.wt |= 1u;
     tr.len = (tr.len < kMaxTrace) ? tr.len + 1 : kMaxTrace;
@@ -1731,9 +1746,10 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     {
       tr.pos[e] = ts[e * 2];
       const uint32_t cw = ts[e * 2 + 1];
-      tr.cnt[e] = cw & 0xFFFFu;
+      const uint32_t cn = cw & 0xFFFFu;
+      tr.cnt2 |= ((cn > 0u ? cn - 1u : 0u) & 3u) << (2 * e);
       if (cw >> 16) tr.wt |= 1u << e;
-      tr.dup = tr.dup || tr.cnt[e] > 1u;
+      tr.dup = tr.dup || cn > 1u;
       if (tr.pos[e] != kInvalidPos) tr.val[e] = value_load(tabC, tr.pos[e]);
     }
   }
@@ -1954,7 +1970,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     for (int e = 0; e < kMaxTrace; ++e)
     {
       ts[e * 2] = tr.pos[e];
-      ts[e * 2 + 1] = (tr.cnt[e] & 0xFFFFu) | (((tr.wt >> e) & 1u) << 16);
+      ts[e * 2 + 1] = (trace_cnt(tr, e) & 0xFFFFu) | (((tr.wt >> e) & 1u) << 16);
     }
   }
   uint32_t ic = ins_c, ia = ins_a;
