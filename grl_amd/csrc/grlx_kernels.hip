@@ -620,7 +620,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     ahip = psin(m.ha) * (m.slar*m.slar - cs) + asl;
     ahip += torque;
   }
-  __device__ static __noinline__ void rk4(const DevParams &P, St &state, double torque, double dt)
+  __device__ static __forceinline__ void rk4(const DevParams &P, St &state, double torque, double dt)
   { // SWModel.cpp:220-258
     St s1 = state, s2 = state, s3 = state, s4 = state;
     double k1s, k1h, k2s, k2h, k3s, k3h, k4s, k4h;
@@ -645,7 +645,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     state.sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
     state.ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
   }
-  __device__ static __noinline__ double heelstrike_moment(const DevParams &P, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
+  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
   { // SWModel.cpp:53-104
     double timeLeft = 0;
     St s0 = t0, s1 = t1;
