@@ -590,3 +590,46 @@ def test_dat_policy_export_matches_dense_table(grlx, tmp_path):
     dense = np.ctypeslib.as_array(e.L.orc_weights(e.h, 0), shape=(8388608,))
     assert got.shape == (8388608,)
     assert_bit_equal(got, dense, ".dat parameters")
+
+
+# ----------------------------------------------------------- edge cases -----
+def test_empty_batches_and_bad_arguments(grlx):
+    """n = 0 is legal everywhere; out-of-range arguments come back as GRLX_ERR_INVALID, never a crash."""
+    capi = grlx.capi
+    cfg = grlx.pendulum_sarsa_config(2)
+    st, obs, rew, term = grlx.runner.env_step(cfg, np.zeros((0, 3)), np.zeros(0))
+    assert st.shape == (0, 3) and obs.shape == (0, 2) and rew.shape == (0,) and term.shape == (0,)
+    assert grlx.runner.device_math(0, np.zeros(0)).shape == (0,)
+    assert grlx.runner.rand48_at(1, np.zeros(0, np.uint64)).shape == (0,)
+    r = grlx.Runner(cfg, [5, 6])
+    assert r.read(np.zeros(0, np.int32), np.zeros((0, 16), np.uint32)).shape == (0,)
+    r.run(0); r.sync()
+    assert r.n_rows() == 0 and r.step_counts() == (0, 0)
+    for bad in (lambda: r.rows(2), lambda: r.rows(0, 0, 10**6), lambda: r.weights(-1, [0]), lambda: r.weights(0, [0], table=1),
+                lambda: r.read([2], np.zeros((1, 16), np.uint32)), lambda: r.read([0], np.full((1, 16), 8388608, np.uint32)),
+                lambda: r.env_state(7)):
+        with pytest.raises(capi.GrlxError) as ei:
+            bad()
+        assert ei.value.code == capi.ERR_INVALID
+    r.close()
+    # unsupported graphs are refused, not emulated
+    for field, value in (("trace", capi.TRACE_ACCUMULATING), ("discrete_time", 0), ("action_steps", 9), ("lambda_", 0.99)):
+        c = grlx.pendulum_sarsa_config(1)
+        setattr(c, field, value)
+        with pytest.raises(capi.GrlxError) as ei:
+            grlx.Runner(c, [1])
+        assert ei.value.code == capi.ERR_INVALID, field
+    c = grlx.pendulum_sarsa_config(1)
+    c.projector.tilings = 8
+    with pytest.raises(capi.GrlxError):
+        grlx.Runner(c, [1])
+
+
+def test_more_rows_than_reserved_is_reported(grlx):
+    cfg = grlx.pendulum_sarsa_config(3, max_rows=2)
+    r = grlx.Runner(cfg, [1, 2, 3])
+    r.run(33)
+    with pytest.raises(grlx.capi.GrlxError) as ei:
+        r.sync()
+    assert ei.value.code == grlx.capi.ERR_ROWS_FULL
+    r.close()
