@@ -42,7 +42,7 @@ class Config(C.Structure):
                 ("ac_update_method", C.c_int32),
                 ("table_log2_capacity", C.c_int32), ("max_rows", C.c_int32), ("tap_replica", C.c_int32),
                 ("tap_capacity", C.c_int32), ("end_stop_penalty", C.c_int32), ("action_penalty", C.c_int32),
-                ("reserved1", C.c_int32),
+                ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double)]
 
 

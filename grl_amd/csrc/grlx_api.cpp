@@ -352,6 +352,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.n_replicas = N;
   P.logC = logC;
   P.max_rows = cfg->max_rows;
+  P.no_specialisation = cfg->force_generic;
   P.tap_replica = cfg->tap_replica;
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
 

@@ -92,6 +92,7 @@ struct DevParams {
   uint32_t *tap_count;
   // diagnostic build only: per-wave cycle sums of 8 phases (NULL = production kernel)
   unsigned long long *diag_out;
+  int32_t  no_specialisation;   // tests: force the generic kernel even when a specialised instantiation matches
 };
 
 // ---------------------------------------------------------------------------

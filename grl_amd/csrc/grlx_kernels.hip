@@ -1333,9 +1333,64 @@ __device__ __forceinline__ unsigned long long stamp()
     diag_last = now__;                                     \
   }
 
-template <int ENV, int NA, bool DIAG>
+// Compile-time specialisation for the headline configuration (cfg/pendulum/sarsa_tc.yaml,
+// tests/pendulum-sarsa-tc.yaml): the values below replace the corresponding fields of the
+// parameter block, so they become literals (fewer live SGPRs, "% memory" becomes a mask, the
+// wrap modulus a constant).  The launcher selects it only when every one of these runtime
+// parameters equals the constant bit for bit, so results cannot differ from the generic kernel.
+constexpr DevParams make_spec_pendulum_tc()
+{
+  DevParams P{};
+  P.env = GRLX_ENV_PENDULUM;
+  P.agent = GRLX_AGENT_SARSA;
+  P.trace_kind = GRLX_TRACE_REPLACING;
+  P.test_interval = 10;
+  P.h = 0.03 / 5;
+  P.integration_steps = 5;
+  P.timeout = 2.99;
+  P.randomization = 0;
+  P.A = 3;
+  P.actions[0] = -3; P.actions[1] = 0; P.actions[2] = 3;
+  P.tile.T = 16; P.tile.D = 3; P.tile.memory = 8388608;
+  P.tile.scaling[0] = 16 / 0.31415; P.tile.scaling[1] = 16 / 3.1415; P.tile.scaling[2] = 16 / 3.0;
+  P.tile.wrap[0] = 320;
+  P.lin.init_min = 0; P.lin.init_range = 1;
+  P.lin.out_min = -1.7976931348623157e308; P.lin.out_max = 1.7976931348623157e308;
+  P.lin.limit = 1; P.lin.draws_before = 0;
+  P.epsilon = 0.05; P.decay_rate = 1; P.decay_min = 0;
+  P.alpha = 0.2; P.gamma = 0.97; P.gl = 0.97 * 0.65;
+  return P;
+}
+__device__ const DevParams d_spec_pendulum_tc = make_spec_pendulum_tc();
+
+struct SpecPendulumTc {
+  // every numeric field the rollout kernel reads must equal the constant, bit for bit
+  static bool matches(const DevParams &P)
+  {
+    constexpr DevParams C = make_spec_pendulum_tc();
+    bool ok = P.env == C.env && P.trace_kind == C.trace_kind && P.test_interval == C.test_interval && P.h == C.h &&
+              P.integration_steps == C.integration_steps && P.timeout == C.timeout && P.randomization == C.randomization && P.A == C.A &&
+              P.tile.T == C.tile.T && P.tile.D == C.tile.D && P.tile.memory == C.tile.memory &&
+              P.lin.init_min == C.lin.init_min && P.lin.init_range == C.lin.init_range && P.lin.out_min == C.lin.out_min &&
+              P.lin.out_max == C.lin.out_max && P.lin.limit == C.lin.limit && P.lin.draws_before == C.lin.draws_before &&
+              P.epsilon == C.epsilon && P.decay_rate == C.decay_rate && P.decay_min == C.decay_min && P.alpha == C.alpha &&
+              P.gamma == C.gamma && P.gl == C.gl && (P.agent == GRLX_AGENT_SARSA);
+    for (int i = 0; i < 3; ++i)
+      ok = ok && P.actions[i] == C.actions[i] && P.tile.scaling[i] == C.tile.scaling[i] && P.tile.wrap[i] == C.tile.wrap[i];
+    return ok;
+  }
+  __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_pendulum_tc; }
+};
+struct SpecNone {
+  __device__ static __forceinline__ const DevParams &numeric(const DevParams &P) { return P; }
+};
+
+template <int ENV, int NA, bool DIAG, typename SPEC>
 __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 {
+  // N: the numeric parameters -- the runtime block, or compile-time constants in a specialised build.
+  // P keeps the pointers, the replica count and the buffer sizes.
+  const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
   __shared__ double   sh_w[(NA + 1) * 16 * 4];
   __shared__ uint32_t sh_ppos[4 * 16];
@@ -1368,13 +1423,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
   const Table tab = table_of(P, 0, r);
   UpdateParams up;
-  up.out_min = P.lin.out_min;
-  up.out_max = P.lin.out_max;
-  up.limit = P.lin.limit != 0;
-  up.ee = P.gl;                                 // pow(gamma*lambda, tau), tau = 1 (discrete_time)
-  up.cut = (P.trace_kind == GRLX_TRACE_REPLACING) ? 0.01 : 0.0001;
-  up.use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
+  up.out_min = N.lin.out_min;
+  up.out_max = N.lin.out_max;
+  up.limit = N.lin.limit != 0;
+  up.ee = N.gl;                                 // pow(gamma*lambda, tau), tau = 1 (discrete_time)
+  up.cut = (N.trace_kind == GRLX_TRACE_REPLACING) ? 0.01 : 0.0001;
+  up.use_trace = N.trace_kind == GRLX_TRACE_REPLACING;
   up.dW = up.dT = 0;
+
+  double acts[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acts[a] = N.actions[a];
 
   TraceRegs tr;
   trace_init(tr);
@@ -1384,7 +1443,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
-    const int ti = P.test_interval;
+    const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;        // online_learning.cpp:160
     double obs[D], reward = 0, total_reward = 0;
     int terminal = 0;
@@ -1393,8 +1452,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
     // environment_->start (modeled.cpp:132-158)
     if (live)
     {
-      Env<ENV>::start(P, test, TL, G, x);
-      Env<ENV>::observe(P, x, obs);
+      Env<ENV>::start(N, test, TL, G, x);
+      Env<ENV>::observe(N, x, obs);
     }
     // agent->start: TDAgent::start clears the trace (td.cpp:50-61, sarsa.cpp:126-132); the
     // trace was written back at the end of the previous learning trial, so it is empty here
@@ -1415,7 +1474,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         // -------- environment step (skipped on the start() pass)
         if (!first)
         {
-          env_step<ENV>(P, x, action, obs, reward, terminal, status);     // online_learning.cpp:196
+          env_step<ENV>(N, x, action, obs, reward, terminal, status);     // online_learning.cpp:196
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
         }
@@ -1436,14 +1495,15 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           uint32_t hpre = 449u ^ (uint32_t)(D + 2);
 #pragma unroll
           for (int i = 0; i < D; ++i)
-            hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, tile_quant(P.tile, i, obs[i]), j));
+            hpre = murmur_mix(hpre, tile_coord<T>(N.tile, i, tile_quant(N.tile, i, obs[i]), j));
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
-            int qa = tile_quant(P.tile, D, P.actions[a]);
-            uint32_t h = murmur_mix(hpre, tile_coord<T>(P.tile, D, qa, j));
+            int qa = tile_quant(N.tile, D, N.actions[a]);
+            uint32_t h = murmur_mix(hpre, tile_coord<T>(N.tile, D, qa, j));
             h = murmur_mix(h, j);
-            slot[a] = murmur_final(h) % (uint32_t)P.tile.memory;
+            const uint32_t hm = murmur_final(h), mem = (uint32_t)N.tile.memory;
+            slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
           }
         }
         DIAG_STAMP(2)
@@ -1455,7 +1515,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (has_next)
         {
           bool shared_event = false;
-          table_get<NA>(tab, P.lin, TL0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+          table_get<NA>(tab, N.lin, TL0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
                         [&](uint32_t mp) {
                           trace_share_event(tr, tab, mp);
                           if (p_pos == mp) p_sh = true;
@@ -1514,10 +1574,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           }
           else
           {
-            if (time == 0.) eps_decay = fmax(eps_decay * P.decay_rate, P.decay_min);
+            if (time == 0.) eps_decay = fmax(eps_decay * N.decay_rate, N.decay_min);
             S1 = lcg_next(S1);
             double rnd = lcg_double(S1);
-            if (rnd < eps_decay * P.epsilon)
+            if (rnd < eps_decay * N.epsilon)
             {
               G = lcg_next(G);
               a_next = (int)(lcg_long(G) % (uint32_t)NA);
@@ -1535,11 +1595,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           double target = reward;
           if (has_next)
           {
-            if (P.agent == GRLX_AGENT_SARSA)
-              target += P.gamma * pick<double, NA>(q, a_next);
-            else if (P.agent == GRLX_AGENT_EXPECTED_SARSA)
+            if (N.agent == GRLX_AGENT_SARSA)
+              target += N.gamma * pick<double, NA>(q, a_next);
+            else if (N.agent == GRLX_AGENT_EXPECTED_SARSA)
             { // QPolicy::value (q.cpp:60-73) = sum_a Q(s',a) * EpsilonGreedySampler::distribution (greedy.cpp:220-238)
-              const double de = eps_decay * P.epsilon;
+              const double de = eps_decay * N.epsilon;
               double v = 0;
 #pragma unroll
               for (int kk = 0; kk < NA; ++kk)
@@ -1549,19 +1609,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
                 d += de / NA;
                 v += q[kk] * d;
               }
-              target += P.gamma * v;
+              target += N.gamma * v;
             }
             else
             {
               double v = -__builtin_inf();
 #pragma unroll
               for (int kk = 0; kk < NA; ++kk) v = fmax(v, q[kk]);
-              target += P.gamma * v;
+              target += N.gamma * v;
             }
           }
           delta = target - qsa;
-          up.dW = P.alpha * (target - qsa);                    // LinearRepresentation::write (linear.cpp:186-196)
-          up.dT = P.alpha * delta;                             // VectorConstructor(alpha_*delta)
+          up.dW = N.alpha * (target - qsa);                    // LinearRepresentation::write (linear.cpp:186-196)
+          up.dT = N.alpha * delta;                             // VectorConstructor(alpha_*delta)
           td_update_lane(tr, tab, up, p_pos, p_sh, wp, g, j, sh_ppos, sh_fb, sh_fbflag, status);
           tr_len_ref = tr.len;
         }
@@ -1583,7 +1643,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
               tp->terminal = terminal;
               tp->trace_len = tr_len_ref;
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
-              tp->action = has_next ? P.actions[a_next] : action;
+              tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
               tp->reward = reward;
               tp->delta = delta;
               for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
@@ -1604,7 +1664,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (has_next)
         {
           action_index = a_next;
-          action = P.actions[a_next];                                      // discretizer_->at(index), uniform.cpp:140-151
+          action = pick<double, NA>(acts, a_next);                         // discretizer_->at(index), uniform.cpp:140-151
           p_pos = pick<uint32_t, NA>(pos, a_next);
           p_slot = pick<uint32_t, NA>(slot, a_next);
           p_sh = pick<bool, NA>(sh, a_next);
@@ -2023,10 +2083,15 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
   if (P.env == ENVID && P.A == NACT)                                                                        \
   {                                                                                                         \
     if (P.diag_out)                                                                                         \
-      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, true>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, true, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     else                                                                                                    \
-      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     return hipGetLastError();                                                                               \
+  }
+  if (!P.diag_out && !P.no_specialisation && SpecPendulumTc::matches(P))
+  {
+    hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, false, SpecPendulumTc>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+    return hipGetLastError();
   }
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 3)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 5)

@@ -102,7 +102,7 @@ typedef struct {
   /* task/cart_pole/swingup (cart_pole.cpp:110-130); class defaults 1 / 0, cfg/cart_pole/ac_tc.yaml: 0 / 0 */
   int32_t  end_stop_penalty;
   int32_t  action_penalty;
-  int32_t  reserved1;
+  int32_t  force_generic;             /* 1: never pick a compile-time specialised kernel (tests) */
   /* model/compass_walker + task/compass_walker/walk (compass_walker.cpp:41-60, 198-249) */
   double   slope_angle;               /* default 0.004 */
   double   initial_state_variation;   /* default 0.2   */

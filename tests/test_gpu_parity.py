@@ -633,3 +633,22 @@ def test_more_rows_than_reserved_is_reported(grlx):
         r.sync()
     assert ei.value.code == grlx.capi.ERR_ROWS_FULL
     r.close()
+
+
+def test_specialised_kernel_equals_generic(grlx):
+    """The headline configuration runs a compile-time specialised instantiation (parameters as
+    literals); it must be indistinguishable from the generic kernel."""
+    seeds = np.arange(1, 38)
+    out = []
+    for force in (0, 1):
+        cfg = grlx.pendulum_sarsa_config(len(seeds), force_generic=force)
+        r = grlx.Runner(cfg, seeds)
+        r.run(55); r.sync()
+        rows = np.stack([r.rows(k)[2] for k in range(len(seeds))])
+        slots = np.arange(0, 8388608, 97, dtype=np.uint32)
+        out.append((rows, r.weights(0, slots), r.weights(len(seeds) - 1, slots), [list(r.rng(k)) for k in range(len(seeds))]))
+        r.close()
+    assert_bit_equal(out[0][0], out[1][0], "rows")
+    assert_bit_equal(out[0][1], out[1][1], "weights of replica 0")
+    assert_bit_equal(out[0][2], out[1][2], "weights of the last replica")
+    assert out[0][3] == out[1][3]
