@@ -1399,6 +1399,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   __shared__ uint32_t sh_mb[4 * NA * 16];      // parallel insert: claimed bucket per (action, tiling), ~0 = none
   __shared__ uint32_t sh_ms[4 * NA * 16];      //                  and the slot claiming it
   __shared__ uint32_t sh_mail[4];              // position of a slot that just became shared between tilings
+  __shared__ double   sh_res[4 * 16];          // per-replica sums (row r in slot r)
   __shared__ uint64_t sh_jump[2048];           // LCG jump table (lazy weight initialisation)
   jump_table_to_lds(sh_jump);
 
@@ -1539,27 +1540,25 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         sh_ppos[g * 16 + j] = p_pos;
         sh_fbflag[j * 4 + g] = 0u;
         wave_sync();
+        // LinearRepresentation::read (linear.cpp:136-184): serial sum over the 16 tilings, mean, clamp.
+        // Lane r of the replica sums row r (Q(s',a_r) for r < NA, Q(s,a) for r = NA) in the reference's
+        // order; the NA+1 results are shared through LDS (lanes beyond NA repeat row 0, harmlessly).
+        {
+          const int row = (j <= NA) ? j : 0;
+          double sum = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sum += SHW(row, k, g);
+          sum /= 16;
+          sh_res[g * 16 + j] = sum;
+        }
+        wave_sync();
         if (has_next)
         {
 #pragma unroll
-          for (int a = 0; a < NA; ++a)
-            { // LinearRepresentation::read (linear.cpp:136-184): serial sum, mean, clamp
-              double s = 0;
-#pragma unroll
-              for (int k = 0; k < 16; ++k) s += SHW(a, k, g);
-              s /= 16;
-              q[a] = clampd(s, up.out_min, up.out_max);
-            }
+          for (int a = 0; a < NA; ++a) q[a] = clampd(sh_res[g * 16 + a], up.out_min, up.out_max);
         }
         double qsa = 0;
-        if (update)
-        {
-          double s = 0;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) s += SHW(NA, k, g);
-          s /= 16;
-          qsa = clampd(s, up.out_min, up.out_max);
-        }
+        if (update) qsa = clampd(sh_res[g * 16 + NA], up.out_min, up.out_max);
 
         // -------- sampler (greedy.cpp:63-86, 144-218)
         int a_next = 0;
@@ -1759,6 +1758,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
   __shared__ uint32_t sh_mb[4 * 16];
   __shared__ uint32_t sh_ms[4 * 16];
   __shared__ uint32_t sh_mail[4];
+  __shared__ double   sh_res[4 * 16];
   __shared__ uint64_t sh_jump[2048];
   jump_table_to_lds(sh_jump);
 
@@ -1888,14 +1888,16 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         sh_fbflag[j * 4 + g] = 0u;
         wave_sync();
         double sums[4];
+        { // lane r sums row r in the reference's order (linear.cpp:147-151); results shared through LDS
+          const int row = j & 3;
+          double sum = 0;
 #pragma unroll
-        for (int row = 0; row < 4; ++row)
-        { // LinearRepresentation::read (linear.cpp:136-184): serial sum, mean
-          double s = 0;
-#pragma unroll
-          for (int k = 0; k < 16; ++k) s += SHA(row, k, g);
-          sums[row] = s / 16;
+          for (int k = 0; k < 16; ++k) sum += SHA(row, k, g);
+          sh_res[g * 16 + j] = sum / 16;
         }
+        wave_sync();
+#pragma unroll
+        for (int row = 0; row < 4; ++row) sums[row] = sh_res[g * 16 + row];
         const double u_next = clampd(sums[0], a_min, a_max);           // actor at s'
         const double v_next = clampd(sums[1], up.out_min, up.out_max); // critic at s'
         const double u_prev = clampd(sums[2], a_min, a_max);           // actor at s (before its update)
