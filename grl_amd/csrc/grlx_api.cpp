@@ -462,6 +462,7 @@ int grlx_set_diag(grlx_ctx *ctx, int enable)
     HIP_TRY(hipMemset(ctx->diag, 0, waves * 8 * sizeof(unsigned long long)));
   }
   ctx->P.diag_out = enable ? ctx->diag : nullptr;
+  ctx->P.diag_deferred = enable == 2 ? 1 : 0;     // 1: in-place instantiation (taps possible), 2: the production ordering
   return GRLX_OK;
 }
 

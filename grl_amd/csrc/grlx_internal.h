@@ -93,6 +93,7 @@ struct DevParams {
   // diagnostic build only: per-wave cycle sums of 8 phases (NULL = production kernel)
   unsigned long long *diag_out;
   int32_t  no_specialisation;   // tests: force the generic kernel even when a specialised instantiation matches
+  int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
 };
 
 // ---------------------------------------------------------------------------

@@ -278,39 +278,60 @@ __device__ __forceinline__ uint32_t bucket_kw(const uint4 &k, int way)
   return (way == 0) ? k.x : (way == 1) ? k.y : (way == 2) ? k.z : k.w;
 }
 
-// Resolve NP independent lookups of one lane with all first-round loads in flight together.
+// NP independent lookups of one lane, in two halves so that a caller can put independent work
+// between the loads and their first use: table_issue starts the home-bucket loads (all in
+// flight together), table_resolve consumes them.
 template <int NP>
-__device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], double (&val)[NP], uint32_t &status)
+__device__ __forceinline__ void table_issue(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], BucketRegs (&br)[NP])
 {
-  BucketRegs br[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i)
   {
     lk[i].bucket = table_home(t, slot[i]);
+    lk[i].pos = 0u;
     br[i] = bucket_load(t, lk[i].bucket);
   }
+}
+
+// way of `slot` in a loaded bucket, branch-free: *hit, and for a hit the way (0..3), the key
+// word and the value; *empty = bit mask of empty ways.  A slot occupies at most one way.
+__device__ __forceinline__ void bucket_select(const BucketRegs &b, uint32_t slot, bool &hit, uint32_t &way, uint32_t &kw, double &val, uint32_t &empty)
+{
+  const uint32_t want = slot + 1u;
+  const uint32_t k0 = b.k.x & kKeyMask, k1 = b.k.y & kKeyMask, k2 = b.k.z & kKeyMask, k3 = b.k.w & kKeyMask;
+  empty = (k0 == 0u ? 1u : 0u) | (k1 == 0u ? 2u : 0u) | (k2 == 0u ? 4u : 0u) | (k3 == 0u ? 8u : 0u);
+  const bool m0 = k0 == want, m1 = k1 == want, m2 = k2 == want, m3 = k3 == want;
+  way = m1 ? 1u : 0u;
+  kw = m1 ? b.k.y : b.k.x;
+  val = m1 ? b.v[1] : b.v[0];
+  way = m2 ? 2u : way;
+  kw = m2 ? b.k.z : kw;
+  val = m2 ? b.v[2] : val;
+  way = m3 ? 3u : way;
+  kw = m3 ? b.k.w : kw;
+  val = m3 ? b.v[3] : val;
+  hit = m0 || m1 || m2 || m3;
+}
+
+template <int NP>
+__device__ __forceinline__ void table_resolve(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], const BucketRegs (&br)[NP],
+                                              double (&val)[NP], uint32_t &status)
+{
   bool pending[NP];
   bool any = false;
 #pragma unroll
   for (int i = 0; i < NP; ++i)
-  {
-    const int way = bucket_find(br[i].k, slot[i], lk[i].empty);
-    lk[i].miss = false;
-    lk[i].kw = 0u;
-    pending[i] = false;
-    if (way >= 0)
-    {
-      lk[i].pos = (lk[i].bucket << 2) | (uint32_t)way;
-      lk[i].kw = bucket_kw(br[i].k, way);
-      val[i] = (way == 0) ? br[i].v[0] : (way == 1) ? br[i].v[1] : (way == 2) ? br[i].v[2] : br[i].v[3];
-    }
-    else if (lk[i].empty != 0u)
-      lk[i].miss = true;
-    else
-    {
-      pending[i] = true;                           // home bucket full of other slots: overflow chain
-      any = true;
-    }
+  { // straight-line selects: nothing here is worth a branch
+    bool hit;
+    uint32_t way, kw;
+    double v;
+    bucket_select(br[i], slot[i], hit, way, kw, v, lk[i].empty);
+    lk[i].pos = hit ? ((lk[i].bucket << 2) | way) : lk[i].pos;
+    lk[i].kw = hit ? kw : 0u;
+    val[i] = hit ? v : val[i];
+    lk[i].miss = !hit && lk[i].empty != 0u;
+    pending[i] = !hit && lk[i].empty == 0u;            // home bucket full of other slots: overflow chain
+    any = any || pending[i];
   }
   if (__any(any))
   { // rare: walk the following buckets
@@ -340,6 +361,14 @@ __device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&sl
     for (int i = 0; i < NP; ++i)
       if (pending[i]) status |= ST_TABLE_FULL;
   }
+}
+
+template <int NP>
+__device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], double (&val)[NP], uint32_t &status)
+{
+  BucketRegs br[NP];
+  table_issue<NP>(t, slot, lk, br);
+  table_resolve<NP>(t, slot, lk, br, val, status);
 }
 
 // Serialised insert (one lane per 16-lane group at a time), re-reading the bucket: used for
@@ -432,6 +461,28 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
     const double J = 0.000191, m = 0.055, g = 9.81, l = 0.042, b = 0.000003, K = 0.0536, R = 9.5;
     double a = x[0], ad = x[1];
     double add = (1 / J) * (m * g * l * psin(a) - b * ad - (K * K / R) * ad + (K / R) * u);
+    xd[0] = ad;
+    xd[1] = add;
+    xd[2] = 1;
+  }
+  // the same equations with the sine's constants held in registers by the caller (rk4_step)
+  struct Consts { SinConsts k; double invJ, mgl, b, kkr, kr; };
+  __device__ static __forceinline__ Consts consts()
+  {
+    const double J = 0.000191, m = 0.055, g = 9.81, l = 0.042, b = 0.000003, K = 0.0536, R = 9.5;
+    Consts c;
+    c.k = sin_consts();
+    c.invJ = math_pin(1 / J);
+    c.mgl = math_pin(m * g * l);
+    c.b = math_pin(b);
+    c.kkr = math_pin(K * K / R);
+    c.kr = math_pin(K / R);
+    return c;
+  }
+  __device__ static __forceinline__ void eom(const Consts &c, const double *x, double u, double *xd)
+  {
+    double a = x[0], ad = x[1];
+    double add = c.invJ * (c.mgl * psin(a, c.k) - c.b * ad - c.kkr * ad + c.kr * u);
     xd[0] = ad;
     xd[1] = add;
     xd[2] = 1;
@@ -796,6 +847,18 @@ template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bo
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
 // (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
+// constants an environment wants held in registers across the integration loop (default: none)
+template <int ENV> struct EnvConsts {
+  struct type {};
+  __device__ static __forceinline__ type make() { return type(); }
+  __device__ static __forceinline__ void eom(const type &, const double *x, double u, double *xd) { Env<ENV>::eom(x, u, xd); }
+};
+template <> struct EnvConsts<GRLX_ENV_PENDULUM> {
+  using type = Env<GRLX_ENV_PENDULUM>::Consts;
+  __device__ static __forceinline__ type make() { return Env<GRLX_ENV_PENDULUM>::consts(); }
+  __device__ static __forceinline__ void eom(const type &c, const double *x, double u, double *xd) { Env<GRLX_ENV_PENDULUM>::eom(c, x, u, xd); }
+};
+
 template <int ENV>
 __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
 {
@@ -805,18 +868,19 @@ __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, do
   double xd[S], k1[SD], k2[SD], k3[SD], k4[SD], t[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) { next[i] = x[i]; t[i] = x[i]; }
+  const typename EnvConsts<ENV>::type ec = EnvConsts<ENV>::make();
   for (int ii = 0; ii < P.integration_steps; ++ii)
   {
-    Env<ENV>::eom(next, u, xd);
+    EnvConsts<ENV>::eom(ec, next, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
-    Env<ENV>::eom(t, u, xd);
+    EnvConsts<ENV>::eom(ec, t, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
-    Env<ENV>::eom(t, u, xd);
+    EnvConsts<ENV>::eom(ec, t, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
-    Env<ENV>::eom(t, u, xd);
+    EnvConsts<ENV>::eom(ec, t, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i)
     {
@@ -990,8 +1054,17 @@ __device__ __forceinline__ double add_clamped(const UpdateParams &u, double v, d
 //   trace->add(p, e)                   -> ssub, push, pop                   (trace.h:215-234)
 // Lane j handles tiling j.  Returns nothing; p's final weight becomes trace entry 0.
 // sh_ppos / sh_fb / sh_fbflag: LDS scratch of the wave (see rollout kernels).
+// Eviction: a weight that leaves the trace is written back to the table.  With HOLD the first
+// write-back of the call is handed to the caller instead ({pos, val} in ev; the caller stores it
+// later; pos = kInvalidPos: nothing held); ev.n counts the write-backs of the call (n > 1, or a
+// path that does not count: n = 2, tells the caller that table values it loaded before this call
+// may be stale).
+struct Evicted { uint32_t n, pos; double val; };
+
+template <bool HOLD>
 __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, const UpdateParams &u, uint32_t p_pos, bool p_sh, double wp,
-                                               int g, int j, const uint32_t *sh_ppos, double *sh_fb, uint32_t *sh_fbflag, uint32_t &status)
+                                               int g, int j, const uint32_t *sh_ppos, double *sh_fb, uint32_t *sh_fbflag, uint32_t &status,
+                                               Evicted &ev)
 {
   // Aliasing between p and the trace (IndexProjection::ssub, projection.h:94-104).  Inside a
   // lane it is a register compare.  Across lanes it needs a p that is a slot shared between
@@ -1138,6 +1211,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
       v = wp;
       for (uint32_t c = 0; c < cp; ++c) v = add_clamped(u, v, u.dW);
     }
+    if (HOLD) ev.n = 2u;                                   // weights moved between lanes: not tracked
   }
   // a shared slot is kept current in the table; an exclusive one only if no trace follows
   if (p_sh || !u.use_trace) value_store(tab, p_pos, v);
@@ -1145,7 +1219,11 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   // trace_->add(p, decay) (trace.h:215-234)
   if (u.use_trace)
   {
-    if (u.ee < u.cut) trace_flush(tr, tab, true);          // decay below the cut: clear() first
+    if (u.ee < u.cut)
+    { // decay below the cut: clear() first
+      trace_flush(tr, tab, true);
+      if (HOLD) ev.n = 2u;
+    }
     if (tr.len >= kMaxTrace) status |= ST_TRACE_OVERFLOW;  // cannot happen: validated at create
 #pragma unroll
     for (int e = kMaxTrace - 1; e > 0; --e)
@@ -1173,7 +1251,17 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
     for (int e = 0; e < kMaxTrace; ++e)
       if (e >= tr.len)
       {
-        if (tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u)) value_store(tab, tr.pos[e], tr.val[e]);
+        const bool wb = tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u);
+        if (HOLD)
+        {
+          const bool hold = wb && ev.n == 0u;
+          if (wb && !hold) value_store(tab, tr.pos[e], tr.val[e]);
+          ev.pos = hold ? tr.pos[e] : ev.pos;
+          ev.val = hold ? tr.val[e] : ev.val;
+          ev.n += wb ? 1u : 0u;
+        }
+        else if (wb)
+          value_store(tab, tr.pos[e], tr.val[e]);
         tr.pos[e] = kInvalidPos;
         tr.wt &= ~(1u << e);
       }
@@ -1184,15 +1272,16 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
 // together; creates missing slots (parallel LDS-ranked claims, serialised fallback) and
 // resolves new cross-tiling sharing events.  sh[i]: the slot is shared between tilings.
 // on_share(mp): called in every lane of the group for each slot position that just became shared.
+// table_get_finish: the part after the loads of table_issue (lk, br).
 template <int NP, typename OnShare>
-__device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
-                                          uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
-                                          uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
-                                          uint32_t &status, uint32_t &inserted, OnShare on_share)
+__device__ __forceinline__ void table_get_finish(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
+                                                 Lookup (&lk)[NP], const BucketRegs (&br)[NP],
+                                                 uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
+                                                 uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
+                                                 uint32_t &status, uint32_t &inserted, OnShare on_share)
 {
   const int lane = threadIdx.x & 63;
-  Lookup lk[NP];
-  table_lookup<NP>(tab, slot, lk, w, status);
+  table_resolve<NP>(tab, slot, lk, br, w, status);
   bool anymiss = false;
 #pragma unroll
   for (int a = 0; a < NP; ++a) anymiss = anymiss || lk[a].miss;
@@ -1316,6 +1405,18 @@ __device__ __forceinline__ void table_get(const Table &tab, const LinearParams &
   }
 }
 
+template <int NP, typename OnShare>
+__device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
+                                          uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
+                                          uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
+                                          uint32_t &status, uint32_t &inserted, OnShare on_share)
+{
+  Lookup lk[NP];
+  BucketRegs br[NP];
+  table_issue<NP>(tab, slot, lk, br);
+  table_get_finish<NP>(tab, lp, tl0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, on_share);
+}
+
 // in-kernel stamps (diagnostic instantiation only; cdna_hip_programming.md section 7)
 __device__ __forceinline__ unsigned long long stamp()
 {
@@ -1385,7 +1486,7 @@ struct SpecNone {
   __device__ static __forceinline__ const DevParams &numeric(const DevParams &P) { return P; }
 };
 
-template <int ENV, int NA, bool DIAG, typename SPEC>
+template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG>
 __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 {
   // N: the numeric parameters -- the runtime block, or compile-time constants in a specialised build.
@@ -1439,6 +1540,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   TraceRegs tr;
   trace_init(tr);
   int tr_len_ref = 0;           // length as the reference reports it (its trace survives test trials)
+  // DEFER: the TD update of a step is applied one pass later, between the next step's table loads
+  // and their first use (same arithmetic, same order of updates; only its position in the
+  // instruction stream moves).  The diagnostic instantiation (stamps, taps) updates in place
+  // (DEFER = false) unless asked to stamp the production ordering.
+  bool pd = false, pd_sh = false;
+  double pd_dW = 0, pd_dT = 0, pd_wp = 0;
+  uint32_t pd_pos = kInvalidPos;
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
   if (DIAG) diag_last = stamp();
 
@@ -1468,7 +1576,21 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
     for (;;)
     {
-      if (!__any(running)) break;
+      if (!__any(running || pd)) break;
+      // state that lives across the deferred-update site
+      uint32_t slot[NA];
+      Lookup lk[NA];
+      BucketRegs br[NA];
+      double wp = 0;
+      bool has_next = false, update = false;
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+      {
+        slot[a] = 0;
+        lk[a].bucket = 0; lk[a].empty = 0; lk[a].pos = 0u; lk[a].kw = 0; lk[a].miss = false;
+        br[a].k = make_uint4(0u, 0u, 0u, 0u);
+        br[a].v[0] = br[a].v[1] = br[a].v[2] = br[a].v[3] = 0;
+      }
       if (running)
       {
         DIAG_STAMP(0)
@@ -1479,18 +1601,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
         }
-        const bool has_next = first || terminal != 2;
+        has_next = first || terminal != 2;
+        update = !first && !test;                                          // a TD update follows
         DIAG_STAMP(1)
 
-        // -------- policy: Q(s', .) for all actions (q.cpp:94-107)
-        double q[NA];
-        uint32_t slot[NA], pos[NA];
-        double w[NA];
-        bool sh[NA];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) { q[a] = 0; slot[a] = 0; pos[a] = kInvalidPos; w[a] = 0; sh[a] = false; }
-        double wp = 0;
-        const bool update = !first && !test;                               // a TD update follows
+        // -------- policy: Q(s', .) for all actions (q.cpp:94-107): projections
         if (has_next)
         {
           uint32_t hpre = 449u ^ (uint32_t)(D + 2);
@@ -1513,17 +1628,77 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         DIAG_STAMP(6)
         if (update) wp = value_load(tab, p_pos);                           // weights of project(s, a) as stored
+        if (has_next) table_issue<NA>(tab, slot, lk, br);                  // home buckets of Q(s', .): loads in flight
+      }
+
+      // -------- the PREVIOUS step's predictor update, in the shadow of the loads just issued.
+      // It works on the register trace only; the one weight it evicts is handed back in `ev` and
+      // stored at the end of this pass, so no store sits between the loads and their use.
+      Evicted ev;
+      ev.n = 0u; ev.pos = kInvalidPos; ev.val = 0;
+      if (DEFER)
+      {
+        DIAG_STAMP(7)
+        if (pd)
+        {
+          sh_ppos[g * 16 + j] = pd_pos;
+          sh_fbflag[j * 4 + g] = 0u;
+        }
+        wave_sync();
+        if (pd)
+        {
+          up.dW = pd_dW;
+          up.dT = pd_dT;
+          td_update_lane<true>(tr, tab, up, pd_pos, pd_sh, pd_wp, g, j, sh_ppos, sh_fb, sh_fbflag, status, ev);
+          pd = false;
+        }
+        DIAG_STAMP(5)
+      }
+
+      if (running)
+      {
+        double q[NA];
+        uint32_t pos[NA];
+        double w[NA];
+        bool sh[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { q[a] = 0; pos[a] = kInvalidPos; w[a] = 0; sh[a] = false; }
         if (has_next)
         {
           bool shared_event = false;
-          table_get<NA>(tab, N.lin, TL0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
-                        [&](uint32_t mp) {
-                          trace_share_event(tr, tab, mp);
-                          if (p_pos == mp) p_sh = true;
-                          shared_event = true;
-                        });
+          table_get_finish<NA>(tab, N.lin, TL0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+                               [&](uint32_t mp) {
+                                 // a weight evicted a moment ago and not stored yet: store it now, the finder reads it
+                                 if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tab, mp, ev.val);
+                                 trace_share_event(tr, tab, mp);
+                                 if (p_pos == mp) p_sh = true;
+                                 shared_event = true;
+                               });
           DIAG_STAMP(7)
           if (__any(shared_event) && update) wp = value_load(tab, p_pos);
+        }
+        if (DEFER)
+        { // Values loaded before the deferred update may be stale where that update wrote the table:
+          // (1) slots shared between tilings (kept current in the table by their owners' lanes) and
+          // paths that do not track their write-backs: load again, the stores precede these loads;
+          // (2) the one held eviction: its value is in `ev`.
+          bool risky = ev.n > 1u || (update && p_sh);
+#pragma unroll
+          for (int a = 0; a < NA; ++a) risky = risky || (has_next && sh[a]);
+          if (__any(risky))
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+              if (has_next) w[a] = value_load(tab, pos[a]);
+            if (update) wp = value_load(tab, p_pos);
+          }
+          const bool held = ev.pos != kInvalidPos;
+#pragma unroll
+          for (int a = 0; a < NA; ++a) w[a] = (held && pos[a] == ev.pos) ? ev.val : w[a];
+          wp = (held && p_pos == ev.pos) ? ev.val : wp;
+        }
+        if (has_next)
+        {
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
@@ -1537,8 +1712,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           SHW(NA, j, g) = wp;
         }
         DIAG_STAMP(3)
-        sh_ppos[g * 16 + j] = p_pos;
-        sh_fbflag[j * 4 + g] = 0u;
+        if (!DEFER)
+        {
+          sh_ppos[g * 16 + j] = p_pos;
+          sh_fbflag[j * 4 + g] = 0u;
+        }
         wave_sync();
         // LinearRepresentation::read (linear.cpp:136-184): serial sum over the 16 tilings, mean, clamp.
         // Lane r of the replica sums row r (Q(s',a_r) for r < NA, Q(s,a) for r = NA) in the reference's
@@ -1619,15 +1797,30 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             }
           }
           delta = target - qsa;
-          up.dW = N.alpha * (target - qsa);                    // LinearRepresentation::write (linear.cpp:186-196)
-          up.dT = N.alpha * delta;                             // VectorConstructor(alpha_*delta)
-          td_update_lane(tr, tab, up, p_pos, p_sh, wp, g, j, sh_ppos, sh_fb, sh_fbflag, status);
-          tr_len_ref = tr.len;
+          const double dW = N.alpha * (target - qsa);          // LinearRepresentation::write (linear.cpp:186-196)
+          const double dT = N.alpha * delta;                   // VectorConstructor(alpha_*delta)
+          if (DEFER)
+          { // applied on the next pass, after that pass's loads are in flight
+            pd = true;
+            pd_dW = dW;
+            pd_dT = dT;
+            pd_pos = p_pos;
+            pd_sh = p_sh;
+            pd_wp = wp;
+          }
+          else
+          {
+            up.dW = dW;
+            up.dT = dT;
+            Evicted none;
+            td_update_lane<false>(tr, tab, up, p_pos, p_sh, wp, g, j, sh_ppos, sh_fb, sh_fbflag, status, none);
+            tr_len_ref = tr.len;
+          }
         }
 
         DIAG_STAMP(5)
-        // -------- tap (debug / parity tests)
-        if (tapped && !first)
+        // -------- tap (debug / parity tests; only the immediate-update instantiation records taps)
+        if (!DEFER && tapped && !first)
         {
           uint32_t n = *P.tap_count;
           if (n < (uint32_t)P.tap_capacity)
@@ -1671,6 +1864,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (!first && terminal) running = false;
         first = false;
       }
+      // the eviction held back by the deferred update: nothing reads the table before the next pass
+      if (DEFER && ev.pos != kInvalidPos) value_store(tab, ev.pos, ev.val);
     }
 
     // end of the trial: the trace is cleared by the next TDAgent::start (td.cpp:54); write the
@@ -1937,7 +2132,8 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
           delta = target - v_prev;
           up.dW = P.alpha * (target - v_prev);
           up.dT = P.alpha * delta;
-          td_update_lane(tr, tabC, up, p_pos, p_sh, wpc, g, j, sh_ppos, sh_fb, sh_fbflag, status);
+          Evicted ev_unused;
+          td_update_lane<false>(tr, tabC, up, p_pos, p_sh, wpc, g, j, sh_ppos, sh_fb, sh_fbflag, status, ev_unused);
           // actor
           if (P.ac_update_method == 0 || delta > 0)
           {
@@ -2081,16 +2277,23 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
 {
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  // stamps and per-step taps are recorded by the instantiation that updates in place
+  const bool inplace = P.diag_out != nullptr || (P.tap_replica >= 0 && P.tap_capacity > 0);
+  if (P.diag_out && P.diag_deferred && P.env == GRLX_ENV_PENDULUM && P.A == 3 && !(P.tap_replica >= 0 && P.tap_capacity > 0))
+  {
+    hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, true, SpecNone, true>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+    return hipGetLastError();
+  }
 #define GRLX_LAUNCH(ENVID, NACT)                                                                              \
   if (P.env == ENVID && P.A == NACT)                                                                        \
   {                                                                                                         \
-    if (P.diag_out)                                                                                         \
+    if (inplace)                                                                                            \
       hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, true, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     else                                                                                                    \
       hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     return hipGetLastError();                                                                               \
   }
-  if (!P.diag_out && !P.no_specialisation && SpecPendulumTc::matches(P))
+  if (!inplace && !P.no_specialisation && SpecPendulumTc::matches(P))
   {
     hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, false, SpecPendulumTc>), dim3(waves), dim3(64), 0, stream, P, n_trials);
     return hipGetLastError();

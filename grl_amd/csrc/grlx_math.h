@@ -104,6 +104,64 @@ __device__ __forceinline__ void math_kboth(double r, double t, double &sn, doubl
   cs = w + __builtin_fma(z2, Q, __builtin_fma(-r, t, tail));
 }
 
+// The constants of reduce + both kernels held in vector registers.  A lone wave issues one
+// instruction every four cycles whatever its kind, so re-materialising 64-bit literals into
+// scalar registers inside a loop (what the compiler does when it runs out of them) costs as
+// much as the arithmetic; hoisted into VGPRs once (pin()), the loop has no such moves.
+struct SinConsts {
+  double invpio2, p1, p2, p3;
+  double s[8], c[8];
+};
+
+__device__ __forceinline__ double math_pin(double v) { asm volatile("" : "+v"(v)); return v; }
+
+__device__ __forceinline__ SinConsts sin_consts()
+{
+  SinConsts k;
+  k.invpio2 = math_pin(GRLX_INVPIO2);
+  k.p1 = math_pin(GRLX_PIO2_1);
+  k.p2 = math_pin(GRLX_PIO2_2);
+  k.p3 = math_pin(GRLX_PIO2_3);
+  const double sv[8] = {-0x1.5555555555555p-3, 0x1.1111111111111p-7, -0x1.a01a01a01a01ap-13, 0x1.71de3a556c734p-19,
+                        -0x1.ae64567f544e4p-26, 0x1.6124613a86d09p-33, -0x1.ae7f3e733b81fp-41, 0x1.952c77030ad4ap-49};
+  const double cv[8] = {0x1.5555555555555p-5, -0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-16, -0x1.27e4fb7789f5cp-22,
+                        0x1.1eed8eff8d898p-29, -0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-45, -0x1.6827863b97d97p-53};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { k.s[i] = math_pin(sv[i]); k.c[i] = math_pin(cv[i]); }
+  return k;
+}
+
+// psin with the constants supplied: the same operations as psin below, in the same order
+__device__ __forceinline__ double psin(double x, const SinConsts &k)
+{
+  const double fn = __builtin_rint(x * k.invpio2);
+  const double r0 = __builtin_fma(-fn, k.p1, x);
+  const double p  = fn * k.p2;
+  const double pl = __builtin_fma(fn, k.p2, -p);
+  const double r = r0 - p;
+  const double e = (r0 - r) - p;
+  const double t = (e - pl) - fn * k.p3;
+  const int q = (int)fn;
+  const double z = r * r, z2 = z * z, z4 = z2 * z2;
+  const double sa = __builtin_fma(z, k.s[1], k.s[0]);
+  const double sb = __builtin_fma(z, k.s[3], k.s[2]);
+  const double sc = __builtin_fma(z, k.s[5], k.s[4]);
+  const double sd = __builtin_fma(z, k.s[7], k.s[6]);
+  const double P = __builtin_fma(z4, __builtin_fma(z2, sd, sc), __builtin_fma(z2, sb, sa));
+  const double ca = __builtin_fma(z, k.c[1], k.c[0]);
+  const double cb = __builtin_fma(z, k.c[3], k.c[2]);
+  const double cc = __builtin_fma(z, k.c[5], k.c[4]);
+  const double cd = __builtin_fma(z, k.c[7], k.c[6]);
+  const double Q = __builtin_fma(z4, __builtin_fma(z2, cd, cc), __builtin_fma(z2, cb, ca));
+  const double hz = 0.5 * z;
+  const double sn = r + __builtin_fma(z * r, P, __builtin_fma(-hz, t, t));
+  const double w = 1.0 - hz;
+  const double tail = (1.0 - w) - hz;
+  const double cs = w + __builtin_fma(z2, Q, __builtin_fma(-r, t, tail));
+  const double v = (q & 1) ? cs : sn;
+  return (q & 2) ? -v : v;
+}
+
 // Branch-free forms: callers guarantee |x| < 2^20 (checked once per environment step;
 // outside the domain the result is unspecified and the replica is flagged).
 __device__ __forceinline__ double psin(double x)

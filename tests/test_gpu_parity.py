@@ -652,3 +652,37 @@ def test_specialised_kernel_equals_generic(grlx):
     assert_bit_equal(out[0][1], out[1][1], "weights of replica 0")
     assert_bit_equal(out[0][2], out[1][2], "weights of the last replica")
     assert out[0][3] == out[1][3]
+
+
+@pytest.mark.parametrize("memory,agent", [(8388608, 0), (4096, 0), (2048, 1), (4099, 3)])
+def test_deferred_update_equals_in_place_and_oracle(grlx, memory, agent):
+    """The production instantiation applies the TD update of a step one pass later, in the
+    shadow of the next step's table loads; the diagnostic instantiation applies it in place.
+    Both must give the oracle's rows, weights and RNG positions -- also with a tiny hash memory,
+    where most slots are shared between tilings (write-through entries, cross-lane aliases,
+    reloads) and the rarely taken paths of the update run all the time."""
+    seeds = list(range(3, 12))
+    trials = 44
+    slots = np.arange(0, memory, 1 if memory < 10000 else 1021, dtype=np.uint32)
+    got = []
+    for inplace in (False, True):
+        cfg = grlx.pendulum_sarsa_config(len(seeds), agent=agent)
+        cfg.projector.memory = memory
+        r = grlx.Runner(cfg, seeds)
+        if inplace:
+            r.set_diag(True)
+        r.run(20); r.run(24); r.sync()
+        got.append(([r.rows(k) for k in range(len(seeds))], [r.weights(k, slots) for k in range(len(seeds))],
+                    [list(r.rng(k))[:3] for k in range(len(seeds))]))
+        r.close()
+    for k, seed in enumerate(seeds):
+        spec = ob.pendulum_sarsa_spec(agent=agent)
+        spec.projector.memory = memory
+        e = ob.Experiment(spec, seed=seed)
+        rows, _ = e.run(trials)
+        for which, g in zip(("deferred", "in place"), got):
+            t, s, rew = g[0][k]
+            assert list(s) == [x.steps for x in rows], which
+            assert_bit_equal(rew, [x.reward for x in rows], f"{which}: returns of seed {seed}")
+            assert_bit_equal(g[1][k], e.weights(slots), f"{which}: weights of seed {seed}")
+            assert g[2][k] == list(e.rng())[:3], which

@@ -14,7 +14,8 @@ cfg = grl_amd.pendulum_sarsa_config(n, max_rows=64, table_log2_capacity=logc)
 r = grl_amd.Runner(cfg, np.arange(1, n + 1))
 warm = int(sys.argv[4]) if len(sys.argv) > 4 else 33
 r.run(warm); r.sync()                     # warm tables
-r.set_diag(True)
+mode = int(sys.argv[5]) if len(sys.argv) > 5 else 1   # 1: in-place update, 2: deferred update (production ordering)
+r.set_diag(mode)
 t0 = time.perf_counter(); r.run(trials); r.sync(); dt = time.perf_counter() - t0
 d = r.read_diag().astype(np.float64)
 names = ["loop/bookkeeping", "env step (RK4)", "tile hashing", "inserts + LDS writes", "LDS sums + sampler", "TD update + trace", "wait for previous stores", "table lookup (loads)"]
