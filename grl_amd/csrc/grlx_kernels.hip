@@ -139,6 +139,19 @@ __device__ __forceinline__ uint32_t murmur_mix(uint32_t h, int c)
   return h;
 }
 
+// the two halves of murmur_mix: the key's own scramble (depends on the coordinate only) and
+// its absorption into the running hash; murmur_mix(h, c) == murmur_absorb(h, murmur_key(c))
+__device__ __forceinline__ uint32_t murmur_key(int c)
+{
+  const uint32_t m = 0x5bd1e995u;
+  uint32_t k = (uint32_t)c;
+  k *= m;
+  k ^= k >> 24;
+  k *= m;
+  return k;
+}
+__device__ __forceinline__ uint32_t murmur_absorb(uint32_t h, uint32_t k) { return (h * 0x5bd1e995u) ^ k; }
+
 __device__ __forceinline__ uint32_t murmur_final(uint32_t h)
 { // tile_coding.h:109-113
   const uint32_t m = 0x5bd1e995u;
@@ -1092,9 +1105,12 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   if (!__any(cross))
   { // ---- common case: no alias crosses lanes in this wave; aliasing is a register compare inside
     // the lane; straight-line code, no exec-mask branches
+    // Entries at e >= len are always invalid (pos == kInvalidPos), so validity alone decides; the
+    // weight sequence 1, ee, ee^2, ... does not depend on the data (a compile-time table in a
+    // specialised build).
     double a_val = 0, a_de = 0;
-    bool aliased = false, a_upd = false;
-    uint32_t stmask = 0;
+    bool a_upd = false;
+    uint32_t doitmask = 0, ownmask = 0;
     if (u.use_trace)
     {
       double weight = 1.;
@@ -1102,24 +1118,24 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
 #pragma unroll
       for (int e = 0; e < kMaxTrace; ++e)
       {
-        const bool in = e < tr.len;
-        upd = upd && (!in || weight > 0.001);            // representation.h:81
+        upd = upd && (weight > 0.001);                   // representation.h:81
         const double de = weight * u.dT * u.ee;
-        const bool valid = in && tr.pos[e] != kInvalidPos;
-        const bool own = valid && tr.pos[e] == p_pos;
+        const bool own = tr.pos[e] == p_pos;             // p_pos is a valid position
+        const bool doit = tr.pos[e] != kInvalidPos && !own && upd;
         const double vv = add_clamped(u, tr.val[e], de);
-        const bool doit = valid && !own && upd;
         tr.val[e] = doit ? vv : tr.val[e];
-        stmask |= (doit && ((tr.wt >> e) & 1u)) ? (1u << e) : 0u;
+        doitmask |= doit ? (1u << e) : 0u;
+        ownmask |= own ? (1u << e) : 0u;
         a_val = own ? tr.val[e] : a_val;
         a_de = own ? de : a_de;
         a_upd = own ? upd : a_upd;
-        aliased = aliased || own;
         tr.pos[e] = own ? kInvalidPos : tr.pos[e];       // ssub: the slot leaves the trace
-        tr.wt = own ? (tr.wt & ~(1u << e)) : tr.wt;
-        weight = in ? weight * u.ee : weight;
+        weight *= u.ee;
       }
     }
+    const bool aliased = ownmask != 0u;
+    const uint32_t stmask = doitmask & tr.wt;            // write-through entries that changed
+    tr.wt &= ~ownmask;
     // p's write first, then the aliased entry's update (if it is still being updated)
     const double base = aliased ? a_val : wp;
     const double v1 = add_clamped(u, base, u.dW);
@@ -1536,6 +1552,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   double acts[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) acts[a] = N.actions[a];
+  // The action coordinate of tiling j and the tiling index itself do not change: their murmur
+  // key words are computed once (32-bit multiplies are quarter rate).
+  uint32_t key_act[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+    key_act[a] = in_reg(murmur_key(tile_coord<T>(N.tile, D, tile_quant(N.tile, D, N.actions[a]), j)));
+  const uint32_t key_j = in_reg(murmur_key(j));
 
   TraceRegs tr;
   trace_init(tr);
@@ -1583,14 +1606,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
       BucketRegs br[NA];
       double wp = 0;
       bool has_next = false, update = false;
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-      {
-        slot[a] = 0;
-        lk[a].bucket = 0; lk[a].empty = 0; lk[a].pos = 0u; lk[a].kw = 0; lk[a].miss = false;
-        br[a].k = make_uint4(0u, 0u, 0u, 0u);
-        br[a].v[0] = br[a].v[1] = br[a].v[2] = br[a].v[3] = 0;
-      }
+      // (slot, lk, br are written and read only under running && has_next)
       if (running)
       {
         DIAG_STAMP(0)
@@ -1612,12 +1628,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 #pragma unroll
           for (int i = 0; i < D; ++i)
             hpre = murmur_mix(hpre, tile_coord<T>(N.tile, i, tile_quant(N.tile, i, obs[i]), j));
+          const uint32_t hpm = hpre * 0x5bd1e995u;                           // shared by the NA projections
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
-            int qa = tile_quant(N.tile, D, N.actions[a]);
-            uint32_t h = murmur_mix(hpre, tile_coord<T>(N.tile, D, qa, j));
-            h = murmur_mix(h, j);
+            uint32_t h = hpm ^ key_act[a];                                   // murmur_mix(hpre, coordinate of action a)
+            h = murmur_absorb(h, key_j);                                     // murmur_mix(h, j)
             const uint32_t hm = murmur_final(h), mem = (uint32_t)N.tile.memory;
             slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
           }
