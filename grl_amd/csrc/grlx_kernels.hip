@@ -469,16 +469,7 @@ template <int ENV> struct Env;
 // dynamics/pendulum + task/pendulum/swingup (pendulum.cpp:40-145)
 template <> struct Env<GRLX_ENV_PENDULUM> {
   static constexpr int S = 3, D = 2;
-  __device__ static __forceinline__ void eom(const double *x, double u, double *xd)
-  { // pendulum.cpp:40-49, 55-68
-    const double J = 0.000191, m = 0.055, g = 9.81, l = 0.042, b = 0.000003, K = 0.0536, R = 9.5;
-    double a = x[0], ad = x[1];
-    double add = (1 / J) * (m * g * l * psin(a) - b * ad - (K * K / R) * ad + (K / R) * u);
-    xd[0] = ad;
-    xd[1] = add;
-    xd[2] = 1;
-  }
-  // the same equations with the sine's constants held in registers by the caller (rk4_step)
+  // pendulum.cpp:40-49, 55-68; the constants are held in registers by the caller (rk4_step)
   struct Consts { SinConsts k; double invJ, mgl, b, kkr, kr; };
   __device__ static __forceinline__ Consts consts()
   {
@@ -533,17 +524,19 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
 // thetad1, thetad2, time].  No reference test pins it: parity is against the oracle only.
 template <> struct Env<GRLX_ENV_ACROBOT> {
   static constexpr int S = 5, D = 4;
-  __device__ static __forceinline__ void eom(const double *x, double u, double *xd)
+  using Consts = SinConsts;                     // held in registers across the integration loop
+  __device__ static __forceinline__ Consts consts() { return sin_consts(); }
+  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
   { // acrobot.cpp:48-79, expression for expression
     const double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
     const double theta1 = x[0], theta2 = x[1], thetad1 = x[2], thetad2 = x[3];
     const double tau = u;
     double sin2, cos2;
-    psincos(theta2, sin2, cos2);
+    psincos(theta2, k, sin2, cos2);
 
-    double phi2 = m2*lc2*g*pcos(theta1+theta2-GRLX_PI/2);
+    double phi2 = m2*lc2*g*pcos(theta1+theta2-GRLX_PI/2, k);
     double phi1 = -m2*l1*lc2*thetad2*thetad2*sin2-2*m2*l1*lc2*thetad2*thetad1*sin2 +
-                  (m1*lc1+m2*l1)*g*pcos(theta1-GRLX_PI/2)+phi2;
+                  (m1*lc1+m2*l1)*g*pcos(theta1-GRLX_PI/2, k)+phi2;
     double d2 = m2*(lc2*lc2+l1*lc2*cos2)+I2;
     double d1 = m1*lc1*lc1 + m2*(l1*l1+lc2*lc2+2*l1*lc2*cos2)+I1+I2;
     double thetadd2 = (tau+d2*phi1/d1-m2*l1*lc2*thetad2*thetad2*sin2-phi2)/
@@ -594,14 +587,16 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
 // state = [x, theta, xd, thetad, time].  parity unpinned by reference tests.
 template <> struct Env<GRLX_ENV_CART_POLE> {
   static constexpr int S = 5, D = 4;
-  __device__ static __forceinline__ void eom(const double *x, double u, double *xd)
+  using Consts = SinConsts;                     // held in registers across the integration loop
+  __device__ static __forceinline__ Consts consts() { return sin_consts(); }
+  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
   { // cart_pole.cpp:58-108.  QUIRK reproduced on purpose: :65 reads dtheta = state[3-2*end_stop_],
     // which for end_stop = 1 is state[1] -- the ANGLE, not its rate.
     const double g = 9.8, mass_cart = 1.0, mass_pole = 0.1, length = 0.5;
     const double total_mass = mass_cart + mass_pole, pole_mass_length = mass_pole * length;
     const double theta = x[1], dtheta = x[3 - 2 * 1];
     double costheta, sintheta;
-    psincos(theta, sintheta, costheta);
+    psincos(theta, k, sintheta, costheta);
     const double temp = (u + pole_mass_length * dtheta * dtheta * sintheta) / total_mass;
     const double thetaacc = (g * sintheta - costheta * temp) /
                             (length * ((4. / 3.) - mass_pole * costheta * costheta / total_mass));
@@ -860,18 +855,6 @@ template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bo
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
 // (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
-// constants an environment wants held in registers across the integration loop (default: none)
-template <int ENV> struct EnvConsts {
-  struct type {};
-  __device__ static __forceinline__ type make() { return type(); }
-  __device__ static __forceinline__ void eom(const type &, const double *x, double u, double *xd) { Env<ENV>::eom(x, u, xd); }
-};
-template <> struct EnvConsts<GRLX_ENV_PENDULUM> {
-  using type = Env<GRLX_ENV_PENDULUM>::Consts;
-  __device__ static __forceinline__ type make() { return Env<GRLX_ENV_PENDULUM>::consts(); }
-  __device__ static __forceinline__ void eom(const type &c, const double *x, double u, double *xd) { Env<GRLX_ENV_PENDULUM>::eom(c, x, u, xd); }
-};
-
 template <int ENV>
 __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
 {
@@ -881,19 +864,19 @@ __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, do
   double xd[S], k1[SD], k2[SD], k3[SD], k4[SD], t[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) { next[i] = x[i]; t[i] = x[i]; }
-  const typename EnvConsts<ENV>::type ec = EnvConsts<ENV>::make();
+  const typename Env<ENV>::Consts ec = Env<ENV>::consts();   // constants pinned in vector registers
   for (int ii = 0; ii < P.integration_steps; ++ii)
   {
-    EnvConsts<ENV>::eom(ec, next, u, xd);
+    Env<ENV>::eom(ec, next, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
-    EnvConsts<ENV>::eom(ec, t, u, xd);
+    Env<ENV>::eom(ec, t, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
-    EnvConsts<ENV>::eom(ec, t, u, xd);
+    Env<ENV>::eom(ec, t, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
-    EnvConsts<ENV>::eom(ec, t, u, xd);
+    Env<ENV>::eom(ec, t, u, xd);
 #pragma unroll
     for (int i = 0; i < SD; ++i)
     {

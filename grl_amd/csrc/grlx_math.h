@@ -162,6 +162,53 @@ __device__ __forceinline__ double psin(double x, const SinConsts &k)
   return (q & 2) ? -v : v;
 }
 
+// reduce + both kernels with supplied constants (the operations of math_reduce / math_kboth)
+__device__ __forceinline__ int math_both(double x, const SinConsts &k, double &sn, double &cs)
+{
+  const double fn = __builtin_rint(x * k.invpio2);
+  const double r0 = __builtin_fma(-fn, k.p1, x);
+  const double p  = fn * k.p2;
+  const double pl = __builtin_fma(fn, k.p2, -p);
+  const double r = r0 - p;
+  const double e = (r0 - r) - p;
+  const double t = (e - pl) - fn * k.p3;
+  const double z = r * r, z2 = z * z, z4 = z2 * z2;
+  const double sa = __builtin_fma(z, k.s[1], k.s[0]);
+  const double sb = __builtin_fma(z, k.s[3], k.s[2]);
+  const double sc = __builtin_fma(z, k.s[5], k.s[4]);
+  const double sd = __builtin_fma(z, k.s[7], k.s[6]);
+  const double P = __builtin_fma(z4, __builtin_fma(z2, sd, sc), __builtin_fma(z2, sb, sa));
+  const double ca = __builtin_fma(z, k.c[1], k.c[0]);
+  const double cb = __builtin_fma(z, k.c[3], k.c[2]);
+  const double cc = __builtin_fma(z, k.c[5], k.c[4]);
+  const double cd = __builtin_fma(z, k.c[7], k.c[6]);
+  const double Q = __builtin_fma(z4, __builtin_fma(z2, cd, cc), __builtin_fma(z2, cb, ca));
+  const double hz = 0.5 * z;
+  sn = r + __builtin_fma(z * r, P, __builtin_fma(-hz, t, t));
+  const double w = 1.0 - hz;
+  const double tail = (1.0 - w) - hz;
+  cs = w + __builtin_fma(z2, Q, __builtin_fma(-r, t, tail));
+  return (int)((long long)fn & 3);
+}
+
+__device__ __forceinline__ double pcos(double x, const SinConsts &k)
+{
+  double sn, cs;
+  const int q = math_both(x, k, sn, cs) + 1;    // cos(x) = sin(x + pi/2)
+  const double v = (q & 1) ? cs : sn;
+  return (q & 2) ? -v : v;
+}
+
+__device__ __forceinline__ void psincos(double x, const SinConsts &k, double &sn_out, double &cs_out)
+{
+  double sn, cs;
+  const int q = math_both(x, k, sn, cs);
+  const double vs = (q & 1) ? cs : sn;
+  sn_out = (q & 2) ? -vs : vs;
+  const double vc = (q & 1) ? sn : cs;
+  cs_out = ((q + 1) & 2) ? -vc : vc;
+}
+
 // Branch-free forms: callers guarantee |x| < 2^20 (checked once per environment step;
 // outside the domain the result is unspecified and the replica is flagged).
 __device__ __forceinline__ double psin(double x)
