@@ -257,6 +257,10 @@ __device__ __forceinline__ void entry_create(const Table &t, uint32_t pos, uint3
   bp->val[pos & 3u] = v;
 }
 
+// branch hint: the rare side is laid out of line, the common path falls through (a lone wave
+// has nothing to hide the fetch bubble of a taken branch behind)
+__device__ __forceinline__ bool rarely(bool c) { return __builtin_expect(c, false); }
+
 // order LDS / global accesses of the lanes of one wave (no instruction beyond waits)
 __device__ __forceinline__ void wave_sync()
 {
@@ -307,12 +311,11 @@ __device__ __forceinline__ void table_issue(const Table &t, const uint32_t (&slo
 }
 
 // way of `slot` in a loaded bucket, branch-free: *hit, and for a hit the way (0..3), the key
-// word and the value; *empty = bit mask of empty ways.  A slot occupies at most one way.
-__device__ __forceinline__ void bucket_select(const BucketRegs &b, uint32_t slot, bool &hit, uint32_t &way, uint32_t &kw, double &val, uint32_t &empty)
+// word and the value.  A slot occupies at most one way.
+__device__ __forceinline__ void bucket_select(const BucketRegs &b, uint32_t slot, bool &hit, uint32_t &way, uint32_t &kw, double &val)
 {
   const uint32_t want = slot + 1u;
   const uint32_t k0 = b.k.x & kKeyMask, k1 = b.k.y & kKeyMask, k2 = b.k.z & kKeyMask, k3 = b.k.w & kKeyMask;
-  empty = (k0 == 0u ? 1u : 0u) | (k1 == 0u ? 2u : 0u) | (k2 == 0u ? 4u : 0u) | (k3 == 0u ? 8u : 0u);
   const bool m0 = k0 == want, m1 = k1 == want, m2 = k2 == want, m3 = k3 == want;
   way = m1 ? 1u : 0u;
   kw = m1 ? b.k.y : b.k.x;
@@ -326,27 +329,47 @@ __device__ __forceinline__ void bucket_select(const BucketRegs &b, uint32_t slot
   hit = m0 || m1 || m2 || m3;
 }
 
+// bit mask of the empty ways of a loaded bucket
+__device__ __forceinline__ uint32_t bucket_empty(const uint4 &k)
+{
+  return ((k.x & kKeyMask) == 0u ? 1u : 0u) | ((k.y & kKeyMask) == 0u ? 2u : 0u) | ((k.z & kKeyMask) == 0u ? 4u : 0u) |
+         ((k.w & kKeyMask) == 0u ? 8u : 0u);
+}
+
 template <int NP>
 __device__ __forceinline__ void table_resolve(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], const BucketRegs (&br)[NP],
                                               double (&val)[NP], uint32_t &status)
 {
   bool pending[NP];
-  bool any = false;
+  bool any = false, anynot = false;
 #pragma unroll
   for (int i = 0; i < NP; ++i)
   { // straight-line selects: nothing here is worth a branch
     bool hit;
     uint32_t way, kw;
     double v;
-    bucket_select(br[i], slot[i], hit, way, kw, v, lk[i].empty);
+    bucket_select(br[i], slot[i], hit, way, kw, v);
     lk[i].pos = hit ? ((lk[i].bucket << 2) | way) : lk[i].pos;
     lk[i].kw = hit ? kw : 0u;
     val[i] = hit ? v : val[i];
-    lk[i].miss = !hit && lk[i].empty != 0u;
-    pending[i] = !hit && lk[i].empty == 0u;            // home bucket full of other slots: overflow chain
-    any = any || pending[i];
+    lk[i].miss = !hit;                                   // refined below
+    lk[i].empty = 0u;
+    pending[i] = false;
+    anynot = anynot || !hit;
   }
-  if (__any(any))
+  if (rarely(__any(anynot)))
+  { // some lane did not find its slot: empty ways decide between "create here" and "walk on"
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+    {
+      const bool nohit = lk[i].miss;
+      lk[i].empty = bucket_empty(br[i].k);
+      lk[i].miss = nohit && lk[i].empty != 0u;
+      pending[i] = nohit && lk[i].empty == 0u;           // home bucket full of other slots: overflow chain
+      any = any || pending[i];
+    }
+  }
+  if (rarely(__any(any)))
   { // rare: walk the following buckets
     for (int it = 1; it < kMaxProbe; ++it)
     {
@@ -1070,7 +1093,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   uint32_t cp = 1;                                     // occurrences of my slot inside p
   double v;                                            // final weight of p's slot after this step
   bool cross = tr.dup;                                 // does this lane see an alias that crosses lanes?
-  if (__any(shmask != 0u))
+  if (rarely(__any(shmask != 0u)))
   { // some lane's p is a shared slot: compare those few positions (usually one) with my trace and my p
     for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
     {
@@ -1085,7 +1108,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
       }
     }
   }
-  if (!__any(cross))
+  if (!rarely(__any(cross)))
   { // ---- common case: no alias crosses lanes in this wave; aliasing is a register compare inside
     // the lane; straight-line code, no exec-mask branches
     // Entries at e >= len are always invalid (pos == kInvalidPos), so validity alone decides; the
@@ -1124,7 +1147,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
     const double v1 = add_clamped(u, base, u.dW);
     const double v2 = add_clamped(u, v1, a_de);
     v = (aliased && a_upd) ? v2 : v1;
-    if (__any(stmask != 0u))
+    if (rarely(__any(stmask != 0u)))
     {
 #pragma unroll
       for (int e = 0; e < kMaxTrace; ++e)
@@ -1284,7 +1307,7 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
   bool anymiss = false;
 #pragma unroll
   for (int a = 0; a < NP; ++a) anymiss = anymiss || lk[a].miss;
-  if (__any(anymiss))
+  if (rarely(__any(anymiss)))
   { // Create the missing slots.  All lookups of this call are complete, so every lane that
     // misses into bucket B saw the same empty ways of B.  Claims are ranked in the fixed order
     // (index, tiling) through LDS: the r-th claimant of a bucket takes its r-th empty way -- no
@@ -1339,7 +1362,7 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
     wave_sync();
 #pragma unroll
     for (int a = 0; a < NP; ++a)
-      if (__any(slow[a]))
+      if (rarely(__any(slow[a])))
       { // out-of-line and rare: work on copies so that nothing of the hot path has its address taken
         Lookup tmp = lk[a];
         double tv = w[a];
@@ -1368,7 +1391,7 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
     fresh[a] = foreign && (lk[a].kw & kSharedBit) == 0u;
     anyfresh = anyfresh || fresh[a];
   }
-  if (__any(anyfresh))
+  if (rarely(__any(anyfresh)))
   {
 #pragma unroll
     for (int a = 0; a < NP; ++a)
@@ -1674,7 +1697,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
                                  shared_event = true;
                                });
           DIAG_STAMP(7)
-          if (__any(shared_event) && update) wp = value_load(tab, p_pos);
+          if (rarely(__any(shared_event)) && update) wp = value_load(tab, p_pos);
         }
         if (DEFER)
         { // Values loaded before the deferred update may be stale where that update wrote the table:
@@ -1684,7 +1707,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           bool risky = ev.n > 1u || (update && p_sh);
 #pragma unroll
           for (int a = 0; a < NA; ++a) risky = risky || (has_next && sh[a]);
-          if (__any(risky))
+          if (rarely(__any(risky)))
           {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
@@ -2069,7 +2092,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
                          if (p_pos == mp) p_sh = true;
                          shared_event = true;
                        });
-          if (__any(shared_event) && update) wpc = value_load(tabC, p_pos);
+          if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, p_pos);
           wC[0] = trace_forward(tr, posC[0], wC[0]);
         }
         if (update) wpc = trace_forward(tr, p_pos, wpc);
