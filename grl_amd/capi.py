@@ -82,6 +82,7 @@ _SIGS = {
     "grlx_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double)]),
     "grlx_table_load": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32)]),
     "grlx_export_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
+    "grlx_load_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_uint64]),
     "grlx_read_taps": (C.c_int, [C.c_void_p, _P(Tap), C.c_int, _P(C.c_int)]),
     "grlx_project": (C.c_int, [_P(TileSpec), _P(C.c_double), C.c_int, _P(C.c_uint32)]),
     "grlx_env_step": (C.c_int, [_P(Config), _P(C.c_double), _P(C.c_double), C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),

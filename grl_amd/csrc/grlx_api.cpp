@@ -209,6 +209,7 @@ struct grlx_ctx {
   uint64_t     *scratch = nullptr;        // 8 x u64
   unsigned long long *diag = nullptr;
   uint32_t     *trace_state = nullptr;
+  std::vector<double *> images;           // loaded policy images (grlx_load_weights), freed with the context
   int          n_tables = 1;
   int64_t      trials_run = 0;
 };
@@ -448,6 +449,7 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->diag);
   (void)hipFree(ctx->trace_state);
+  for (double *img : ctx->images) (void)hipFree(img);
   delete ctx;
   return GRLX_OK;
 }
@@ -616,6 +618,33 @@ int grlx_export_weights(grlx_ctx *ctx, int table, int replica, double *out)
   HIP_TRY(dout.alloc(sizeof(double) * memory));
   HIP_TRY(launch_export_weights(ctx->P, table, replica, dout.as<double>(), nullptr));
   HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * memory, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replicas, const double *dense, uint64_t count)
+{
+  if (!ctx || !dense || table < 0 || table >= ctx->n_tables) return fail(GRLX_ERR_INVALID, "bad argument");
+  const int N = ctx->P.n_replicas;
+  if (first_replica < 0 || n_replicas < 0 || first_replica > N || n_replicas > N - first_replica)
+    return fail(GRLX_ERR_INVALID, "replica range [%d, %d) outside [0, %d)", first_replica, first_replica + n_replicas, N);
+  const size_t memory = (size_t)(table == 1 ? ctx->P.tile_actor.memory : ctx->P.tile.memory);
+  if (count != (uint64_t)memory)                       // representation.h:247-252 "Configuration mismatch"
+    return fail(GRLX_ERR_INVALID, "configuration mismatch: %llu weights given, the table has %zu", (unsigned long long)count, memory);
+  if (ctx->cfg.agent == GRLX_AGENT_AC && ctx->trials_run != 0)
+    return fail(GRLX_ERR_INVALID, "actor-critic: load before the first run (the critic's trace refers to table positions)");
+  if (n_replicas == 0) return GRLX_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  double *img = nullptr;
+  if (hipMalloc((void **)&img, sizeof(double) * memory) != hipSuccess) return fail(GRLX_ERR_OOM, "no device memory for a %zu-weight policy image", memory);
+  ctx->images.push_back(img);
+  HIP_TRY(hipMemcpy(img, dense, sizeof(double) * memory, hipMemcpyHostToDevice));
+  // setParams() overwrites every weight: forget the sparse tables of these replicas; every slot is
+  // re-created on first touch from the image
+  const size_t per_replica = sizeof(Entry) << ctx->P.logC;
+  Entry *base = ctx->tables + (((size_t)table * (size_t)N + (size_t)first_replica) << ctx->P.logC);
+  HIP_TRY(hipMemset(base, 0, per_replica * (size_t)n_replicas));
+  HIP_TRY(launch_set_lazy_base(ctx->P, table, first_replica, n_replicas, img, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
   return GRLX_OK;
 }
 

@@ -45,6 +45,10 @@ struct __attribute__((aligned(16))) ReplicaState {
   int32_t  tr_len;
   int32_t  pad0;
   double   tr_total;
+  // a loaded policy (ParameterizedRepresentation {action: load}, representation.h:231-263): dense
+  // image double[memory] that replaces the drawn initial value of every slot not yet in the
+  // sparse table; NULL = the reference's random initialisation.  Shared between replicas.
+  const double *lazy_base[2];
 };
 
 struct TileParams {
@@ -105,6 +109,7 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);
 hipError_t launch_table_op(const DevParams &P, int table, int op, const int32_t *replica_dev, const uint32_t *idx_dev, int n,
                            const double *arg_dev, double alpha, double *out_dev, hipStream_t stream);
+hipError_t launch_set_lazy_base(const DevParams &P, int table, int first, int count, const double *image_dev, hipStream_t stream);
 hipError_t launch_export_weights(const DevParams &P, int table, int replica, double *out_dev, hipStream_t stream);
 hipError_t launch_get_weights(const DevParams &P, int table, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
 hipError_t launch_math(int op, const double *x, const double *y, int n, double *out, hipStream_t stream);

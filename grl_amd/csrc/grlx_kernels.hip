@@ -114,6 +114,13 @@ __device__ inline double lazy_weight(uint64_t tl0, const LinearParams &lp, uint3
   return lp.init_min + lcg_double(x) * lp.init_range;
 }
 
+// initial value of a slot: the loaded image when there is one, else the reference's draw
+__device__ inline double initial_weight(const ReplicaState &rs, int table, const LinearParams &lp, uint32_t slot)
+{
+  const double *img = rs.lazy_base[table];
+  return img ? img[slot] : lazy_weight(rs.TL0, lp, slot);
+}
+
 __device__ __forceinline__ double lazy_weight_lds(const uint64_t *sh_jump, uint64_t tl0, const LinearParams &lp, uint32_t slot)
 {
   uint64_t x = lcg_next(lcg_jump_lds(sh_jump, tl0, lp.draws_before + (uint64_t)slot));
@@ -464,7 +471,7 @@ __device__ __noinline__ void table_insert_serial(const Table &t, bool todo, uint
 }
 
 // single lookup-or-create (fine-grained operators): lane = tiling
-__device__ inline void table_probe(const Table &t, const LinearParams &lp, uint64_t tl0, bool active,
+__device__ inline void table_probe(const Table &t, const LinearParams &lp, const ReplicaState &rs, int table, bool active,
                                    uint32_t slot, uint32_t &pos, double &val, uint32_t &status, uint32_t &inserted)
 {
   uint32_t sl[1] = {slot};
@@ -476,7 +483,7 @@ __device__ inline void table_probe(const Table &t, const LinearParams &lp, uint6
   double w0 = 0;
   if (__any(miss))
   {
-    if (miss) w0 = lazy_weight(tl0, lp, slot);
+    if (miss) w0 = initial_weight(rs, table, lp, slot);
     table_insert_serial(t, miss, slot, (uint32_t)(threadIdx.x & 31), w0, lk[0], v[0], status, inserted);
   }
   // keep the "touched by a second tiling" bit current (the fused kernel relies on it)
@@ -1296,7 +1303,7 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
 // on_share(mp): called in every lane of the group for each slot position that just became shared.
 // table_get_finish: the part after the loads of table_issue (lk, br).
 template <int NP, typename OnShare>
-__device__ __forceinline__ void table_get_finish(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
+__device__ __forceinline__ void table_get_finish(const Table &tab, const LinearParams &lp, const ReplicaState &rs, int table, const uint32_t (&slot)[NP],
                                                  Lookup (&lk)[NP], const BucketRegs (&br)[NP],
                                                  uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
                                                  uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
@@ -1324,7 +1331,12 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
       claims[a] = (uint32_t)((__ballot(lk[a].miss) >> (16 * g)) & 0xFFFFull);
       w0[a] = 0;
       slow[a] = false;
-      if (lk[a].miss) w0[a] = lazy_weight_lds(sh_jump, tl0, lp, slot[a]);
+      if (lk[a].miss)
+      { // a loaded policy image replaces the drawn initial value (read here, on the rare path, so
+        // that the hot path carries no pointer for it)
+        const double *img = rs.lazy_base[table];
+        w0[a] = img ? img[slot[a]] : lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
+      }
     }
     wave_sync();
 #pragma unroll
@@ -1428,7 +1440,7 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
 }
 
 template <int NP, typename OnShare>
-__device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, uint64_t tl0, const uint32_t (&slot)[NP],
+__device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, const ReplicaState &rs, int table, const uint32_t (&slot)[NP],
                                           uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
                                           uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
                                           uint32_t &status, uint32_t &inserted, OnShare on_share)
@@ -1436,7 +1448,7 @@ __device__ __forceinline__ void table_get(const Table &tab, const LinearParams &
   Lookup lk[NP];
   BucketRegs br[NP];
   table_issue<NP>(tab, slot, lk, br);
-  table_get_finish<NP>(tab, lp, tl0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, on_share);
+  table_get_finish<NP>(tab, lp, rs, table, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, on_share);
 }
 
 // in-kernel stamps (diagnostic instantiation only; cdna_hip_programming.md section 7)
@@ -1539,7 +1551,6 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 #pragma unroll
   for (int i = 0; i < S; ++i) x[i] = RS.x[i];
   uint64_t G = RS.G, TL = RS.TL, S1 = RS.S1;
-  const uint64_t TL0 = RS.TL0;
   double eps_decay = RS.eps_decay;
   int64_t tt = RS.tt, ss = RS.ss;
   uint64_t test_steps = RS.test_steps;
@@ -1688,7 +1699,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (has_next)
         {
           bool shared_event = false;
-          table_get_finish<NA>(tab, N.lin, TL0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+          table_get_finish<NA>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
                                [&](uint32_t mp) {
                                  // a weight evicted a moment ago and not stored yet: store it now, the finder reads it
                                  if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tab, mp, ev.val);
@@ -1992,7 +2003,6 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
 #pragma unroll
   for (int i = 0; i < S; ++i) x[i] = RS.x[i];
   uint64_t G = RS.G, TL = RS.TL;
-  const uint64_t TL0 = RS.TL0;
   double ac_decay = RS.ac_decay, ac_noise = RS.ac_noise;
   int64_t tt = RS.tt, ss = RS.ss;
   uint64_t test_steps = RS.test_steps;
@@ -2080,13 +2090,13 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         }
         if (has_next)
         {
-          table_get<1>(tabA, P.lin_actor, TL0, slotA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
+          table_get<1>(tabA, P.lin_actor, RS, 1, slotA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
                        [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
         }
         if (need_critic)
         {
           bool shared_event = false;
-          table_get<1>(tabC, P.lin, TL0, slotC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
+          table_get<1>(tabC, P.lin, RS, 0, slotC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
                        [&](uint32_t mp) {
                          trace_share_event(tr, tabC, mp);
                          if (p_pos == mp) p_sh = true;
@@ -2420,7 +2430,7 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
     double w = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const LinearParams &lp = table == 1 ? P.lin_actor : P.lin;
-    table_probe(tab, lp, P.states[r].TL0, valid, slot, pos, w, status, inserted);
+    table_probe(tab, lp, P.states[r], table, valid, slot, pos, w, status, inserted);
     sh[lane] = w;
     shp[lane] = valid ? pos : kInvalidPos;
     wave_sync();
@@ -2474,7 +2484,7 @@ __global__ void get_weights_kernel(DevParams P, int table, int replica, const ui
   const Table tab = table_of(P, table, replica);
   uint32_t slot = slots[i];
   uint32_t b = table_home(tab, slot);
-  double v = lazy_weight(P.states[replica].TL0, table == 1 ? P.lin_actor : P.lin, slot);
+  double v = initial_weight(P.states[replica], table, table == 1 ? P.lin_actor : P.lin, slot);
   for (int it = 0; it < kMaxProbe; ++it)
   {
     const BucketRegs br = bucket_load(tab, b);
@@ -2487,13 +2497,30 @@ __global__ void get_weights_kernel(DevParams P, int table, int replica, const ui
   out[i] = v;
 }
 
+// {action: load}: replicas [first, first+count) take `image` as the initial value of every slot of
+// `table` and forget what they had learned in it (their sparse tables are cleared by the caller)
+__global__ void set_lazy_base_kernel(DevParams P, int table, int first, int count, const double *image)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  ReplicaState &rs = P.states[first + i];
+  rs.lazy_base[table] = image;
+  rs.n_slots[table] = 0u;
+}
+
+hipError_t launch_set_lazy_base(const DevParams &P, int table, int first, int count, const double *image_dev, hipStream_t stream)
+{
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(set_lazy_base_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, P, table, first, count, image_dev);
+  return hipGetLastError();
+}
+
 // dense export of a table: out[slot] for every reference slot (grid-stride)
 __global__ void export_weights_kernel(DevParams P, int table, int replica, double *out)
 {
   const Table tab = table_of(P, table, replica);
   const LinearParams &lp = table == 1 ? P.lin_actor : P.lin;
   const uint32_t memory = (uint32_t)(table == 1 ? P.tile_actor.memory : P.tile.memory);
-  const uint64_t tl0 = P.states[replica].TL0;
   for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < memory; slot += gridDim.x * blockDim.x)
   {
     uint32_t b = table_home(tab, slot);
@@ -2508,7 +2535,7 @@ __global__ void export_weights_kernel(DevParams P, int table, int replica, doubl
       if (empty != 0u) break;
       b = (b + 1u) & tab.bmask;
     }
-    if (!found) v = lazy_weight(tl0, lp, slot);
+    if (!found) v = initial_weight(P.states[replica], table, lp, slot);
     out[slot] = v;
   }
 }

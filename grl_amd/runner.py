@@ -124,6 +124,14 @@ class Runner:
         capi.check(self.lib.grlx_export_weights(self._ctx, table, replica, _ptr(out, C.c_double)))
         return out
 
+    def load_weights(self, dense, table: int = 0, first_replica: int = 0, n_replicas=None):
+        """ParameterizedRepresentation {action: load} (representation.h:231-263): every weight of `table`
+        of the given replicas becomes dense[slot]; nothing else of the experiment changes."""
+        dense = np.ascontiguousarray(dense, dtype=np.float64)
+        if n_replicas is None:
+            n_replicas = self.cfg.n_replicas - first_replica
+        capi.check(self.lib.grlx_load_weights(self._ctx, table, first_replica, n_replicas, _ptr(dense, C.c_double), dense.size))
+
     def table_load(self, replica: int, table: int = 0) -> int:
         n = C.c_uint32()
         capi.check(self.lib.grlx_table_load(self._ctx, table, replica, C.byref(n)))

@@ -161,7 +161,11 @@ int  grlx_curve_stats(grlx_ctx *ctx, int first, int count, double *out_dev, void
 int  grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps);
 
 /* --- diagnostics: a separately compiled, stamped build of the rollout kernel
- * (s_memtime per phase).  Its run time is NOT representative; only the shares. */
+ * (s_memtime per phase).  Its run time is NOT representative; only the shares.
+ * enable = 1: the instantiation that applies each TD update in place (the one
+ * that also records taps); enable = 2: the production ordering (update applied
+ * one pass later, under the next step's table loads; pendulum with 3 actions
+ * only); 0: off. */
 int  grlx_set_diag(grlx_ctx *ctx, int enable);
 int  grlx_read_diag(grlx_ctx *ctx, uint64_t *out /*[waves][8] cycle sums*/, int cap_waves, int *n_waves);
 
@@ -172,6 +176,15 @@ int  grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4] /* G, TL, S1, S2 *
  * representation.h:201-263): current weights of the given reference slots. */
 int  grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out);
 int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used);
+/* Replaces ParameterizedRepresentation's {action: load} (representation.h:231-263, driven by
+ * experiment/online_learning:load_file, online_learning.cpp:140-150): setParams() with the raw
+ * little-endian double[memory] image of a .dat file.  Every weight of `table` of the replicas
+ * [first_replica, first_replica + n_replicas) becomes dense[slot]; RNG streams, environment state
+ * and counters are untouched, as in the reference.  The image (count must equal the table's
+ * memory, else GRLX_ERR_INVALID like the reference's "Configuration mismatch") is copied once to
+ * the device and shared by those replicas; their sparse tables are cleared and re-created on
+ * first touch from it.  Actor-critic contexts accept it only before the first grlx_run. */
+int  grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replicas, const double *dense, uint64_t count);
 /* Replaces ParameterizedRepresentation's {action: save} (representation.h:201-229): the DENSE
  * parameter vector double[memory] of one replica's table, little-endian as grl's .dat files hold it
  * (untouched slots carry their lazily computed initial value).  out: host buffer of `memory` doubles. */

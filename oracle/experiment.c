@@ -621,6 +621,16 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
 /* ------------------------------------------------------------ accessors -- */
 void orc_get_stats(const orc_exp *e, orc_stats *out) { *out = e->stats; }
 const double *orc_weights(const orc_exp *e, int table) { return (table == 0 || table == 1) ? e->w[table] : NULL; }
+
+/* ParameterizedRepresentation {action: load} (representation.h:231-263): setParams() overwrites
+ * every weight of the table; nothing else of the experiment changes. */
+int orc_set_weights(orc_exp *e, int table, const double *w, size_t n)
+{
+  const size_t mem = (size_t)(table == 1 ? e->spec.actor_projector.memory : e->spec.projector.memory);
+  if ((table != 0 && table != 1) || !e->w[table] || !w || n != mem) return -1;
+  memcpy(e->w[table], w, n * sizeof(double));
+  return 0;
+}
 void orc_get_state(const orc_exp *e, double *state) { memcpy(state, e->state, sizeof(double) * (size_t)orc_env_state_dims(e->spec.env)); }
 void orc_rng_states(const orc_exp *e, uint64_t out[4]) { out[0] = e->G.x; out[1] = e->TL.x; out[2] = e->S1.x; out[3] = e->S2.x; }
 

@@ -184,6 +184,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
 
 void          orc_get_stats(const orc_exp *e, orc_stats *out);
 const double *orc_weights(const orc_exp *e, int table);        /* table 0: Q/critic, 1: actor */
+/* {action: load} of a representation (representation.h:231-263): overwrite all n = memory weights; 0 or -1 */
+int           orc_set_weights(orc_exp *e, int table, const double *w, size_t n);
 void          orc_get_state(const orc_exp *e, double *state);  /* current env state           */
 void          orc_rng_states(const orc_exp *e, uint64_t out[4]); /* G, TL, S1, S2              */
 

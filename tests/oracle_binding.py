@@ -96,6 +96,7 @@ def load():
     L.orc_run.argtypes = [C.c_void_p, C.c_int, P(Row), C.c_int, P(Tap), C.c_int, P(C.c_int)]; L.orc_run.restype = C.c_int
     L.orc_get_stats.argtypes = [C.c_void_p, P(Stats)]
     L.orc_weights.argtypes = [C.c_void_p, C.c_int]; L.orc_weights.restype = P(C.c_double)
+    L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_double), C.c_size_t]; L.orc_set_weights.restype = C.c_int
     L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
     L.orc_rng_states.argtypes = [C.c_void_p, P(C.c_uint64)]
     L.orc_format_row.argtypes = [P(Row), C.c_char_p, C.c_size_t]; L.orc_format_row.restype = C.c_int
@@ -155,6 +156,15 @@ class Experiment:
     def weights(self, slots, table=0):
         p = self.L.orc_weights(self.h, table)
         return np.array([p[int(i)] for i in slots], dtype=np.float64)
+
+    def all_weights(self, table=0):
+        n = self.spec.actor_projector.memory if table == 1 else self.spec.projector.memory
+        return np.ctypeslib.as_array(self.L.orc_weights(self.h, table), shape=(n,)).copy()
+
+    def set_weights(self, w, table=0):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        if self.L.orc_set_weights(self.h, table, w.ctypes.data_as(C.POINTER(C.c_double)), w.size) != 0:
+            raise ValueError("orc_set_weights: wrong table or size")
 
     def state(self):
         st = (C.c_double * MAX_STATE)()

@@ -686,3 +686,67 @@ def test_deferred_update_equals_in_place_and_oracle(grlx, memory, agent):
             assert_bit_equal(rew, [x.reward for x in rows], f"{which}: returns of seed {seed}")
             assert_bit_equal(g[1][k], e.weights(slots), f"{which}: weights of seed {seed}")
             assert g[2][k] == list(e.rng())[:3], which
+
+
+# --------------------------------------------------- policy load (.dat) ----
+@pytest.mark.parametrize("agent", [0, 1])
+def test_load_weights_equals_oracle_set_params(grlx, agent):
+    """ParameterizedRepresentation {action: load} (representation.h:231-263): a policy trained
+    elsewhere is loaded into replicas 1..3 in mid-run (what they had learned is discarded, RNG
+    streams and counters go on); replicas 0 and 4 are not touched.  Rows, RNG positions and the
+    complete dense tables must equal the oracle's setParams() at the same point."""
+    src = ob.Experiment(ob.pendulum_sarsa_spec(agent=agent), seed=21)
+    src.run(33)
+    image = src.all_weights()
+    seeds = [5, 6, 7, 8, 9]
+    cfg = grlx.pendulum_sarsa_config(len(seeds), agent=agent)
+    r = grlx.Runner(cfg, seeds)
+    r.run(11); r.sync()
+    r.load_weights(image, first_replica=1, n_replicas=3)
+    r.run(22); r.sync()
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(agent=agent), seed=seed)
+        rows, _ = e.run(11)
+        if 1 <= k <= 3:
+            e.set_weights(image)
+        rows2, _ = e.run(22)
+        rows = list(rows) + list(rows2)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3]
+        if k in (0, 2):
+            assert_bit_equal(r.export_weights(k), e.all_weights(), f"dense table of replica {k}")
+    with pytest.raises(grlx.capi.GrlxError, match="mismatch"):
+        r.load_weights(image[:-1])
+    with pytest.raises(grlx.capi.GrlxError, match="replica range"):
+        r.load_weights(image, first_replica=3, n_replicas=3)
+    r.close()
+
+
+def test_load_weights_actor_critic(grlx):
+    """Both tables of an actor-critic graph loaded before the first run (critic = table 0, actor = 1)."""
+    from tests import configs
+    cfg, spec = configs.cart_pole_ac(grlx, 3)
+    src = ob.Experiment(spec, seed=77)
+    src.run(12)
+    critic, actor = src.all_weights(0), src.all_weights(1)
+    seeds = [41, 42, 43]
+    r = grlx.Runner(cfg, seeds)
+    r.load_weights(critic, table=0)
+    r.load_weights(actor, table=1)
+    r.run(12); r.sync()
+    rng = np.random.default_rng(23)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        e.set_weights(critic, 0); e.set_weights(actor, 1)
+        rows, _ = e.run(12)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        slots = rng.integers(0, 8388608, 5000).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots, table=0), e.weights(slots, table=0), "critic")
+        assert_bit_equal(r.weights(k, slots, table=1), e.weights(slots, table=1), "actor")
+    with pytest.raises(grlx.capi.GrlxError, match="before the first run"):
+        r.load_weights(critic, table=0)
+    r.close()
