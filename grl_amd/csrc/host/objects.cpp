@@ -630,8 +630,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       throw Exception(path() + ": the accelerated path needs environment/modeled, agent/td and agent/fixed");
     if (save_every != "never" && save_every != "run")
       throw Exception(path() + ": save_every must be never or run on the accelerated path (test/trial would stop the device every episode)");
-    if (config["exporter"].ptr() || !load_file.empty() || (int)config["rate"] != 0 || test_trials != 1 || steps != 0)
-      throw Exception(path() + ": exporter/load_file/rate/test_trials/steps are outside the accelerated path (a dense 64 MiB policy cannot be loaded into the sparse tables)");
+    if (config["exporter"].ptr() || (int)config["rate"] != 0 || test_trials != 1 || steps != 0)
+      throw Exception(path() + ": exporter/rate/test_trials/steps are outside the accelerated path");
   }
 
   // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernels make is checked
@@ -740,6 +740,17 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     c->trace = pred->trace ? pred->trace->kind() : GRLX_TRACE_NONE;
   }
 
+  // the parameterized representations of the agent in table order: 0 = Q / critic, 1 = actor
+  std::vector<const Configurable *> representations() const
+  {
+    std::vector<const Configurable *> reprs;
+    if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
+    { reprs.push_back(ac->critic->representation); reprs.push_back(ac->representation); }
+    else
+      reprs.push_back(dynamic_cast<const QPolicy *>(agent->policy)->representation);
+    return reprs;
+  }
+
   std::vector<double> run(const RunOptions &opt) override
   {
     if (trials <= 0) throw Exception(path() + ": trials must be > 0 (the reference's trials: 0 runs forever)");
@@ -761,6 +772,32 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i + (int64_t)(rr - run_offset) * opt.replicas;
       grlx_ctx *ctx = nullptr;
       if (grlx_create(&c, seeds.data(), &ctx) != GRLX_OK) throw Exception(grlx_last_error());
+      // Load policy every run (online_learning.cpp:140-150 -> ParameterizedRepresentation {action: load},
+      // representation.h:231-263): <load_file with $run -> rr>-<config path with '/'->'_'>.dat, raw
+      // double[memory]; a missing or wrong-sized file is a warning, not an error, as in the reference.
+      // All clones of a run read the same file (multi.cpp does not touch load_file).
+      if (!load_file.empty())
+      {
+        std::string base = load_file + "-";
+        for (size_t at; (at = base.find("$run")) != std::string::npos;) base.replace(at, 4, std::to_string(rr));
+        log(2, "Loading policy: " + base);
+        const std::vector<const Configurable *> reprs = representations();
+        for (size_t tb = 0; tb < reprs.size(); ++tb)
+        {
+          std::string cfg_path = reprs[tb]->path();
+          std::replace(cfg_path.begin(), cfg_path.end(), '/', '_');
+          const std::string file = base + cfg_path + ".dat";
+          const size_t memory = (size_t)(tb == 1 ? c.actor_projector.memory : c.projector.memory);
+          std::ifstream f(file, std::ios::binary | std::ios::ate);
+          if (!f) { log(1, "Could not open '" + file + "' for reading"); continue; }
+          if ((size_t)f.tellg() != memory * sizeof(double)) { log(1, "Configuration mismatch for '" + file + "'"); continue; }
+          std::vector<double> dense(memory);
+          f.seekg(0);
+          if (!f.read(reinterpret_cast<char *>(dense.data()), (std::streamsize)(memory * sizeof(double)))) { log(1, "Could not read '" + file + "'"); continue; }
+          if (grlx_load_weights(ctx, (int)tb, 0, opt.replicas, dense.data(), (uint64_t)memory) != GRLX_OK)
+          { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
+        }
+      }
       auto start = std::chrono::steady_clock::now();
       int rc = grlx_run(ctx, trials, nullptr);
       if (rc == GRLX_OK) rc = grlx_sync(ctx, nullptr);
@@ -798,11 +835,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       // representation.h:201-229): raw double[memory] to <output>-run<rr>-<config path with '/'->'_'>.dat
       if (save_every == "run" && !output.empty())
       {
-        std::vector<const Configurable *> reprs;          // table 0 = Q / critic, table 1 = actor
-        if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
-        { reprs.push_back(ac->critic->representation); reprs.push_back(ac->representation); }
-        else
-          reprs.push_back(dynamic_cast<const QPolicy *>(agent->policy)->representation);
+        const std::vector<const Configurable *> reprs = representations();
         for (size_t tb = 0; tb < reprs.size(); ++tb)
           for (int i = 0; i < opt.replicas; ++i)
           {

@@ -592,6 +592,50 @@ def test_dat_policy_export_matches_dense_table(grlx, tmp_path):
     assert_bit_equal(got, dense, ".dat parameters")
 
 
+def test_deployer_load_file_round_trip(grlx, tmp_path):
+    """experiment/online_learning:load_file (online_learning.cpp:140-150): the .dat a first run saved is
+    loaded by a second run with another seed; its rows equal the oracle's after setParams() of the
+    first run's table.  A missing file and a file of the wrong size are warnings, as in the reference."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    a = tmp_path / "a.yaml"
+    a.write_text(text.replace("save_every: never", "save_every: run").replace("trials: 2000", "trials: 33")
+                 .replace("output: pendulum-sarsa-tc", "output: first"))
+    res = subprocess.run([grlxd, "-s", "7", "-q", str(a)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert (tmp_path / "first-run0-experiment_agent_policy_representation.dat").exists()
+    b = tmp_path / "b.yaml"
+    b.write_text(text.replace('load_file: ""', "load_file: first-run$run").replace("trials: 2000", "trials: 22")
+                 .replace("output: pendulum-sarsa-tc", "output: second"))
+    res = subprocess.run([grlxd, "-s", "9", "-l", "-q", str(b)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    src = ob.Experiment(ob.pendulum_sarsa_spec(), seed=7)
+    src.run(33)
+    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_PORTABLE), seed=9)
+    e.set_weights(src.all_weights())
+    rows, _ = e.run(22)
+    assert (tmp_path / "second-0.txt").read_text() == e.format_rows(rows)
+    # missing file: warning, the run goes on with the random initialisation
+    c = tmp_path / "c.yaml"
+    c.write_text(text.replace('load_file: ""', "load_file: nowhere").replace("trials: 2000", "trials: 11")
+                 .replace("output: pendulum-sarsa-tc", "output: third"))
+    res = subprocess.run([grlxd, "-s", "9", "-l", "-q", str(c)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "Could not open 'nowhere-experiment_agent_policy_representation.dat'" in res.stderr
+    fresh = ob.Experiment(ob.pendulum_sarsa_spec(), seed=9)
+    rows, _ = fresh.run(11)
+    assert (tmp_path / "third-0.txt").read_text() == fresh.format_rows(rows)
+    # wrong size: "Configuration mismatch" warning
+    (tmp_path / "short-experiment_agent_policy_representation.dat").write_bytes(b"\0" * 800)
+    d = tmp_path / "d.yaml"
+    d.write_text(text.replace('load_file: ""', "load_file: short").replace("trials: 2000", "trials: 11")
+                 .replace("output: pendulum-sarsa-tc", "output: fourth"))
+    res = subprocess.run([grlxd, "-s", "9", "-l", "-q", str(d)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "Configuration mismatch" in res.stderr
+    assert (tmp_path / "fourth-0.txt").read_text() == fresh.format_rows(rows)
+
+
 # ----------------------------------------------------------- edge cases -----
 def test_empty_batches_and_bad_arguments(grlx):
     """n = 0 is legal everywhere; out-of-range arguments come back as GRLX_ERR_INVALID, never a crash."""

@@ -75,3 +75,13 @@ def test_instantiates_actor_critic_yaml(grlxd, tmp_path):
     text = open(yaml).read()
     swapped = text.replace("    policy:\n      type: mapping/policy/action\n      sigma: [ 5 ]", "    policy_moved:\n      type: mapping/policy/action\n      sigma: [ 5 ]")
     assert swapped != text
+
+
+def test_load_file_is_accepted_and_needs_a_device(grlxd, tmp_path):
+    """load_file is part of the accelerated path (grlx_load_weights); without a GPU the deployer still
+    stops at "no HIP device", never at the configuration."""
+    from grl_amd import capi
+    res = run(grlxd, ["-s", "1", "-l", "-q", _variant(tmp_path, 'load_file: ""', "load_file: some-policy-run$run")], tmp_path)
+    assert "outside the accelerated path" not in res.stderr
+    if capi.load().grlx_device_count() == 0:
+        assert res.returncode == 1 and "no HIP device" in res.stderr
