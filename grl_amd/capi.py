@@ -35,7 +35,7 @@ class Config(C.Structure):
                 ("projector", TileSpec), ("representation", LinearSpec),
                 ("epsilon", C.c_double), ("decay_rate", C.c_double), ("decay_min", C.c_double),
                 ("alpha", C.c_double), ("gamma", C.c_double), ("lambda_", C.c_double),
-                ("trace", C.c_int32), ("reserved0", C.c_int32),
+                ("trace", C.c_int32), ("tap_starts", C.c_int32),
                 ("actor_projector", TileSpec), ("actor_representation", LinearSpec),
                 ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double), ("ac_step_limit", C.c_double),
@@ -75,6 +75,7 @@ _SIGS = {
     "grlx_read_diag": (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int, _P(C.c_int)]),
     "grlx_rows": (C.c_int, [C.c_void_p]),
     "grlx_read_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64), _P(C.c_double)]),
+    "grlx_read_row_times": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_curve_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grlx_step_counts": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),
     "grlx_get_env_state": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double)]),

@@ -202,7 +202,7 @@ struct grlx_ctx {
   int         S, D;
   Entry        *tables = nullptr;
   ReplicaState *states = nullptr;
-  double       *row_reward = nullptr;
+  double       *row_reward = nullptr, *row_time = nullptr;
   int64_t      *row_steps = nullptr, *row_trial = nullptr;
   grlx_tap     *taps = nullptr;
   uint32_t     *tap_count = nullptr;
@@ -356,6 +356,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.no_specialisation = cfg->force_generic;
   P.tap_replica = cfg->tap_replica;
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
+  P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
 
   const size_t n_tables = cfg->agent == GRLX_AGENT_AC ? 2 : 1;
   ctx->n_tables = (int)n_tables;
@@ -377,6 +378,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMalloc((void **)&ctx->row_steps, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->row_trial, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMemset(ctx->row_reward, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMalloc((void **)&ctx->row_time, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMemset(ctx->row_time, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));
   CTX_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
@@ -426,6 +429,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tables = ctx->tables;
   P.states = ctx->states;
   P.row_reward = ctx->row_reward;
+  P.row_time = ctx->row_time;
   P.row_steps = ctx->row_steps;
   P.row_trial = ctx->row_trial;
   P.taps = ctx->taps;
@@ -442,6 +446,7 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->tables);
   (void)hipFree(ctx->states);
   (void)hipFree(ctx->row_reward);
+  (void)hipFree(ctx->row_time);
   (void)hipFree(ctx->row_steps);
   (void)hipFree(ctx->row_trial);
   (void)hipFree(ctx->taps);
@@ -548,6 +553,17 @@ int grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count, int64_t *tr
   if (reward) HIP_TRY(hipMemcpy2D(reward, sizeof(double), ctx->row_reward + at, N * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));
   if (steps) HIP_TRY(hipMemcpy2D(steps, sizeof(int64_t), ctx->row_steps + at, N * sizeof(int64_t), sizeof(int64_t), (size_t)count, hipMemcpyDeviceToHost));
   if (trial) HIP_TRY(hipMemcpy2D(trial, sizeof(int64_t), ctx->row_trial + at, N * sizeof(int64_t), sizeof(int64_t), (size_t)count, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, double *episode_time)
+{
+  if (!ctx || !episode_time || replica < 0 || replica >= ctx->P.n_replicas || first < 0 || count < 0 || first + count > ctx->P.max_rows)
+    return fail(GRLX_ERR_INVALID, "bad argument");
+  const size_t N = (size_t)ctx->P.n_replicas;
+  if (count == 0) return GRLX_OK;
+  HIP_TRY(hipMemcpy2D(episode_time, sizeof(double), ctx->row_time + (size_t)first * N + (size_t)replica, N * sizeof(double), sizeof(double),
+                      (size_t)count, hipMemcpyDeviceToHost));
   return GRLX_OK;
 }
 

@@ -88,11 +88,13 @@ struct DevParams {
   ReplicaState *states;
   // rows: [row][replica]
   double  *row_reward;
+  double  *row_time;            // episode time of the row's trial = sum of tau (= steps: discrete_time)
   int64_t *row_steps, *row_trial;
   int32_t  max_rows;
   // taps
   grlx_tap *taps;
   int32_t  tap_replica, tap_capacity;
+  int32_t  tap_starts;          // also record the start pass of every trial (terminal = -1)
   uint32_t *tap_count;
   // diagnostic build only: per-wave cycle sums of 8 phases (NULL = production kernel)
   unsigned long long *diag_out;

@@ -1853,7 +1853,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
         DIAG_STAMP(5)
         // -------- tap (debug / parity tests; only the immediate-update instantiation records taps)
-        if (!DEFER && tapped && !first)
+        if (!DEFER && tapped && (!first || P.tap_starts))
         {
           uint32_t n = *P.tap_count;
           if (n < (uint32_t)P.tap_capacity)
@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             {
               tp->test = test;
               tp->action_index = has_next ? a_next : action_index;
-              tp->terminal = terminal;
+              tp->terminal = first ? -1 : terminal;
               tp->trace_len = tr_len_ref;
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
@@ -1914,6 +1914,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         {
           size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
           P.row_reward[at] = total_reward;
+          P.row_time[at] = time;
           P.row_steps[at] = ss;
           P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
         }
@@ -2188,7 +2189,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         }
 
         // -------- tap
-        if (tapped && !first)
+        if (tapped && (!first || P.tap_starts))
         {
           uint32_t n = *P.tap_count;
           if (n < (uint32_t)P.tap_capacity)
@@ -2200,7 +2201,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
             {
               tp->test = test;
               tp->action_index = 0;
-              tp->terminal = terminal;
+              tp->terminal = first ? -1 : terminal;
               tp->trace_len = tr.len;
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? a_next : action;
@@ -2242,6 +2243,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         {
           size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
           P.row_reward[at] = total_reward;
+          P.row_time[at] = time;
           P.row_steps[at] = ss;
           P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
         }

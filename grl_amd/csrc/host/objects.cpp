@@ -807,10 +807,11 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       const int n = grlx_rows(ctx);
       std::vector<int64_t> trial((size_t)n), stp((size_t)n);
       std::vector<double> reward((size_t)n);
-      const double episode_time = c.control_step * std::floor(c.timeout / c.control_step + 1);   // nominal (timeout episodes)
+      std::vector<double> episode_time((size_t)n);     // total_time: sum of tau = steps of the trial (discrete_time, modeled.cpp:209-212)
       for (int i = 0; i < opt.replicas; ++i)
       {
         grlx_read_rows(ctx, i, 0, n, trial.data(), stp.data(), reward.data());
+        grlx_read_row_times(ctx, i, 0, n, episode_time.data());
         std::ostringstream name;                       // <output>-<run><identity>.txt, identity "@i" for clones (multi.cpp:52-56)
         name << output << "-" << rr;
         if (opt.replicas > 1) name << "@" << i;
@@ -824,8 +825,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
             oss << std::setw(15) << trial[(size_t)k] << std::setw(15) << stp[(size_t)k] << std::setw(15) << reward[(size_t)k];
           else                                         // online_learning.cpp:243
             oss << std::setw(15) << trial[(size_t)k] << std::setw(15) << stp[(size_t)k] << std::setw(15) << std::setprecision(3) << std::fixed
-                << reward[(size_t)k] << std::setw(15) << std::setprecision(3) << episode_time << std::setw(15) << std::setprecision(3)
-                << reward[(size_t)k] / episode_time << std::setw(15) << std::setprecision(3) << wall;
+                << reward[(size_t)k] << std::setw(15) << std::setprecision(3) << episode_time[(size_t)k] << std::setw(15) << std::setprecision(3)
+                << reward[(size_t)k] / episode_time[(size_t)k] << std::setw(15) << std::setprecision(3) << wall;
           if (ofs.is_open()) ofs << oss.str() << std::endl;
           if (i == 0 && opt.print_rows) std::cout << oss.str() << std::endl;
         }

@@ -93,6 +93,14 @@ class Runner:
                                            _ptr(steps, C.c_int64), _ptr(reward, C.c_double)))
         return trial, steps, reward
 
+    def row_times(self, replica: int, first: int = 0, count: int = None):
+        """Episode time of each row's trial (column 4, online_learning.cpp:243): steps under discrete_time."""
+        if count is None:
+            count = self.n_rows() - first
+        out = np.zeros(count, np.float64)
+        capi.check(self.lib.grlx_read_row_times(self._ctx, replica, first, count, _ptr(out, C.c_double)))
+        return out
+
     def curve_stats(self, out_dev_ptr: int, first: int, count: int, stream: int = 0):
         capi.check(self.lib.grlx_curve_stats(self._ctx, first, count, C.c_void_p(out_dev_ptr), C.c_void_p(stream)))
 

@@ -88,7 +88,7 @@ typedef struct {
   double   epsilon, decay_rate, decay_min;    /* sampler/epsilon_greedy                         */
   double   alpha, gamma, lambda;              /* predictor                                      */
   int32_t  trace;                             /* GRLX_TRACE_*                                   */
-  int32_t  reserved0;
+  int32_t  tap_starts;                /* 1: taps also record the start of every trial (terminal = -1): the rows of a transition log */
   /* actor-critic only */
   grlx_tile_spec   actor_projector;
   grlx_linear_spec actor_representation;
@@ -111,7 +111,8 @@ typedef struct {
 
 typedef struct grlx_ctx grlx_ctx;
 
-/* per-step record of the tapped replica (debug / parity tests) */
+/* per-step record of the tapped replica (debug / parity tests / transition log).  A record with
+ * terminal = -1 (only with tap_starts) is the start of a trial: first observation and first action. */
 typedef struct {
   int32_t  test, action_index, terminal, trace_len;
   double   obs[GRLX_MAX_DIMS];
@@ -151,6 +152,9 @@ int  grlx_rows(grlx_ctx *ctx);
  * copy rows [first, first+count) of `replica` to host arrays (columns 1-3). */
 int  grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count,
                     int64_t *trial, int64_t *steps, double *reward);
+/* column 4 of the same rows (online_learning.cpp:243 `total_time`): the sum of the tau returned by
+ * Environment::step over the trial -- under discrete_time (modeled.cpp:209-212) the number of steps. */
+int  grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, double *episode_time);
 /* Device-side learning-curve statistics over this GPU's replicas, written to a
  * DEVICE buffer out[count][3] = {sum reward, sum reward^2, replica count};
  * fixed reduction order (bitwise reproducible).  Input of the one RCCL

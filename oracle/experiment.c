@@ -507,7 +507,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
   {
     int ti = s->test_interval;
     int test = (ti >= 0 && e->tt % (ti + 1) == ti);           /* :160 */
-    double obs[ORC_MAX_DIMS], reward, total_reward = 0;
+    double obs[ORC_MAX_DIMS], reward, total_reward = 0, total_time = 0;
     int terminal;
     act_t act;
 
@@ -533,10 +533,24 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
       e->prev_action_index = act.index;
     }
 
+    if (s->tap_starts && tap && ntap < tap_cap)
+    { /* the row the transition log gets at the start of a trial (online_learning.cpp:183-184) */
+      orc_tap *tp = &tap[ntap++];
+      memset(tp, 0, sizeof(*tp));
+      tp->test = test;
+      tp->action_index = act.index;
+      memcpy(tp->obs, obs, sizeof(double) * (size_t)D);
+      tp->action = act.value;
+      tp->terminal = -1;
+      tp->trace_len = e->trace.len;
+      for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = act.q[a];
+    }
+
     do
     {
       double tau = orc_env_step(s, e->state, act.value, obs, &reward, &terminal);   /* :196 */
       total_reward += reward;                                                      /* :202 */
+      total_time += tau;                                                           /* :203 */
       double delta = 0;
       orc_proj p, ap;
       p.n = 0;
@@ -610,6 +624,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
         rows[nrows].trial = (ti >= 0) ? (e->tt + 1 - (e->tt + 1) / (ti + 1)) : e->tt;
         rows[nrows].steps = e->ss;
         rows[nrows].reward = total_reward;
+        rows[nrows].time = total_time;
         nrows++;
       }
     }

@@ -120,6 +120,8 @@ typedef struct {
   double ac_step_limit;               /* <0: none                               */
   /* arithmetic */
   int    math;                        /* ORC_MATH_*                             */
+  /* taps */
+  int    tap_starts;                  /* 1: also record the start of every trial (terminal = -1) */
 } orc_spec;
 
 /* fill with the values of the reference's tests/pendulum-sarsa-tc.yaml */
@@ -145,6 +147,7 @@ typedef struct {
   int64_t trial;      /* column 1: tt+1-(tt+1)/(test_interval+1)  (or tt)   */
   int64_t steps;      /* column 2: cumulative learning steps                */
   double  reward;     /* column 3: episode return                           */
+  double  time;       /* column 4: episode time = sum of tau (online_learning.cpp:203,243) */
 } orc_row;
 
 /* per-step tap, for kernel unit tests (learning and test steps alike) */

@@ -42,11 +42,11 @@ class Spec(C.Structure):
                 ("actor_projector", TileSpec), ("actor_representation", LinearSpec),
                 ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double),
-                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int)]
+                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int)]
 
 
 class Row(C.Structure):
-    _fields_ = [("trial", C.c_int64), ("steps", C.c_int64), ("reward", C.c_double)]
+    _fields_ = [("trial", C.c_int64), ("steps", C.c_int64), ("reward", C.c_double), ("time", C.c_double)]
 
 
 class Tap(C.Structure):

@@ -234,6 +234,42 @@ def test_fused_steps_bit_exact(grlx, agent):
     r.close()
 
 
+def test_taps_with_trial_starts(grlx):
+    """tap_starts: the tapped replica also records the start of every trial (first observation, first
+    action; terminal = -1) -- together with the step records these are the rows of the reference's
+    transition log (online_learning.cpp:183-184, 205-206).  Q agent and actor-critic."""
+    from tests import configs
+    cap = 1500
+    cfg = grlx.pendulum_sarsa_config(3, tap_replica=1, tap_capacity=cap, tap_starts=1)
+    r = grlx.Runner(cfg, [8, 9, 10])
+    r.run(5); r.run(7); r.sync()
+    e = ob.Experiment(ob.pendulum_sarsa_spec(tap_starts=1), seed=9)
+    _, otaps = e.run(12, tap_cap=cap)
+    gtaps = r.taps()
+    assert len(gtaps) == len(otaps) == 12 * 101
+    assert [t.terminal for t in otaps].count(-1) == 12
+    for k, (gt, ot) in enumerate(zip(gtaps, otaps)):
+        try:
+            _compare_taps(gt, ot)
+        except AssertionError as ex:
+            raise AssertionError(f"record {k}: {ex}")
+    r.close()
+    cfg, spec = configs.cart_pole_ac(grlx, 2, tap_replica=0, tap_capacity=cap, tap_starts=1)
+    spec.tap_starts = 1
+    r = grlx.Runner(cfg, [51, 52])
+    r.run(6); r.sync()
+    e = ob.Experiment(spec, seed=51)
+    _, otaps = e.run(6, tap_cap=cap)
+    gtaps = r.taps()
+    assert len(gtaps) == len(otaps) and [t.terminal for t in otaps].count(-1) == 6
+    for k, (gt, ot) in enumerate(zip(gtaps, otaps)):
+        try:
+            _compare_taps(gt, ot, A=1, D=4)
+        except AssertionError as ex:
+            raise AssertionError(f"record {k}: {ex}")
+    r.close()
+
+
 def test_fused_many_replicas_vs_oracle(grlx):
     """N ragged (not a multiple of 4) replicas with different seeds, 10 test rows each,
     final weights of every slot the oracle touched."""
@@ -248,6 +284,7 @@ def test_fused_many_replicas_vs_oracle(grlx):
         e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=seed)
         rows, _ = e.run(trials)
         t, s, rew = r.rows(k)
+        assert_bit_equal(r.row_times(k), [x.time for x in rows], "episode time (column 4)")
         assert list(s) == [x.steps for x in rows]
         assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
         slots = rng.integers(0, 8388608, 3000).astype(np.uint32)
@@ -357,6 +394,7 @@ def test_acrobot_fused_bit_exact(grlx, agent):
         e = ob.Experiment(spec, seed=seed)
         rows, otaps = e.run(trials, tap_cap=cap)
         t, s, rew = r.rows(k)
+        assert_bit_equal(r.row_times(k), [x.time for x in rows], "episode time (column 4)")
         assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
         assert_bit_equal(rew, [x.reward for x in rows], f"returns seed {seed}")
         assert list(r.rng(k))[:3] == list(e.rng())[:3]
@@ -421,6 +459,7 @@ def test_actor_critic_fused_bit_exact(grlx, over):
         e = ob.Experiment(spec, seed=seed)
         rows, otaps = e.run(trials, tap_cap=cap)
         t, s, rew = r.rows(k)
+        assert_bit_equal(r.row_times(k), [x.time for x in rows], "episode time (column 4)")
         assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
         assert_bit_equal(rew, [x.reward for x in rows], f"returns seed {seed}")
         assert list(r.rng(k))[:2] == list(e.rng())[:2]
@@ -498,6 +537,7 @@ def test_walker_fused_bit_exact(grlx, agent):
         e = ob.Experiment(spec, seed=seed)
         rows, otaps = e.run(trials, tap_cap=cap)
         t, s, rew = r.rows(k)
+        assert_bit_equal(r.row_times(k), [x.time for x in rows], "episode time (column 4)")
         assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows]
         assert_bit_equal(rew, [x.reward for x in rows], f"returns seed {seed}")
         assert list(r.rng(k))[:3] == list(e.rng())[:3]
