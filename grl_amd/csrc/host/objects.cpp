@@ -11,6 +11,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <map>
 #include <sstream>
 
 #include "../../../include/grlx.h"
@@ -591,12 +592,121 @@ struct FixedAgent : Configurable {
 };
 GRLX_REGISTER(FixedAgent)
 
+// exporter/csv (exporters/csv.cpp:37-206, exporter.h:62-95): comma-separated transition log.
+// Same parameters, file naming (<file>-<variant>-<run counter>.csv), header styles and number
+// format; fed from the device's per-step taps after a run instead of once per step.
+struct CSVExporter : Configurable {
+  GRLX_TYPEINFO("exporter/csv")
+  std::string file, fields, style = "line", variant = "all";
+  int enabled = 1, offset = 0;
+  std::vector<std::string> headers;
+  std::vector<size_t> order;
+  std::ofstream stream;
+  bool header_due = true;
+  std::map<std::string, int> counter;
+
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("file", "Output base filename", file));
+    config->push_back(CRP("fields", "Comma-separated list of fields to write", fields));
+    config->push_back(CRP("style", "Header style", style));
+    config->push_back(CRP("variant", "Variant to export", variant));
+    config->push_back(CRP("enabled", "Enable writing to output file", enabled, CRP::Online));
+    config->push_back(CRP("offset", "Start of numbering", offset));
+  }
+  void configure(Configuration &config) override
+  {
+    file = config["file"].str(); fields = config["fields"].str(); style = config["style"].str(); variant = config["variant"].str();
+    enabled = config["enabled"]; offset = config["offset"];
+    if (file.empty()) throw bad_param("exporter/csv:file");
+    if (style != "none" && style != "line" && style != "meshup") throw bad_param("exporter/csv:style");
+    if (variant != "test" && variant != "learn" && variant != "all") throw bad_param("exporter/csv:variant");
+    if (enabled != 0 && enabled != 1) throw bad_param("exporter/csv:enabled");
+  }
+  // register the columns the caller will supply and resolve `fields` against them (csv.cpp:66-121)
+  void init(const std::vector<std::string> &h)
+  {
+    headers = h;
+    order.clear();
+    if (fields.empty())
+    {
+      for (size_t i = 0; i < h.size(); ++i) order.push_back(i);
+      return;
+    }
+    std::stringstream list(fields);
+    std::string item;
+    while (std::getline(list, item, ','))
+    {
+      item.erase(std::remove_if(item.begin(), item.end(), [](char ch) { return ch == ' ' || ch == '\t'; }), item.end());
+      bool known = false;
+      for (size_t i = 0; i < h.size(); ++i)
+        if (h[i] == item) { order.push_back(i); known = true; }
+      if (!known)
+      {
+        log(0, "Requested unregistered field '" + item + "'");
+        throw bad_param("exporter/csv:fields");
+      }
+    }
+  }
+  // csv.cpp:123-157: a non-appending open starts the next numbered file of the variant
+  void open(const std::string &which, bool append)
+  {
+    if (stream.is_open()) stream.close();
+    if (variant != "all" && variant != which) return;
+    std::string name = which.empty() ? file : file + "-" + which;
+    int &runs_seen = counter[name];
+    if (runs_seen == 0) runs_seen = offset;
+    if (!append) runs_seen++;
+    name += "-" + std::to_string(runs_seen - 1) + ".csv";
+    std::ifstream probe(name, std::ios::binary | std::ios::ate);
+    header_due = !append || !probe || probe.tellg() == std::streampos(0);
+    probe.close();
+    stream.open(name, append ? (std::ios::out | std::ios::app) : (std::ios::out | std::ios::trunc));
+    if (!stream.good())
+    {
+      log(0, "Could not open '" + name + "' for writing");
+      throw bad_param("exporter/csv:file");
+    }
+  }
+  // csv.cpp:159-206
+  void write(const std::vector<std::vector<double>> &vars)
+  {
+    if (!enabled || !stream.is_open()) return;
+    if (vars.size() != headers.size()) { log(0, "Variable list does not match header list"); return; }
+    if (header_due && style != "none")
+    {
+      const bool mesh = style == "meshup";
+      if (mesh) stream << "COLUMNS:" << std::endl;
+      for (size_t i = 0; i < order.size(); ++i)
+        for (size_t k = 0; k < vars[order[i]].size(); ++k)
+        {
+          stream << headers[order[i]] << "[" << k << "]";
+          if (i + 1 < order.size() || k + 1 < vars[order[i]].size()) stream << ", ";
+          if (mesh) stream << std::endl;
+        }
+      if (mesh) stream << "DATA:" << std::endl;
+      else stream << std::endl;
+    }
+    header_due = false;
+    for (size_t i = 0; i < order.size(); ++i)
+      for (size_t k = 0; k < vars[order[i]].size(); ++k)
+      {
+        stream << std::fixed << std::setw(11) << std::setprecision(6) << vars[order[i]][k];
+        if (i + 1 < order.size() || k + 1 < vars[order[i]].size()) stream << ", ";
+      }
+    stream << std::endl;
+  }
+  void close() { if (stream.is_open()) stream.close(); }
+};
+GRLX_REGISTER(CSVExporter)
+
 // ------------------------------------------------------------- experiment ---
 struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
   GRLX_TYPEINFO("experiment/online_learning")
   int runs = 1, run_offset = 0, trials = 0, steps = 0, test_interval = -1, test_trials = 1;
   std::string output, load_file, save_every;
   ModeledEnvironment *environment = nullptr; TDAgent *agent = nullptr; FixedAgent *test_agent = nullptr;
+  CSVExporter *exporter = nullptr;
 
   void request(const std::string &, ConfigurationRequest *config) override
   { // online_learning.cpp:40-62
@@ -630,8 +740,11 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       throw Exception(path() + ": the accelerated path needs environment/modeled, agent/td and agent/fixed");
     if (save_every != "never" && save_every != "run")
       throw Exception(path() + ": save_every must be never or run on the accelerated path (test/trial would stop the device every episode)");
-    if (config["exporter"].ptr() || (int)config["rate"] != 0 || test_trials != 1 || steps != 0)
-      throw Exception(path() + ": exporter/rate/test_trials/steps are outside the accelerated path");
+    if ((int)config["rate"] != 0 || test_trials != 1 || steps != 0)
+      throw Exception(path() + ": rate/test_trials/steps are outside the accelerated path");
+    exporter = dynamic_cast<CSVExporter *>(config["exporter"].ptr());
+    if (config["exporter"].ptr() && !exporter) throw Exception(path() + ": only exporter/csv is available on the accelerated path");
+    if (exporter) exporter->init({"time", "observation", "action", "reward", "terminal"});      // online_learning.cpp:74-75
   }
 
   // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernels make is checked
@@ -760,6 +873,18 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     c.max_rows = (test_interval >= 0 ? trials / (test_interval + 1) : trials) + 1;
     if (opt.table_log2_capacity) c.table_log2_capacity = opt.table_log2_capacity;
     std::vector<double> curve;
+    int obs_dims = 0, state_dims = 0;
+    grlx_env_dims(c.env, &state_dims, &obs_dims);
+    if (exporter)
+    { // transition log of replica 0: every step and every trial start is tapped on the device and
+      // written after the run (the reference writes one row per step, online_learning.cpp:183-206)
+      const double per_trial = std::floor(c.timeout / c.control_step) + 3;
+      const double want = per_trial * (double)trials;
+      if (want > 4e6) throw Exception(path() + ": transition log of " + std::to_string((long long)want) + " rows is too large for the device-side tap buffer");
+      c.tap_replica = 0;
+      c.tap_capacity = (int)want;
+      c.tap_starts = 1;
+    }
 
     if (!output.empty())
     { // store the resolved configuration with the output (online_learning.cpp:117-122)
@@ -803,6 +928,35 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       if (rc == GRLX_OK) rc = grlx_sync(ctx, nullptr);
       if (rc != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
       double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+
+      if (exporter)
+      { // online_learning.cpp:127-131 (new numbered files per run), :164-165 (append per trial), :183-206 (rows)
+        std::vector<grlx_tap> taps((size_t)c.tap_capacity);
+        int ntaps = 0;
+        if (grlx_read_taps(ctx, taps.data(), c.tap_capacity, &ntaps) != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
+        if (ntaps == c.tap_capacity) log(1, "transition log truncated at " + std::to_string(ntaps) + " rows");
+        exporter->open("test", false);
+        exporter->open("learn", false);
+        double total_time = 0, applied = 0;
+        for (int k = 0; k < ntaps; ++k)
+        {
+          const grlx_tap &tp = taps[(size_t)k];
+          const std::vector<double> obs(tp.obs, tp.obs + obs_dims);
+          if (tp.terminal == -1)
+          { // start of a trial: first observation, first action
+            exporter->open(tp.test ? "test" : "learn", true);
+            total_time = 0;
+            exporter->write({{total_time}, obs, {tp.action}, {0.}, {0.}});
+          }
+          else
+          { // a step: the action that was applied, the observation and reward it led to
+            total_time += 1;                          // tau = 1 (discrete_time)
+            exporter->write({{total_time}, obs, {applied}, {tp.reward}, {(double)tp.terminal}});
+          }
+          applied = tp.action;
+        }
+        exporter->close();
+      }
 
       const int n = grlx_rows(ctx);
       std::vector<int64_t> trial((size_t)n), stp((size_t)n);

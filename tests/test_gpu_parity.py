@@ -676,6 +676,62 @@ def test_deployer_load_file_round_trip(grlx, tmp_path):
     assert (tmp_path / "fourth-0.txt").read_text() == fresh.format_rows(rows)
 
 
+def _expected_csv(otaps, D, style, fields, want_test):
+    """The text exporter/csv writes for the taps of one variant (csv.cpp:159-206)."""
+    names = ["time", "observation", "action", "reward", "terminal"]
+    order = [names.index(f.strip()) for f in fields.split(",")] if fields else list(range(5))
+    lines, rows, applied, t = [], [], 0.0, 0.0
+    for tp in otaps:
+        if tp.terminal == -1:
+            t = 0.0
+            row = [[t], list(tp.obs[:D]), [tp.action], [0.0], [0.0]]
+        else:
+            t += 1
+            row = [[t], list(tp.obs[:D]), [applied], [tp.reward], [float(tp.terminal)]]
+        applied = tp.action
+        if bool(tp.test) == want_test:
+            rows.append(row)
+    if rows and style != "none":
+        cols = [f"{names[i]}[{k}]" for i in order for k in range(len(rows[0][i]))]
+        if style == "meshup":
+            lines.append("COLUMNS:")
+            lines += [c + (", " if n + 1 < len(cols) else "") for n, c in enumerate(cols)]
+            lines.append("DATA:")
+        else:
+            lines.append(", ".join(cols))
+    for row in rows:
+        lines.append(", ".join(f"{v:11.6f}" for i in order for v in row[i]))
+    return "".join(l + "\n" for l in lines)
+
+
+@pytest.mark.parametrize("style,fields,variant", [("line", "", "all"), ("meshup", "time, reward,observation", "learn"), ("none", "", "test")])
+def test_deployer_transition_log_csv(grlx, tmp_path, style, fields, variant):
+    """experiment/online_learning:exporter (exporter/csv, csv.cpp): <file>-learn-0.csv / <file>-test-0.csv with
+    one row per trial start and per step (time, observation, action applied, reward, terminal), in the
+    reference's header styles and number format -- against the oracle's own step records."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    exporter = f"  exporter:\n    type: exporter/csv\n    file: translog\n    style: {style}\n    variant: {variant}\n"
+    if fields:
+        exporter += f"    fields: {fields}\n"
+    y = tmp_path / "log.yaml"
+    y.write_text(text.replace("trials: 2000", "trials: 23").replace('  load_file: ""\n', exporter + '  load_file: ""\n'))
+    res = subprocess.run([grlxd, "-s", "4", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.Experiment(ob.pendulum_sarsa_spec(tap_starts=1), seed=4)
+    rows, otaps = e.run(23, tap_cap=3000)
+    assert len(otaps) == 23 * 101
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)       # the run itself is unchanged
+    for which, want_test in (("learn", False), ("test", True)):
+        f = tmp_path / f"translog-{which}-0.csv"
+        if variant in ("all", which):
+            assert f.read_text() == _expected_csv(otaps, 2, style, fields, want_test), which
+        else:
+            assert not f.exists()
+
+
 # ----------------------------------------------------------- edge cases -----
 def test_empty_batches_and_bad_arguments(grlx):
     """n = 0 is legal everywhere; out-of-range arguments come back as GRLX_ERR_INVALID, never a crash."""

@@ -85,3 +85,14 @@ def test_load_file_is_accepted_and_needs_a_device(grlxd, tmp_path):
     assert "outside the accelerated path" not in res.stderr
     if capi.load().grlx_device_count() == 0:
         assert res.returncode == 1 and "no HIP device" in res.stderr
+
+
+@pytest.mark.parametrize("body,needle", [
+    ("    type: exporter/csv\n    file: \"\"\n", "exporter/csv:file"),                                   # csv.cpp:57-58
+    ("    type: exporter/csv\n    file: log\n    fields: time, velocity\n", "exporter/csv:fields"),      # csv.cpp:113-117
+    ("    type: exporter/csv\n    file: log\n    style: fancy\n", "exporter/csv:style"),
+])
+def test_exporter_parameters_are_validated(grlxd, tmp_path, body, needle):
+    res = run(grlxd, ["-s", "1", "-q", _variant(tmp_path, '  load_file: ""\n', "  exporter:\n" + body + '  load_file: ""\n')], tmp_path)
+    assert res.returncode == 1
+    assert needle in res.stderr, res.stderr
