@@ -501,16 +501,16 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
   static constexpr int S = 3, D = 2;
   // pendulum.cpp:40-49, 55-68; the constants are held in registers by the caller (rk4_step)
   struct Consts { SinConsts k; double invJ, mgl, b, kkr, kr; };
-  __device__ static __forceinline__ Consts consts()
+  template <bool PIN> __device__ static __forceinline__ Consts consts()
   {
     const double J = 0.000191, m = 0.055, g = 9.81, l = 0.042, b = 0.000003, K = 0.0536, R = 9.5;
     Consts c;
-    c.k = sin_consts();
-    c.invJ = math_pin(1 / J);
-    c.mgl = math_pin(m * g * l);
-    c.b = math_pin(b);
-    c.kkr = math_pin(K * K / R);
-    c.kr = math_pin(K / R);
+    c.k = sin_consts<PIN>();
+    c.invJ = math_const<PIN>(1 / J);
+    c.mgl = math_const<PIN>(m * g * l);
+    c.b = math_const<PIN>(b);
+    c.kkr = math_const<PIN>(K * K / R);
+    c.kr = math_const<PIN>(K / R);
     return c;
   }
   __device__ static __forceinline__ void eom(const Consts &c, const double *x, double u, double *xd)
@@ -555,7 +555,7 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
 template <> struct Env<GRLX_ENV_ACROBOT> {
   static constexpr int S = 5, D = 4;
   using Consts = SinConsts;                     // held in registers across the integration loop
-  __device__ static __forceinline__ Consts consts() { return sin_consts(); }
+  template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
   __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
   { // acrobot.cpp:48-79, expression for expression
     const double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
@@ -618,7 +618,7 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
 template <> struct Env<GRLX_ENV_CART_POLE> {
   static constexpr int S = 5, D = 4;
   using Consts = SinConsts;                     // held in registers across the integration loop
-  __device__ static __forceinline__ Consts consts() { return sin_consts(); }
+  template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
   __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
   { // cart_pole.cpp:58-108.  QUIRK reproduced on purpose: :65 reads dtheta = state[3-2*end_stop_],
     // which for end_stop = 1 is state[1] -- the ANGLE, not its rate.
@@ -885,7 +885,7 @@ template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bo
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
 // (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
-template <int ENV>
+template <int ENV, bool PIN>
 __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
 {
   constexpr int S = Env<ENV>::S, SD = S - 1;
@@ -894,7 +894,7 @@ __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, do
   double xd[S], k1[SD], k2[SD], k3[SD], k4[SD], t[S];
 #pragma unroll
   for (int i = 0; i < S; ++i) { next[i] = x[i]; t[i] = x[i]; }
-  const typename Env<ENV>::Consts ec = Env<ENV>::consts();   // constants pinned in vector registers
+  const typename Env<ENV>::Consts ec = Env<ENV>::template consts<PIN>();   // PIN: constants held in vector registers
   for (int ii = 0; ii < P.integration_steps; ++ii)
   {
     Env<ENV>::eom(ec, next, u, xd);
@@ -918,7 +918,9 @@ __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, do
 }
 
 // ModeledEnvironment::step (modeled.cpp:160-213), window 1, no delta, discrete_time 1
-template <int ENV>
+// PIN: hold the dynamics' constants in vector registers across the integration loop (pays at one
+// wave per SIMD, costs registers)
+template <int ENV, bool PIN = true>
 __device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal, uint32_t &status)
 {
   constexpr int S = Env<ENV>::S;
@@ -926,7 +928,7 @@ __device__ __forceinline__ void env_step(const DevParams &P, double *x, double a
   if constexpr (HasCustomModel<ENV>::value)
     Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next);     // model/compass_walker integrates itself
   else
-    rk4_step<ENV>(P, x, Env<ENV>::actuate(action), next);
+    rk4_step<ENV, PIN>(P, x, Env<ENV>::actuate(action), next);
   terminal = Env<ENV>::observe(P, next, obs);
   reward = Env<ENV>::evaluate(P, x, action, next);
   // the branch-free sin/cos need |angle| < 2^20; 2^19 at step ends leaves room for the stages
@@ -2089,15 +2091,20 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
           wap = value_load(tabA, ap_pos);                // actor weights of project(prev_obs), current
           wpc = value_load(tabC, p_pos);                 // critic weights of project(prev_obs), as stored
         }
+        // both tables' home buckets in flight together: one memory round trip for the two lookups
+        Lookup lkA[1], lkC[1];
+        BucketRegs brA[1], brC[1];
+        if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
+        if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
         if (has_next)
         {
-          table_get<1>(tabA, P.lin_actor, RS, 1, slotA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
-                       [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
+          table_get_finish<1>(tabA, P.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
+                              [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
         }
         if (need_critic)
         {
           bool shared_event = false;
-          table_get<1>(tabC, P.lin, RS, 0, slotC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
+          table_get_finish<1>(tabC, P.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
                        [&](uint32_t mp) {
                          trace_share_event(tr, tabC, mp);
                          if (p_pos == mp) p_sh = true;

@@ -114,20 +114,24 @@ struct SinConsts {
 };
 
 __device__ __forceinline__ double math_pin(double v) { asm volatile("" : "+v"(v)); return v; }
+// PIN = false leaves the constants to the compiler (literals): the choice for kernels that run
+// several waves per SIMD, where registers are scarcer than scalar issue slots.
+template <bool PIN> __device__ __forceinline__ double math_const(double v) { return PIN ? math_pin(v) : v; }
 
+template <bool PIN = true>
 __device__ __forceinline__ SinConsts sin_consts()
 {
   SinConsts k;
-  k.invpio2 = math_pin(GRLX_INVPIO2);
-  k.p1 = math_pin(GRLX_PIO2_1);
-  k.p2 = math_pin(GRLX_PIO2_2);
-  k.p3 = math_pin(GRLX_PIO2_3);
+  k.invpio2 = math_const<PIN>(GRLX_INVPIO2);
+  k.p1 = math_const<PIN>(GRLX_PIO2_1);
+  k.p2 = math_const<PIN>(GRLX_PIO2_2);
+  k.p3 = math_const<PIN>(GRLX_PIO2_3);
   const double sv[8] = {-0x1.5555555555555p-3, 0x1.1111111111111p-7, -0x1.a01a01a01a01ap-13, 0x1.71de3a556c734p-19,
                         -0x1.ae64567f544e4p-26, 0x1.6124613a86d09p-33, -0x1.ae7f3e733b81fp-41, 0x1.952c77030ad4ap-49};
   const double cv[8] = {0x1.5555555555555p-5, -0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-16, -0x1.27e4fb7789f5cp-22,
                         0x1.1eed8eff8d898p-29, -0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-45, -0x1.6827863b97d97p-53};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { k.s[i] = math_pin(sv[i]); k.c[i] = math_pin(cv[i]); }
+  for (int i = 0; i < 8; ++i) { k.s[i] = math_const<PIN>(sv[i]); k.c[i] = math_const<PIN>(cv[i]); }
   return k;
 }
 
