@@ -612,6 +612,31 @@ def test_full_size_batches(grlx, name, n, trials):
     r.close()
 
 
+def test_wide_seed_sweep(grlx):
+    """192 seeds x 66 trials of the headline configuration, every replica against its own scalar
+    oracle run: rows, RNG positions, environment state and 400 random weights each.  Rare paths of
+    the production ordering (evictions that alias a pending lookup, slots shared between tilings,
+    colliding inserts) occur somewhere in a sweep of this width."""
+    seeds = np.arange(1000, 1192)
+    trials = 66
+    cfg = grlx.pendulum_sarsa_config(len(seeds))
+    r = grlx.Runner(cfg, seeds)
+    r.run(40); r.run(26); r.sync()
+    rng = np.random.default_rng(41)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=int(seed))
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3], seed
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of seed {seed}")
+        slots = rng.integers(0, 8388608, 400).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots), e.weights(slots), f"weights of seed {seed}")
+        e.close()
+    r.close()
+
+
 def test_dat_policy_export_matches_dense_table(grlx, tmp_path):
     """save_every: run writes grl's raw .dat parameter files (representation.h:201-229): 8,388,608 doubles
     that must equal the oracle's dense table bit for bit -- the file a real grl build could load."""
