@@ -1021,4 +1021,33 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
 };
 GRLX_REGISTER(OnlineLearningExperimentImpl)
 
+// experiment/multi (multi.cpp:36-75): `instances` clones of an experiment running side by side, each
+// with the identity "@i" in its output names.  Here the clones are the replicas of ONE device
+// context (instance i is seeded seed + i; the reference's clones draw their seeds from the shared
+// global stream in instantiation order and then race on it, which no golden file pins).
+struct MultiExperiment : OnlineLearningExperiment {
+  GRLX_TYPEINFO("experiment/multi")
+  int instances = 1;
+  OnlineLearningExperiment *prototype = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("instances", "Number of experiments to run in parallel", instances));
+    config->push_back(CRP("experiment", "experiment", "Experiment to run", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    instances = config["instances"];
+    prototype = dynamic_cast<OnlineLearningExperiment *>(config["experiment"].ptr());
+    if (instances < 1) throw bad_param("experiment/multi:instances");
+    if (!prototype || dynamic_cast<MultiExperiment *>(prototype)) throw Exception(path() + ": experiment must be an experiment/online_learning");
+  }
+  std::vector<double> run(const RunOptions &opt) override
+  {
+    RunOptions clones = opt;
+    clones.replicas = instances * std::max(1, opt.replicas);
+    return prototype->run(clones);
+  }
+};
+GRLX_REGISTER(MultiExperiment)
+
 } // namespace grlx_host

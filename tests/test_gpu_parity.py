@@ -361,6 +361,28 @@ def test_deployer_reproduces_golden_file(grlx, tmp_path):
     assert (tmp_path / "pendulum-sarsa-tc-0@2.txt").read_text() != first
 
 
+def test_deployer_experiment_multi(grlx, tmp_path):
+    """experiment/multi (multi.cpp:36-75): `instances` clones side by side, outputs named <output>-<run>@<i>.txt.
+    Here the clones are replicas of one device context, instance i seeded seed + i."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    assert text.startswith("experiment:\n")
+    inner = "".join("  " + line + "\n" for line in text.splitlines()[1:])
+    for sub in ("environment", "agent"):                 # absolute references move one level down
+        inner = inner.replace(f": experiment/{sub}", f": experiment/experiment/{sub}")
+    inner = inner.replace("trials: 2000", "trials: 22")
+    y = tmp_path / "multi.yaml"
+    y.write_text("experiment:\n  type: experiment/multi\n  instances: 3\n  experiment:\n" + inner)
+    res = subprocess.run([grlxd, "-s", "11", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    for i in range(3):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=11 + i)
+        rows, _ = e.run(22)
+        assert (tmp_path / f"pendulum-sarsa-tc-0@{i}.txt").read_text() == e.format_rows(rows)
+
+
 # ------------------------------------------------------------- acrobot -----
 def test_acrobot_env_step_bit_exact(grlx):
     from tests import configs
