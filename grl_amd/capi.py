@@ -97,7 +97,9 @@ _SIGS = {
 
 
 def lib_path() -> str:
-    return _build.LIB
+    """grl_amd/lib/libgrlx.so; GRLX_LIB names another build of the same library (A/B timing of two
+    builds on one GPU box, tools/ab_bench.sh) -- never a fallback: a missing file is an error."""
+    return os.environ.get("GRLX_LIB") or _build.LIB
 
 
 def _share_hip_runtime_with_torch():

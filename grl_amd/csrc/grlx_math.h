@@ -320,6 +320,10 @@ __device__ __forceinline__ double plog(double x)
 __device__ __forceinline__ double pfmod(double x, double y)
 {
   double ax = __builtin_fabs(x);
+  // every lane within two periods (the wrapped angles of the environments): the long division below
+  // is then its last step alone -- one exact conditional subtraction
+  if (__builtin_expect(__all(ax < y + y && y > 0.0), 1))
+    return __builtin_copysign((ax >= y) ? ax - y : ax, x);
   if (!(ax < __builtin_inf()) || !(y > 0.0)) return __builtin_nan("");
   if (ax < y) return x;
   int ex = (int)(((unsigned long long)__double_as_longlong(ax) >> 52) & 0x7FF);
