@@ -269,8 +269,12 @@ __device__ __forceinline__ double div6(double x)
   const double c = 0x1.5555555555555p-3;        // RN(1/6)
   const double q0 = x * c;
   const double r = __builtin_fma(-6.0, q0, x);
-  const double q = __builtin_fma(r, c, q0);
-  return (__builtin_fabs(x) > 0x1p-900) ? q : x / 6.0;
+  double q = __builtin_fma(r, c, q0);
+  // tiny |x| (never seen in practice): one wave-uniform test instead of an exec-mask region per call
+  const bool tiny = !(__builtin_fabs(x) > 0x1p-900);
+  if (__builtin_expect(__any(tiny), 0))
+    q = tiny ? x / 6.0 : q;
+  return q;
 }
 
 // plog(x): x = m*2^k, m in [sqrt2/2, sqrt2); f = m-1; d = f+2; s = f/d;
