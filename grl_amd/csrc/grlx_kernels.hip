@@ -694,6 +694,9 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
 
   __device__ static __forceinline__ double hip_x(const St &m) { return m.sfx - psin(m.sla); }
   __device__ static __forceinline__ double swing_y(const St &m) { return pcos(m.sla) - pcos(m.sla - m.ha); }
+  // the same with the sine constants held in registers by model_step (20 sub-steps x 10 evaluations)
+  __device__ static __forceinline__ double hip_x(const SinConsts &k, const St &m) { return m.sfx - psin(m.sla, k); }
+  __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m) { return pcos(m.sla, k) - pcos(m.sla - m.ha, k); }
   __device__ static __forceinline__ void wrap(St &m)
   { // SWModel.h:48-59
     if (m.sla >= GRLX_PI) m.sla -= 2*GRLX_PI;
@@ -701,40 +704,40 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     if (m.ha >= GRLX_PI) m.ha -= 2*GRLX_PI;
     if (m.ha < -GRLX_PI) m.ha += 2*GRLX_PI;
   }
-  __device__ static __forceinline__ void accel(const DevParams &P, const St &m, double torque, double &asl, double &ahip)
+  __device__ static __forceinline__ void accel(const DevParams &P, const SinConsts &k, const St &m, double torque, double &asl, double &ahip)
   { // SWModel.cpp:212-218
     double sn, cs;
-    psincos(m.sla - P.slope_angle, sn, cs);
+    psincos(m.sla - P.slope_angle, k, sn, cs);
     asl = sn;
-    ahip = psin(m.ha) * (m.slar*m.slar - cs) + asl;
+    ahip = psin(m.ha, k) * (m.slar*m.slar - cs) + asl;
     ahip += torque;
   }
-  __device__ static __forceinline__ void rk4(const DevParams &P, St &state, double torque, double dt)
+  __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt)
   { // SWModel.cpp:220-258
     St s1 = state, s2 = state, s3 = state, s4 = state;
     double k1s, k1h, k2s, k2h, k3s, k3h, k4s, k4h;
-    accel(P, s1, torque, k1s, k1h);
+    accel(P, k, s1, torque, k1s, k1h);
     s2.slar = s1.slar + (dt/2)*k1s;
     s2.har  = s1.har  + (dt/2)*k1h;
     s2.sla  = s1.sla  + (dt/2)*s1.slar;
     s2.ha   = s1.ha   + (dt/2)*s1.har;
-    accel(P, s2, torque, k2s, k2h);
+    accel(P, k, s2, torque, k2s, k2h);
     s3.slar = s1.slar + (dt/2)*k2s;
     s3.har  = s1.har  + (dt/2)*k2h;
     s3.sla  = s1.sla  + (dt/2)*s2.slar;
     s3.ha   = s1.ha   + (dt/2)*s2.har;
-    accel(P, s3, torque, k3s, k3h);
+    accel(P, k, s3, torque, k3s, k3h);
     s4.slar = s1.slar + (dt)*k3s;
     s4.har  = s1.har  + (dt)*k3h;
     s4.sla  = s1.sla  + (dt)*s3.slar;
     s4.ha   = s1.ha   + (dt)*s3.har;
-    accel(P, s4, torque, k4s, k4h);
+    accel(P, k, s4, torque, k4s, k4h);
     state.slar = s1.slar + (dt/6)*(k1s + 2*k2s + 2*k3s + k4s);
     state.har  = s1.har  + (dt/6)*(k1h + 2*k2h + 2*k3h + k4h);
     state.sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
     state.ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
   }
-  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
+  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
   { // SWModel.cpp:53-104
     double timeLeft = 0;
     St s0 = t0, s1 = t1;
@@ -744,10 +747,10 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     for (iIter = 0; iIter < maxIterations; iIter++)
     {
       hs = s0;
-      const double y0 = swing_y(s0);
-      double newDt = (s1time - s0time) * y0 / (y0 - swing_y(s1));
-      rk4(P, hs, torque, newDt);
-      if (swing_y(hs) > 0)
+      const double y0 = swing_y(k, s0);
+      double newDt = (s1time - s0time) * y0 / (y0 - swing_y(k, s1));
+      rk4(P, k, hs, torque, newDt);
+      if (swing_y(k, hs) > 0)
       {
         s0 = hs;
         s0time = s0time + newDt;
@@ -757,13 +760,13 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
         s1 = hs;
         s1time = s0time + newDt;
       }
-      if (swing_y(s0) < precision)
+      if (swing_y(k, s0) < precision)
       {
         hs = s0;
         timeLeft = dt - s0time;
         break;
       }
-      else if (-swing_y(s1) < precision)
+      else if (-swing_y(k, s1) < precision)
       {
         hs = s1;
         timeLeft = dt - s1time;
@@ -772,7 +775,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     }
     if (iIter >= maxIterations)
     {
-      if (swing_y(hs) > 0) timeLeft = dt - s0time;
+      if (swing_y(k, hs) > 0) timeLeft = dt - s0time;
       else timeLeft = dt - s1time;
     }
     return timeLeft;
@@ -785,30 +788,37 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     hs = st;
     bool changed = false;
     const double partial = P.walker_dt;
+    const SinConsts k = sin_consts<true>();
+    double y_prev = swing_y(k, prev);            // swing_y(prev) of the next sub-step is this sub-step's swing_y(st)
     for (int i = 0; i < P.integration_steps; i++)
     {
-      rk4(P, st, torque, partial);
+      rk4(P, k, st, torque, partial);
       wrap(st);
       // detectEvents (SWModel.cpp:30-45)
       double timeleft = 0;
-      if ((swing_y(prev) >= 0) && (swing_y(st) < 0))
+      bool struck = false;
+      const double y_now = swing_y(k, st);
+      if ((y_prev >= 0) && (y_now < 0))
         if (((prev.ha < 0) && (st.ha < 0)) || ((prev.ha > 0) && (st.ha > 0)))
           if ((st.slar < 0) && (st.ha < 0))
           { // processStanceLegChange (:106-124)
-            timeleft = heelstrike_moment(P, prev, st, hs, torque, 1.0E-11, partial);
-            const double c2 = pcos(2.0*hs.sla);
+            struck = true;
+            timeleft = heelstrike_moment(P, k, prev, st, hs, torque, 1.0E-11, partial);
+            const double c2 = pcos(2.0*hs.sla, k);
             st.har  = hs.slar*(c2*(1.0 - c2));
             st.slar = hs.slar*(c2);
-            st.sfx  = hip_x(hs) + psin(hs.sla - hs.ha);
+            st.sfx  = hip_x(k, hs) + psin(hs.sla - hs.ha, k);
             st.sla  = -hs.sla;
             st.ha   = -2.0*hs.sla;
           }
       changed = changed || (timeleft > 0);
       if (timeleft > 0)
       {
-        rk4(P, st, torque, timeleft);
+        rk4(P, k, st, torque, timeleft);
         wrap(st);
       }
+      // a pure function of the state: recomputed only where a heel strike replaced the state
+      y_prev = struck ? swing_y(k, st) : y_now;
       prev = st;
     }
 #pragma unroll
@@ -819,8 +829,8 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     next[HAR] = st.har;
     next[SFX] = st.sfx;
     next[CHANGED] = changed ? 1. : 0.;
-    next[LASTHIPX] = changed ? hip_x(st) : x[LASTHIPX];
-    next[HIPVEL] = - st.slar * pcos(st.sla);
+    next[LASTHIPX] = changed ? hip_x(k, st) : x[LASTHIPX];
+    next[HIPVEL] = - st.slar * pcos(st.sla, k);
     next[TIME] = x[TIME] + P.control_step;
     next[TIMEOUT] = x[TIMEOUT];
   }
