@@ -1510,7 +1510,10 @@ constexpr DevParams make_spec_pendulum_tc()
 }
 __device__ const DevParams d_spec_pendulum_tc = make_spec_pendulum_tc();
 
-struct SpecPendulumTc {
+// AGENT: the predictor kind is a compile-time constant of the instantiation too (one per TD agent)
+template <int AGENT>
+struct SpecPendulumTcA {
+  __device__ static __forceinline__ int agent(const DevParams &) { return AGENT; }
   // every numeric field the rollout kernel reads must equal the constant, bit for bit
   static bool matches(const DevParams &P)
   {
@@ -1521,15 +1524,17 @@ struct SpecPendulumTc {
               P.lin.init_min == C.lin.init_min && P.lin.init_range == C.lin.init_range && P.lin.out_min == C.lin.out_min &&
               P.lin.out_max == C.lin.out_max && P.lin.limit == C.lin.limit && P.lin.draws_before == C.lin.draws_before &&
               P.epsilon == C.epsilon && P.decay_rate == C.decay_rate && P.decay_min == C.decay_min && P.alpha == C.alpha &&
-              P.gamma == C.gamma && P.gl == C.gl && (P.agent == GRLX_AGENT_SARSA);
+              P.gamma == C.gamma && P.gl == C.gl && P.agent == AGENT;
     for (int i = 0; i < 3; ++i)
       ok = ok && P.actions[i] == C.actions[i] && P.tile.scaling[i] == C.tile.scaling[i] && P.tile.wrap[i] == C.tile.wrap[i];
     return ok;
   }
   __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_pendulum_tc; }
 };
+using SpecPendulumTc = SpecPendulumTcA<GRLX_AGENT_SARSA>;
 struct SpecNone {
   __device__ static __forceinline__ const DevParams &numeric(const DevParams &P) { return P; }
+  __device__ static __forceinline__ int agent(const DevParams &P) { return P.agent; }
 };
 
 template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG>
@@ -1817,9 +1822,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           double target = reward;
           if (has_next)
           {
-            if (N.agent == GRLX_AGENT_SARSA)
+            if (SPEC::agent(P) == GRLX_AGENT_SARSA)
               target += N.gamma * pick<double, NA>(q, a_next);
-            else if (N.agent == GRLX_AGENT_EXPECTED_SARSA)
+            else if (SPEC::agent(P) == GRLX_AGENT_EXPECTED_SARSA)
             { // QPolicy::value (q.cpp:60-73) = sum_a Q(s',a) * EpsilonGreedySampler::distribution (greedy.cpp:220-238)
               const double de = eps_decay * N.epsilon;
               double v = 0;
@@ -2344,10 +2349,18 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
       hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     return hipGetLastError();                                                                               \
   }
-  if (!inplace && !P.no_specialisation && SpecPendulumTc::matches(P))
-  {
-    hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, false, SpecPendulumTc>), dim3(waves), dim3(64), 0, stream, P, n_trials);
-    return hipGetLastError();
+  if (!inplace && !P.no_specialisation)
+  { // compile-time specialised instantiations of the reference's cfg/pendulum/{sarsa,q}_tc.yaml family
+#define GRLX_LAUNCH_SPEC(AGENT)                                                                                        \
+    if (SpecPendulumTcA<AGENT>::matches(P))                                                                            \
+    {                                                                                                                  \
+      hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, false, SpecPendulumTcA<AGENT>>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                        \
+    }
+    GRLX_LAUNCH_SPEC(GRLX_AGENT_SARSA)
+    GRLX_LAUNCH_SPEC(GRLX_AGENT_Q)
+    GRLX_LAUNCH_SPEC(GRLX_AGENT_EXPECTED_SARSA)
+#undef GRLX_LAUNCH_SPEC
   }
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 3)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 5)

@@ -822,13 +822,14 @@ def test_more_rows_than_reserved_is_reported(grlx):
     r.close()
 
 
-def test_specialised_kernel_equals_generic(grlx):
-    """The headline configuration runs a compile-time specialised instantiation (parameters as
-    literals); it must be indistinguishable from the generic kernel."""
+@pytest.mark.parametrize("agent", [0, 1, 3])
+def test_specialised_kernel_equals_generic(grlx, agent):
+    """The headline configuration (and its Q / Expected-SARSA siblings) runs a compile-time specialised
+    instantiation (parameters as literals); it must be indistinguishable from the generic kernel."""
     seeds = np.arange(1, 38)
     out = []
     for force in (0, 1):
-        cfg = grlx.pendulum_sarsa_config(len(seeds), force_generic=force)
+        cfg = grlx.pendulum_sarsa_config(len(seeds), force_generic=force, agent=agent)
         r = grlx.Runner(cfg, seeds)
         r.run(55); r.sync()
         rows = np.stack([r.rows(k)[2] for k in range(len(seeds))])
