@@ -126,6 +126,9 @@ def main():
     parallel.reduce_curve(curve, world)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the measured launches must have been the production instantiation of this configuration
+    if runner.last_kernel() != 2:
+        raise SystemExit("bench.py: the headline configuration did not run its specialised kernel (grlx_last_kernel = %d)" % runner.last_kernel())
     runner.sync(sptr)                                          # raises on table overflow etc.
 
     elapsed = parallel.max_over_ranks(elapsed, world, device="cuda")
@@ -160,7 +163,7 @@ def main():
                        "tilings": 16, "memory": 8388608, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
-                         "kernel": "rollout_kernel<pendulum,3>", "kernel_ms_avg": avg_ms,
+                         "kernel": "rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
         }

@@ -75,6 +75,7 @@ _SIGS = {
     "grlx_read_diag": (C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int, _P(C.c_int)]),
     "grlx_rows": (C.c_int, [C.c_void_p]),
     "grlx_read_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64), _P(C.c_double)]),
+    "grlx_last_kernel": (C.c_int, [C.c_void_p]),
     "grlx_read_row_times": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_curve_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grlx_step_counts": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),

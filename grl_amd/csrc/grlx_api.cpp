@@ -212,6 +212,7 @@ struct grlx_ctx {
   std::vector<double *> images;           // loaded policy images (grlx_load_weights), freed with the context
   int          n_tables = 1;
   int64_t      trials_run = 0;
+  int          last_kernel = GRLX_KERNEL_NONE;
 };
 
 // small RAII helper for the copy-in / copy-out entry points
@@ -496,9 +497,9 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
   {
     const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
     if (ctx->cfg.agent == GRLX_AGENT_AC)
-      HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream));
+      HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else
-      HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream));
+      HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
   }
   ctx->trials_run += n_trials;
   return GRLX_OK;
@@ -555,6 +556,8 @@ int grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count, int64_t *tr
   if (trial) HIP_TRY(hipMemcpy2D(trial, sizeof(int64_t), ctx->row_trial + at, N * sizeof(int64_t), sizeof(int64_t), (size_t)count, hipMemcpyDeviceToHost));
   return GRLX_OK;
 }
+
+int grlx_last_kernel(grlx_ctx *ctx) { return ctx ? ctx->last_kernel : GRLX_KERNEL_NONE; }
 
 int grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, double *episode_time)
 {

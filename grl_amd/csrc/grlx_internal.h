@@ -104,8 +104,9 @@ struct DevParams {
 
 // ---------------------------------------------------------------------------
 // launchers implemented in grlx_kernels.hip
-hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream);
-hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream);
+// *variant (optional) receives the GRLX_KERNEL_* instantiation that was launched
+hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);

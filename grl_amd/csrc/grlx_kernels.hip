@@ -1970,6 +1970,69 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
   if (live && j == 0) RS.status = st;
 }
 
+// cfg/cart_pole/ac_tc.yaml as compile-time constants (see SpecPendulumTcA): every field the actor-critic
+// kernel reads, derived with the expressions of make_params (grlx_api.cpp)
+constexpr DevParams make_spec_cart_pole_ac()
+{
+  DevParams P = {};
+  P.env = GRLX_ENV_CART_POLE;
+  P.agent = GRLX_AGENT_AC;
+  P.trace_kind = GRLX_TRACE_REPLACING;
+  P.test_interval = 10;
+  P.integration_steps = 5;
+  P.h = 0.05 / 5.0;
+  P.control_step = 0.05;
+  P.timeout = 9.99;
+  P.randomization = 0;
+  P.end_stop_penalty = 0;
+  P.action_penalty = 0;
+  P.action_min = -15;
+  P.action_max = 15;
+  P.A = 0;
+  const double res[4] = {2.5, 0.157075, 2.5, 1.57075};
+  P.tile.T = 16; P.tile.D = 4; P.tile.memory = 8388608;
+  P.tile_actor.T = 16; P.tile_actor.D = 4; P.tile_actor.memory = 8388608;
+  for (int i = 0; i < 4; ++i) { P.tile.scaling[i] = 16 / res[i]; P.tile_actor.scaling[i] = 16 / res[i]; }
+  P.tile.wrap[1] = 640; P.tile_actor.wrap[1] = 640;              // round(6.283 * 16 / 0.157075)
+  P.lin.init_min = 0; P.lin.init_range = 1;
+  P.lin.out_min = -1.7976931348623157e308; P.lin.out_max = 1.7976931348623157e308;
+  P.lin.limit = 1; P.lin.draws_before = 8388608;
+  P.lin_actor.init_min = 0; P.lin_actor.init_range = 1;
+  P.lin_actor.out_min = -15; P.lin_actor.out_max = 15;
+  P.lin_actor.limit = 1; P.lin_actor.draws_before = 0;
+  P.actor_alpha = 0.01; P.sigma = 5; P.theta = 1; P.ac_decay_rate = 1; P.ac_decay_min = 0;
+  P.ac_step_limit = -1; P.ac_update_method = 0;
+  P.alpha = 0.2; P.gamma = 0.97; P.gl = 0.97 * 0.65;
+  return P;
+}
+__device__ const DevParams d_spec_cart_pole_ac = make_spec_cart_pole_ac();
+
+struct SpecCartPoleAc {
+  static bool same_tile(const TileParams &a, const TileParams &b)
+  {
+    bool ok = a.T == b.T && a.D == b.D && a.memory == b.memory;
+    for (int i = 0; i < GRLX_MAX_DIMS; ++i) ok = ok && a.scaling[i] == b.scaling[i] && a.wrap[i] == b.wrap[i];
+    return ok;
+  }
+  static bool same_lin(const LinearParams &a, const LinearParams &b)
+  {
+    return a.init_min == b.init_min && a.init_range == b.init_range && a.out_min == b.out_min && a.out_max == b.out_max &&
+           a.limit == b.limit && a.draws_before == b.draws_before;
+  }
+  static bool matches(const DevParams &P)
+  {
+    constexpr DevParams C = make_spec_cart_pole_ac();
+    return P.env == C.env && P.agent == C.agent && P.trace_kind == C.trace_kind && P.test_interval == C.test_interval &&
+           P.integration_steps == C.integration_steps && P.h == C.h && P.control_step == C.control_step && P.timeout == C.timeout &&
+           P.randomization == C.randomization && P.end_stop_penalty == C.end_stop_penalty && P.action_penalty == C.action_penalty &&
+           P.action_min == C.action_min && P.action_max == C.action_max && same_tile(P.tile, C.tile) && same_tile(P.tile_actor, C.tile_actor) &&
+           same_lin(P.lin, C.lin) && same_lin(P.lin_actor, C.lin_actor) && P.actor_alpha == C.actor_alpha && P.sigma == C.sigma &&
+           P.theta == C.theta && P.ac_decay_rate == C.ac_decay_rate && P.ac_decay_min == C.ac_decay_min && P.ac_step_limit == C.ac_step_limit &&
+           P.ac_update_method == C.ac_update_method && P.alpha == C.alpha && P.gamma == C.gamma && P.gl == C.gl;
+  }
+  __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_cart_pole_ac; }
+};
+
 // ------------------------------------------------------ actor-critic rollout ---
 // agent/td { policy: mapping/policy/action, predictor: predictor/ac/action { critic:
 // predictor/critic/td } } with agent/fixed for test trials (cfg/cart_pole/ac_tc.yaml).
@@ -1992,9 +2055,11 @@ __device__ __forceinline__ uint32_t tile_slot_obs(const TileParams &tp, const do
 
 #define SHA(row, k, g) sh_w[(((row) * 16 + (k)) << 2) + (g)]
 
-template <int ENV>
+template <int ENV, typename SPEC>
 __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trials)
 {
+  // N: numeric parameters (compile-time constants in a specialised build); P: pointers and sizes
+  const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
   __shared__ double   sh_w[4 * 16 * 4];        // rows: actor(s'), critic(s'), actor(s), critic(s)
   __shared__ uint32_t sh_ppos[4 * 16];
@@ -2028,15 +2093,15 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
 
   const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
   UpdateParams up;
-  up.out_min = P.lin.out_min;
-  up.out_max = P.lin.out_max;
-  up.limit = P.lin.limit != 0;
-  up.ee = P.gl;
+  up.out_min = N.lin.out_min;
+  up.out_max = N.lin.out_max;
+  up.limit = N.lin.limit != 0;
+  up.ee = N.gl;
   up.cut = 0.01;
-  up.use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
+  up.use_trace = N.trace_kind == GRLX_TRACE_REPLACING;
   up.dW = up.dT = 0;
-  const double a_min = P.lin_actor.out_min, a_max = P.lin_actor.out_max;
-  const bool a_limit = P.lin_actor.limit != 0;
+  const double a_min = N.lin_actor.out_min, a_max = N.lin_actor.out_max;
+  const bool a_limit = N.lin_actor.limit != 0;
 
   // restore the critic's trace: positions from HBM, weights from the (current) table
   TraceRegs tr;
@@ -2061,15 +2126,15 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
 
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
-    const int ti = P.test_interval;
+    const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
     double obs[D], reward = 0, total_reward = 0;
     int terminal = 0;
     bool running = live;
     if (live)
     {
-      Env<ENV>::start(P, test, TL, G, x);
-      Env<ENV>::observe(P, x, obs);
+      Env<ENV>::start(N, test, TL, G, x);
+      Env<ENV>::observe(N, x, obs);
     }
     double time = 0, action = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0, ap_pos = kInvalidPos, ap_slot = 0;
@@ -2083,7 +2148,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
       {
         if (!first)
         {
-          env_step<ENV>(P, x, action, obs, reward, terminal, status);
+          env_step<ENV>(N, x, action, obs, reward, terminal, status);
           total_reward += reward;
           time += 1;
         }
@@ -2096,8 +2161,8 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         bool shA[1] = {false}, shC[1] = {false};
         if (has_next)
         {
-          slotA[0] = tile_slot_obs<T>(P.tile_actor, obs, D, j);
-          slotC[0] = tile_slot_obs<T>(P.tile, obs, D, j);
+          slotA[0] = tile_slot_obs<T>(N.tile_actor, obs, D, j);
+          slotC[0] = tile_slot_obs<T>(N.tile, obs, D, j);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         double wap = 0, wpc = 0;
@@ -2113,13 +2178,13 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
         if (has_next)
         {
-          table_get_finish<1>(tabA, P.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
+          table_get_finish<1>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
                               [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
         }
         if (need_critic)
         {
           bool shared_event = false;
-          table_get_finish<1>(tabC, P.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
+          table_get_finish<1>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
                        [&](uint32_t mp) {
                          trace_share_event(tr, tabC, mp);
                          if (p_pos == mp) p_sh = true;
@@ -2161,20 +2226,20 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
           if (!test)
           {
             if (time == 0) ac_noise = 0;
-            if (time == 0.) ac_decay = fmax(ac_decay * P.ac_decay_rate, P.ac_decay_min);
-            if (P.sigma != 0)
+            if (time == 0.) ac_decay = fmax(ac_decay * N.ac_decay_rate, N.ac_decay_min);
+            if (N.sigma != 0)
             { // Rand::getNormal(0, decay*sigma): two thread-local draws (utils.h:120-125)
               TL = lcg_next(TL);
               const double U1 = lcg_double(TL);
               TL = lcg_next(TL);
               const double U2 = lcg_double(TL);
-              const double sg = ac_decay * P.sigma;
+              const double sg = ac_decay * N.sigma;
               const double nrm = __builtin_sqrt(-2 * plog(U1)) * pcos(2 * GRLX_PI * U2) * sg + 0.;
-              ac_noise = (1 - P.theta) * ac_noise + nrm;
+              ac_noise = (1 - N.theta) * ac_noise + nrm;
               out += ac_noise;
             }
           }
-          a_next = fmin(fmax(out, P.action_min), P.action_max);
+          a_next = fmin(fmax(out, N.action_min), N.action_max);
         }
 
         // -------- predictor (ActionACPredictor::update, ac.cpp:72-110)
@@ -2183,20 +2248,20 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         {
           // critic: TDPredictor::criticize (td.cpp:68-91)
           double target = reward;
-          if (has_next) target += P.gamma * v_next;
+          if (has_next) target += N.gamma * v_next;
           delta = target - v_prev;
-          up.dW = P.alpha * (target - v_prev);
-          up.dT = P.alpha * delta;
+          up.dW = N.alpha * (target - v_prev);
+          up.dT = N.alpha * delta;
           Evicted ev_unused;
           td_update_lane<false>(tr, tabC, up, p_pos, p_sh, wpc, g, j, sh_ppos, sh_fb, sh_fbflag, status, ev_unused);
           // actor
-          if (P.ac_update_method == 0 || delta > 0)
+          if (N.ac_update_method == 0 || delta > 0)
           {
             double du = action - u_prev;                          // transition.prev_action - u
-            if (P.ac_update_method == 0) du = delta * du;
-            if (P.ac_step_limit >= 0) du = fmin(fmax(du, -P.ac_step_limit), P.ac_step_limit);
+            if (N.ac_update_method == 0) du = delta * du;
+            if (N.ac_step_limit >= 0) du = fmin(fmax(du, -N.ac_step_limit), N.ac_step_limit);
             const double target_u = u_prev + du;
-            const double dA = P.actor_alpha * (target_u - u_prev);    // LinearRepresentation::write
+            const double dA = N.actor_alpha * (target_u - u_prev);    // LinearRepresentation::write
             uint32_t cpa = 1;                                         // a slot that occurs twice is updated twice
             const uint32_t amask = (uint32_t)((__ballot(ap_sh) >> (16 * g)) & 0xFFFFull);
             for (uint32_t mm = amask; mm != 0u; mm &= mm - 1u)
@@ -2313,16 +2378,23 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
   if (live && j == 0) RS.status = st;
 }
 
-hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream)
+hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
 {
+  if (variant) *variant = GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
   switch (P.env)
   {
     case GRLX_ENV_CART_POLE:
-      hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      if (!P.no_specialisation && !(P.tap_replica >= 0 && P.tap_capacity > 0) && SpecCartPoleAc::matches(P))
+      {
+        if (variant) *variant = GRLX_KERNEL_SPECIALISED;
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecCartPoleAc>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      }
+      else
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials);
       break;
     case GRLX_ENV_PENDULUM:
-      hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_PENDULUM>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_PENDULUM, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials);
       break;
     default:
       return hipErrorInvalidValue;
@@ -2330,19 +2402,22 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
   return hipGetLastError();
 }
 
-hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
+hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
 {
+  if (variant) *variant = GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
   // stamps and per-step taps are recorded by the instantiation that updates in place
   const bool inplace = P.diag_out != nullptr || (P.tap_replica >= 0 && P.tap_capacity > 0);
   if (P.diag_out && P.diag_deferred && P.env == GRLX_ENV_PENDULUM && P.A == 3 && !(P.tap_replica >= 0 && P.tap_capacity > 0))
   {
+    if (variant) *variant = GRLX_KERNEL_GENERIC;
     hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, true, SpecNone, true>), dim3(waves), dim3(64), 0, stream, P, n_trials);
     return hipGetLastError();
   }
 #define GRLX_LAUNCH(ENVID, NACT)                                                                              \
   if (P.env == ENVID && P.A == NACT)                                                                        \
   {                                                                                                         \
+    if (variant && inplace) *variant = GRLX_KERNEL_IN_PLACE;                                                \
     if (inplace)                                                                                            \
       hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, true, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     else                                                                                                    \
@@ -2354,6 +2429,7 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream)
 #define GRLX_LAUNCH_SPEC(AGENT)                                                                                        \
     if (SpecPendulumTcA<AGENT>::matches(P))                                                                            \
     {                                                                                                                  \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                                 \
       hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, false, SpecPendulumTcA<AGENT>>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
       return hipGetLastError();                                                                                        \
     }

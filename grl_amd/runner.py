@@ -93,6 +93,10 @@ class Runner:
                                            _ptr(steps, C.c_int64), _ptr(reward, C.c_double)))
         return trial, steps, reward
 
+    def last_kernel(self) -> int:
+        """capi GRLX_KERNEL_*: 1 generic, 2 specialised (compile-time instantiation), 3 diagnostic in-place."""
+        return self.lib.grlx_last_kernel(self._ctx)
+
     def row_times(self, replica: int, first: int = 0, count: int = None):
         """Episode time of each row's trial (column 4, online_learning.cpp:243): steps under discrete_time."""
         if count is None:

@@ -161,6 +161,15 @@ int  grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, doubl
  * all-reduce of the multi-GPU path. */
 int  grlx_curve_stats(grlx_ctx *ctx, int first, int count, double *out_dev, void *stream);
 
+/* Which instantiation of the rollout kernel the last grlx_run launched (tests and benchmarks check that
+ * the configuration they mean to measure takes the path they mean to measure). */
+enum { GRLX_KERNEL_NONE = 0,          /* nothing launched yet                                                  */
+       GRLX_KERNEL_GENERIC = 1,       /* parameters read at run time                                           */
+       GRLX_KERNEL_SPECIALISED = 2,   /* compile-time instantiation of a reference yaml (pendulum tile-coding
+                                         SARSA / Q / Expected SARSA, cart-pole actor-critic)                   */
+       GRLX_KERNEL_IN_PLACE = 3       /* diagnostic instantiation: taps / stamps, TD update applied in place   */ };
+int  grlx_last_kernel(grlx_ctx *ctx);
+
 /* counters: total env steps executed by all replicas since create */
 int  grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps);
 

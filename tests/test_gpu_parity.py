@@ -822,6 +822,43 @@ def test_more_rows_than_reserved_is_reported(grlx):
     r.close()
 
 
+def test_kernel_selection(grlx):
+    """Which instantiation a configuration runs: the reference yamls take their compile-time build, any
+    deviation (or force_generic, or taps) takes the generic one -- never silently the wrong constants."""
+    from tests import configs
+    cases = [(grlx.pendulum_sarsa_config(4), 2), (grlx.pendulum_sarsa_config(4, agent=1), 2), (grlx.pendulum_sarsa_config(4, agent=3), 2),
+             (grlx.pendulum_sarsa_config(4, force_generic=1), 1), (grlx.pendulum_sarsa_config(4, alpha=0.25), 1),
+             (grlx.pendulum_sarsa_config(4, tap_replica=0, tap_capacity=10), 3),
+             (configs.cart_pole_ac(grlx, 4)[0], 2), (configs.cart_pole_ac(grlx, 4, sigma=4.0)[0], 1),
+             (configs.cart_pole_ac(grlx, 4, force_generic=1)[0], 1), (configs.acrobot(grlx, 4)[0], 1)]
+    for cfg, want in cases:
+        r = grlx.Runner(cfg, [1, 2, 3, 4])
+        assert r.last_kernel() == 0
+        r.run(1); r.sync()
+        assert r.last_kernel() == want, (cfg.env, cfg.agent, want, r.last_kernel())
+        r.close()
+
+
+def test_specialised_actor_critic_equals_generic(grlx):
+    from tests import configs
+    seeds = np.arange(60, 71)
+    out = []
+    for force in (0, 1):
+        cfg, _ = configs.cart_pole_ac(grlx, len(seeds), force_generic=force)
+        r = grlx.Runner(cfg, seeds)
+        r.run(9); r.run(8); r.sync()
+        assert r.last_kernel() == (1 if force else 2)
+        slots = np.arange(0, 8388608, 211, dtype=np.uint32)
+        out.append((np.stack([r.rows(k)[2] for k in range(len(seeds))]), r.weights(3, slots, table=0), r.weights(3, slots, table=1),
+                    [list(r.rng(k)) for k in range(len(seeds))], np.stack([r.env_state(k) for k in range(len(seeds))])))
+        r.close()
+    assert_bit_equal(out[0][0], out[1][0], "rows")
+    assert_bit_equal(out[0][1], out[1][1], "critic weights")
+    assert_bit_equal(out[0][2], out[1][2], "actor weights")
+    assert out[0][3] == out[1][3]
+    assert_bit_equal(out[0][4], out[1][4], "env states")
+
+
 @pytest.mark.parametrize("agent", [0, 1, 3])
 def test_specialised_kernel_equals_generic(grlx, agent):
     """The headline configuration (and its Q / Expected-SARSA siblings) runs a compile-time specialised

@@ -12,10 +12,11 @@ make = {"pendulum": configs.pendulum, "pendulum_q": lambda g, k: configs.pendulu
         "acrobot": configs.acrobot, "compass_walker": configs.compass_walker}[name]
 cfg, _ = make(grl_amd, n)
 cfg.max_rows = 256
+cfg.force_generic = int(os.environ.get("GRLX_FORCE_GENERIC", "0"))     # A/B: generic vs specialised instantiation
 r = grl_amd.Runner(cfg, np.arange(1, n + 1))
 r.run(warm); r.sync()
 l0, t0s = r.step_counts()
 t0 = time.perf_counter(); r.run(trials); r.sync(); dt = time.perf_counter() - t0
 l1, t1s = r.step_counts()
 steps = (l1 - l0) + (t1s - t0s)
-print(f"{name} {n} replicas {trials} trials: {steps/1e6:.1f} M env-steps in {dt*1e3:.1f} ms -> {steps/dt/1e6:.1f} M env-steps/s")
+print(f"{name} {n} replicas {trials} trials (kernel variant {r.last_kernel()}): {steps/1e6:.1f} M env-steps in {dt*1e3:.1f} ms -> {steps/dt/1e6:.1f} M env-steps/s")
