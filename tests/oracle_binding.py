@@ -203,3 +203,16 @@ def env_step(spec: Spec, state, action):
         L.orc_env_step(C.byref(spec), st, float(action[i]), ob, C.byref(rw), C.byref(tm))
         state[i] = st[:]; obs[i] = ob[:]; reward[i] = rw.value; term[i] = tm.value
     return state, obs, reward, term
+
+
+def timed_run(args):
+    """Worker of bench.py's cpu_baseline (one process per host core): run `trials` trials of the
+    pendulum SARSA oracle with libm arithmetic, return (env-steps, seconds) without the weight init."""
+    import time
+    seed, trials = args
+    e = Experiment(pendulum_sarsa_spec(math=MATH_LIBM), seed=seed)
+    t0 = time.perf_counter()
+    e.run(trials)
+    dt = time.perf_counter() - t0
+    e.close()
+    return trials * 100, dt
