@@ -779,6 +779,21 @@ def test_deployer_transition_log_csv(grlx, tmp_path, style, fields, variant):
             assert not f.exists()
 
 
+def test_deployer_compass_walker_rows_equal_oracle(grlx, tmp_path):
+    """grlxd on the walker's Q-learning yaml (model/compass_walker + task/compass_walker/walk): rows = oracle's."""
+    import subprocess
+    from grl_amd import _build
+    from tests import configs
+    grlxd = _build.build_host()
+    yaml = os.path.join(os.path.dirname(__file__), "golden", "compass_walker-q-tc.yaml")
+    res = subprocess.run([grlxd, "-s", "17", "-l", "-q", yaml], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    _, spec = configs.compass_walker(grlx, 1)
+    e = ob.Experiment(spec, seed=17)
+    rows, _ = e.run(33)
+    assert (tmp_path / "compass_walker-q-tc-0.txt").read_text() == e.format_rows(rows)
+
+
 # ----------------------------------------------------------- edge cases -----
 def test_empty_batches_and_bad_arguments(grlx):
     """n = 0 is legal everywhere; out-of-range arguments come back as GRLX_ERR_INVALID, never a crash."""
