@@ -112,7 +112,14 @@ int make_params(const grlx_config &c, DevParams *P)
   if (c.struct_size != sizeof(grlx_config)) return fail(GRLX_ERR_INVALID, "grlx_config.struct_size %u != %zu (ABI mismatch)", c.struct_size, sizeof(grlx_config));
   int S, D;
   if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
-  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC && c.agent != GRLX_AGENT_EXPECTED_SARSA) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+  if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC && c.agent != GRLX_AGENT_EXPECTED_SARSA &&
+      c.agent != GRLX_AGENT_ADVANTAGE) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+  if (c.agent == GRLX_AGENT_ADVANTAGE)
+  {
+    if (!(c.kappa > 0)) return fail(GRLX_ERR_INVALID, "predictor/critic/advantage:kappa");
+    if ((c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) || c.action_steps != 3)
+      return fail(GRLX_ERR_INVALID, "advantage learning is built for the pendulum and the acrobot with 3 actions");
+  }
   const bool ac = c.agent == GRLX_AGENT_AC;
   if (ac && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
   if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");
@@ -181,6 +188,7 @@ int make_params(const grlx_config &c, DevParams *P)
   P->decay_rate = c.decay_rate;
   P->decay_min = c.decay_min;
   P->alpha = c.alpha;
+  P->kappa = c.kappa;
   P->gamma = c.gamma;                     // pow(gamma, tau) with tau = 1
   P->gl = c.gamma * c.lambda;             // pow(gamma*lambda, tau) with tau = 1
   if (c.trace == GRLX_TRACE_REPLACING)

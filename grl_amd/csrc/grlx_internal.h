@@ -100,6 +100,7 @@ struct DevParams {
   unsigned long long *diag_out;
   int32_t  no_specialisation;   // tests: force the generic kernel even when a specialised instantiation matches
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
+  double   kappa;               // predictor/critic/advantage: advantage scaling factor
 };
 
 // ---------------------------------------------------------------------------

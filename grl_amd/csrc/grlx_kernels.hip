@@ -1537,14 +1537,19 @@ struct SpecNone {
   __device__ static __forceinline__ int agent(const DevParams &P) { return P.agent; }
 };
 
-template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG>
+// ADV: advantage learning (predictor/critic/advantage, advantage.cpp:222-268) also reads A(s, .) of the
+// PREVIOUS state for every action with the current weights: NA more rows (their table positions are
+// those of the previous pass), Q(s,a) being one of them.  Built without the deferred update.
+template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG, bool ADV = false>
 __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 {
+  static_assert(!(ADV && DEFER), "the advantage-learning instantiation updates in place");
+  constexpr int NROWS = ADV ? 2 * NA : NA + 1;      // LDS rows of weights summed per pass
   // N: the numeric parameters -- the runtime block, or compile-time constants in a specialised build.
   // P keeps the pointers, the replica count and the buffer sizes.
   const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
-  __shared__ double   sh_w[(NA + 1) * 16 * 4];
+  __shared__ double   sh_w[NROWS * 16 * 4];
   __shared__ uint32_t sh_ppos[4 * 16];
   __shared__ double   sh_fb[16 * 4];
   __shared__ uint32_t sh_fbflag[16 * 4];
@@ -1628,6 +1633,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
     int    action_index = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0;
     bool   p_sh = false;
+    uint32_t pos_prev[NA];                // ADV: positions of project(s, a_k) for every action
+#pragma unroll
+    for (int a = 0; a < NA; ++a) pos_prev[a] = 0u;
     if (!test) tr_len_ref = 0;          // TDAgent::start -> trace_->clear()
     bool first = true;                    // first pass = start(): act only, no env step / update
 
@@ -1639,6 +1647,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
       Lookup lk[NA];
       BucketRegs br[NA];
       double wp = 0;
+      double wprev[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) wprev[a] = 0;
       bool has_next = false, update = false;
       // (slot, lk, br are written and read only under running && has_next)
       if (running)
@@ -1678,6 +1689,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         DIAG_STAMP(6)
         if (update) wp = value_load(tab, p_pos);                           // weights of project(s, a) as stored
+        if (ADV && update)
+        {
+#pragma unroll
+          for (int a = 0; a < NA; ++a) wprev[a] = value_load(tab, pos_prev[a]);
+        }
         if (has_next) table_issue<NA>(tab, slot, lk, br);                  // home buckets of Q(s', .): loads in flight
       }
 
@@ -1725,7 +1741,15 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
                                  shared_event = true;
                                });
           DIAG_STAMP(7)
-          if (rarely(__any(shared_event)) && update) wp = value_load(tab, p_pos);
+          if (rarely(__any(shared_event)) && update)
+          {
+            wp = value_load(tab, p_pos);
+            if (ADV)
+            {
+#pragma unroll
+              for (int a = 0; a < NA; ++a) wprev[a] = value_load(tab, pos_prev[a]);
+            }
+          }
         }
         if (DEFER)
         { // Values loaded before the deferred update may be stale where that update wrote the table:
@@ -1759,7 +1783,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (update)
         {
           wp = trace_forward(tr, p_pos, wp);
-          SHW(NA, j, g) = wp;
+          if (ADV)
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+            {
+              wprev[a] = trace_forward(tr, pos_prev[a], wprev[a]);
+              SHW(NA + a, j, g) = wprev[a];
+            }
+          }
+          else
+            SHW(NA, j, g) = wp;
         }
         DIAG_STAMP(3)
         if (!DEFER)
@@ -1772,7 +1806,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         // Lane r of the replica sums row r (Q(s',a_r) for r < NA, Q(s,a) for r = NA) in the reference's
         // order; the NA+1 results are shared through LDS (lanes beyond NA repeat row 0, harmlessly).
         {
-          const int row = (j <= NA) ? j : 0;
+          const int row = (j < NROWS) ? j : 0;
           double sum = 0;
 #pragma unroll
           for (int k = 0; k < 16; ++k) sum += SHW(row, k, g);
@@ -1786,7 +1820,20 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           for (int a = 0; a < NA; ++a) q[a] = clampd(sh_res[g * 16 + a], up.out_min, up.out_max);
         }
         double qsa = 0;
-        if (update) qsa = clampd(sh_res[g * 16 + NA], up.out_min, up.out_max);
+        double qprev[NA];                                  // ADV: A(s, a_k) with the current weights
+#pragma unroll
+        for (int a = 0; a < NA; ++a) qprev[a] = 0;
+        if (update)
+        {
+          if (ADV)
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) qprev[a] = clampd(sh_res[g * 16 + NA + a], up.out_min, up.out_max);
+            qsa = pick<double, NA>(qprev, action_index);          // project(s, a) is the row of the action taken
+          }
+          else
+            qsa = clampd(sh_res[g * 16 + NA], up.out_min, up.out_max);
+        }
 
         // -------- sampler (greedy.cpp:63-86, 144-218)
         int a_next = 0;
@@ -1820,7 +1867,21 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         if (update)
         {
           double target = reward;
-          if (has_next)
+          if (ADV)
+          { // AdvantagePredictor::criticize (advantage.cpp:232-254)
+            double v = -__builtin_inf();
+#pragma unroll
+            for (int kk = 0; kk < NA; ++kk) v = fmax(v, qprev[kk]);
+            target = v + (reward - v) / N.kappa;
+            if (has_next)
+            {
+              v = -__builtin_inf();
+#pragma unroll
+              for (int kk = 0; kk < NA; ++kk) v = fmax(v, q[kk]);
+              target += N.gamma * v / N.kappa;
+            }
+          }
+          else if (has_next)
           {
             if (SPEC::agent(P) == GRLX_AGENT_SARSA)
               target += N.gamma * pick<double, NA>(q, a_next);
@@ -1910,6 +1971,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           p_pos = pick<uint32_t, NA>(pos, a_next);
           p_slot = pick<uint32_t, NA>(slot, a_next);
           p_sh = pick<bool, NA>(sh, a_next);
+          if (ADV)
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) pos_prev[a] = pos[a];
+          }
         }
         if (!first && terminal) running = false;
         first = false;
@@ -2423,6 +2489,20 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
     else                                                                                                    \
       hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
     return hipGetLastError();                                                                               \
+  }
+  if (P.agent == GRLX_AGENT_ADVANTAGE)
+  { // advantage learning: its own in-place instantiation (taps included)
+    if (variant) *variant = GRLX_KERNEL_IN_PLACE;
+#define GRLX_LAUNCH_ADV(ENVID, NACT)                                                                                  \
+    if (P.env == ENVID && P.A == NACT)                                                                              \
+    {                                                                                                               \
+      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, true, SpecNone, false, true>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                     \
+    }
+    GRLX_LAUNCH_ADV(GRLX_ENV_PENDULUM, 3)
+    GRLX_LAUNCH_ADV(GRLX_ENV_ACROBOT, 3)
+#undef GRLX_LAUNCH_ADV
+    return hipErrorInvalidValue;
   }
   if (!inplace && !P.no_specialisation)
   { // compile-time specialised instantiations of the reference's cfg/pendulum/{sarsa,q}_tc.yaml family

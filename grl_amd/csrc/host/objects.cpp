@@ -452,7 +452,7 @@ struct Predictor : Configurable {};
 
 // predictor/critic/sarsa (sarsa.cpp:35-60), predictor/critic/q (advantage.cpp:35-62)
 struct TDPredictorBase : Predictor {
-  double alpha = 0.2, gamma = 0.97, lambda = 0.65;
+  double alpha = 0.2, gamma = 0.97, lambda = 0.65, kappa = 0;
   TileCodingProjector *projector = nullptr; LinearRepresentation *representation = nullptr; Trace *trace = nullptr;
   virtual int agent_id() const = 0;
   void request(const std::string &, ConfigurationRequest *config) override
@@ -460,7 +460,9 @@ struct TDPredictorBase : Predictor {
     config->push_back(CRP("alpha", "Learning rate", 0.2));
     config->push_back(CRP("gamma", "Discount rate", 0.97));
     config->push_back(CRP("lambda", "Trace decay rate", 0.65));
-    if (agent_id() == GRLX_AGENT_Q)
+    if (agent_id() == GRLX_AGENT_ADVANTAGE)
+      config->push_back(CRP("kappa", "Advantage scaling factor", 0.2));          // advantage.cpp:188
+    if (agent_id() == GRLX_AGENT_Q || agent_id() == GRLX_AGENT_ADVANTAGE)
       config->push_back(CRP("discretizer", "discretizer.action", "Action discretizer", (Configurable *)nullptr));
     config->push_back(CRP("projector", "projector.pair", "Projects observation-action pairs onto representation space", (Configurable *)nullptr));
     config->push_back(CRP("representation", "representation.value/action", "Q-value representation", (Configurable *)nullptr));
@@ -471,6 +473,7 @@ struct TDPredictorBase : Predictor {
   void configure(Configuration &config) override
   {
     alpha = config["alpha"]; gamma = config["gamma"]; lambda = config["lambda"];
+    if (agent_id() == GRLX_AGENT_ADVANTAGE) kappa = config["kappa"];
     projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
     representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
     trace = dynamic_cast<Trace *>(config["trace"].ptr());
@@ -482,6 +485,9 @@ struct SARSAPredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/sarsa"
 GRLX_REGISTER(SARSAPredictor)
 struct QPredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/q") int agent_id() const override { return GRLX_AGENT_Q; } };
 GRLX_REGISTER(QPredictor)
+// predictor/critic/advantage (advantage.cpp:181-268): advantage learning, scaling factor kappa
+struct AdvantagePredictor : TDPredictorBase { GRLX_TYPEINFO("predictor/critic/advantage") int agent_id() const override { return GRLX_AGENT_ADVANTAGE; } };
+GRLX_REGISTER(AdvantagePredictor)
 // predictor/critic/expected_sarsa (sarsa.cpp:134-165): the target policy must be the learning policy
 struct ExpectedSARSAPredictor : TDPredictorBase {
   GRLX_TYPEINFO("predictor/critic/expected_sarsa")
@@ -849,7 +855,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     const EpsilonGreedySampler *sm = static_cast<const EpsilonGreedySampler *>(pol->sampler);
     c->epsilon = sm->epsilon[0]; c->decay_rate = sm->decay_rate; c->decay_min = sm->decay_min;
     c->agent = pred->agent_id();
-    c->alpha = pred->alpha; c->gamma = pred->gamma; c->lambda = pred->lambda;
+    c->alpha = pred->alpha; c->gamma = pred->gamma; c->lambda = pred->lambda; c->kappa = pred->kappa;
     c->trace = pred->trace ? pred->trace->kind() : GRLX_TRACE_NONE;
   }
 

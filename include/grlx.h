@@ -41,7 +41,8 @@ enum { GRLX_ENV_PENDULUM = 0,        /* dynamics/pendulum + task/pendulum/swingu
 enum { GRLX_AGENT_SARSA = 0,         /* agent/td + policy/discrete/q + predictor/critic/sarsa (sarsa.cpp)     */
        GRLX_AGENT_Q = 1,             /* ... + predictor/critic/q (advantage.cpp:71-110)                       */
        GRLX_AGENT_AC = 2,            /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */
-       GRLX_AGENT_EXPECTED_SARSA = 3 /* ... + predictor/critic/expected_sarsa (sarsa.cpp:167-194)              */ };
+       GRLX_AGENT_EXPECTED_SARSA = 3,/* ... + predictor/critic/expected_sarsa (sarsa.cpp:167-194)              */
+       GRLX_AGENT_ADVANTAGE = 4      /* ... + predictor/critic/advantage (advantage.cpp:222-268), `kappa`     */ };
 enum { GRLX_TRACE_NONE = 0, GRLX_TRACE_REPLACING = 1, GRLX_TRACE_ACCUMULATING = 2 };   /* trace.h:208-263 */
 
 #define GRLX_MAX_DIMS 8
@@ -107,6 +108,8 @@ typedef struct {
   double   slope_angle;               /* default 0.004 */
   double   initial_state_variation;   /* default 0.2   */
   double   negative_reward;           /* default -100  */
+  /* predictor/critic/advantage (advantage.cpp:183-213) */
+  double   kappa;                     /* advantage scaling factor (cfg/pendulum/advantage_tc.yaml: 0.2) */
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;

@@ -324,6 +324,43 @@ static double q_update(orc_exp *e, const double *prev_obs, double prev_action, d
   return delta;
 }
 
+static double advantage_update(orc_exp *e, const double *prev_obs, double prev_action, double tau,
+                               double reward, const double *obs, int has_action, orc_proj *pout)
+{ /* advantage.cpp:222-268 (AdvantagePredictor::criticize): advantage learning with scaling kappa.
+   * parity unpinned by reference tests. */
+  const orc_spec *s = &e->spec;
+  orc_proj p, pa;
+  project_sa(e, prev_obs, prev_action, &p);
+  const double a = lin_read(e, 0, &s->representation, &p);            /* A(x_t, u_t) */
+  double v = -INFINITY;                                                /* max_u A(x_t, u) */
+  for (int kk = 0; kk < e->A; ++kk)
+  {
+    project_sa(e, prev_obs, e->actions[kk], &pa);
+    v = fmax(v, lin_read(e, 0, &s->representation, &pa));
+  }
+  double target = v + (reward - v) / s->kappa;
+  if (has_action)
+  {
+    v = -INFINITY;                                                     /* max_u A(x_{t+1}, u) */
+    for (int kk = 0; kk < e->A; ++kk)
+    {
+      project_sa(e, obs, e->actions[kk], &pa);
+      v = fmax(v, lin_read(e, 0, &s->representation, &pa));
+    }
+    target += orc_m_powtau(s, s->gamma, tau) * v / s->kappa;
+  }
+  double delta = target - a;
+  lin_write(e, 0, &s->representation, &p, target, s->alpha);
+  if (s->trace != ORC_TRACE_NONE)
+  {
+    double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
+    lin_update_trace(e, 0, &s->representation, &e->trace, s->alpha * delta, ee);
+    trace_add(&e->trace, s->trace, &p, ee);
+  }
+  *pout = p;
+  return delta;
+}
+
 /* -------------------------------------------------------- actor-critic ---
  * parity unpinned by reference tests (its cart-pole AC test yaml is stale). */
 static double rand_normal(orc_exp *e, double mu, double sigma)
@@ -430,7 +467,9 @@ static double *table_alloc_init(orc_exp *e, const orc_tile_spec *ts, const orc_l
 orc_exp *orc_create(const orc_spec *spec, long seed)
 {
   if (orc_env_state_dims(spec->env) < 0) return NULL;             /* environments not restated yet */
-  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC && spec->agent != ORC_AGENT_EXPECTED_SARSA) return NULL;
+  if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC && spec->agent != ORC_AGENT_EXPECTED_SARSA &&
+      spec->agent != ORC_AGENT_ADVANTAGE) return NULL;
+  if (spec->agent == ORC_AGENT_ADVANTAGE && !(spec->kappa > 0)) return NULL;
   if (spec->agent == ORC_AGENT_AC)
   {
     if (spec->projector.dims != orc_env_obs_dims(spec->env) || spec->actor_projector.dims != orc_env_obs_dims(spec->env)) return NULL;
@@ -575,6 +614,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
           else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
             delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
+          else if (s->agent == ORC_AGENT_ADVANTAGE)
+            delta = advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
           else
             delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
         }
@@ -589,6 +630,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
           else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
             delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
+          else if (s->agent == ORC_AGENT_ADVANTAGE)
+            delta = advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
           else
             delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
           memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);

@@ -234,6 +234,70 @@ def test_fused_steps_bit_exact(grlx, agent):
     r.close()
 
 
+def test_advantage_learning_bit_exact(grlx):
+    """predictor/critic/advantage (advantage.cpp:222-268, kappa = 0.2 as in cfg/pendulum/advantage_tc.yaml):
+    every step of one replica (A(s', .), actions, TD errors, trace) plus rows, RNG and weights of all;
+    and on the acrobot, whose episodes end in an absorbing state (target without the next-state term)."""
+    from tests import configs
+    seeds, trials, cap = [14, 15, 16, 17, 18], 23, 2400
+    cfg = grlx.pendulum_sarsa_config(len(seeds), tap_replica=3, tap_capacity=cap, agent=4, kappa=0.2)
+    r = grlx.Runner(cfg, seeds)
+    r.run(12); r.run(11); r.sync()
+    assert r.last_kernel() == 3
+    rng = np.random.default_rng(2)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(agent=4, kappa=0.2), seed=seed)
+        rows, otaps = e.run(trials, tap_cap=cap)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3]
+        if k == 3:
+            gtaps = r.taps()
+            assert len(gtaps) == len(otaps) == trials * 100
+            for i, (gt, ot) in enumerate(zip(gtaps, otaps)):
+                try:
+                    _compare_taps(gt, ot)
+                except AssertionError as ex:
+                    raise AssertionError(f"step {i}: {ex}")
+            touched = np.unique(np.array([list(tp.p_idx[:16]) for tp in otaps if not tp.test]).ravel()).astype(np.uint32)
+            assert_bit_equal(r.weights(k, touched), e.weights(touched), "touched weights")
+        slots = rng.integers(0, 8388608, 1000).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots), e.weights(slots), "weights")
+    r.close()
+    cfg, spec = configs.acrobot(grlx, 6, agent=4, kappa=0.5)
+    spec.kappa = 0.5
+    seeds = [21, 22, 23, 24, 25, 26]
+    r = grlx.Runner(cfg, seeds)
+    r.run(44); r.sync()
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, _ = e.run(44)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"acrobot returns of seed {seed}")
+        assert_bit_equal(r.env_state(k), e.state(), "env state")
+    r.close()
+    with pytest.raises(grlx.capi.GrlxError, match="kappa"):
+        grlx.Runner(grlx.pendulum_sarsa_config(1, agent=4), [1])
+
+
+def test_deployer_advantage_learning(grlx, tmp_path):
+    """grlxd with predictor/critic/advantage (the predictor block of cfg/pendulum/advantage_tc.yaml): rows = oracle's."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    text = text.replace("      type: predictor/sarsa\n", "      kappa: 0.2\n      discretizer: ../../policy/discretizer\n      type: predictor/critic/advantage\n")
+    y = tmp_path / "adv.yaml"
+    y.write_text(text.replace("trials: 2000", "trials: 44"))
+    res = subprocess.run([grlxd, "-s", "6", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.Experiment(ob.pendulum_sarsa_spec(agent=4, kappa=0.2), seed=6)
+    rows, _ = e.run(44)
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)
+
+
 def test_taps_with_trial_starts(grlx):
     """tap_starts: the tapped replica also records the start of every trial (first observation, first
     action; terminal = -1) -- together with the step records these are the rows of the reference's
