@@ -13,7 +13,7 @@ MAX_DIMS, MAX_STATE, MAX_ACTIONS = 8, 12, 8
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TABLE_FULL, ERR_DOMAIN, ERR_ROWS_FULL, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7
 ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER = 0, 1, 2, 3
-AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE = 0, 1, 2, 3, 4
+AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE, AGENT_QV = 0, 1, 2, 3, 4, 5
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
 
@@ -44,7 +44,7 @@ class Config(C.Structure):
                 ("tap_capacity", C.c_int32), ("end_stop_penalty", C.c_int32), ("action_penalty", C.c_int32),
                 ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
-                ("kappa", C.c_double)]
+                ("kappa", C.c_double), ("beta", C.c_double)]
 
 
 class Tap(C.Structure):

@@ -113,7 +113,7 @@ int make_params(const grlx_config &c, DevParams *P)
   int S, D;
   if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
   if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC && c.agent != GRLX_AGENT_EXPECTED_SARSA &&
-      c.agent != GRLX_AGENT_ADVANTAGE) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
+      c.agent != GRLX_AGENT_ADVANTAGE && c.agent != GRLX_AGENT_QV) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
   if (c.agent == GRLX_AGENT_ADVANTAGE)
   {
     if (!(c.kappa > 0)) return fail(GRLX_ERR_INVALID, "predictor/critic/advantage:kappa");
@@ -121,6 +121,10 @@ int make_params(const grlx_config &c, DevParams *P)
       return fail(GRLX_ERR_INVALID, "advantage learning is built for the pendulum and the acrobot with 3 actions");
   }
   const bool ac = c.agent == GRLX_AGENT_AC;
+  const bool qv = c.agent == GRLX_AGENT_QV;
+  if (qv && ((c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) || c.action_steps != 3))
+    return fail(GRLX_ERR_INVALID, "predictor/critic/qv is built for the pendulum and the acrobot with 3 actions");
+  if (qv && !(c.beta > 0)) return fail(GRLX_ERR_INVALID, "predictor/critic/qv:beta");
   if (ac && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
   if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");
   if (!(c.control_step >= 0.00001)) return fail(GRLX_ERR_INVALID, "model/dynamical:control_step");
@@ -182,6 +186,16 @@ int make_params(const grlx_config &c, DevParams *P)
     P->ac_update_method = c.ac_update_method;
     if (c.ac_update_method != 0 && c.ac_update_method != 1) return fail(GRLX_ERR_INVALID, "predictor/ac/action:update_method");
     if (!(c.action_min < c.action_max)) return fail(GRLX_ERR_INVALID, "policy/action:{output_min,output_max}");
+  }
+
+  if (qv)
+  { // predictor/critic/qv: table 0 = the policy's Q representation (first in the yaml), table 1 = v_representation
+    rc = make_tile_params(c.actor_projector, &P->tile_actor);
+    if (rc != GRLX_OK) return rc;
+    if (P->tile_actor.T != kLanesPerReplica) return fail(GRLX_ERR_INVALID, "v_projector/tile_coding:tilings must be %d on the fused path", kLanesPerReplica);
+    if (P->tile_actor.D != D) return fail(GRLX_ERR_INVALID, "v_projector/tile_coding:resolution must have %d entries (observation)", D);
+    make_linear_params(c.actor_representation, (uint64_t)c.projector.memory, &P->lin_actor);   // drawn after the Q table
+    P->beta = c.beta;
   }
 
   P->epsilon = c.epsilon;
@@ -367,7 +381,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
   P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
 
-  const size_t n_tables = cfg->agent == GRLX_AGENT_AC ? 2 : 1;
+  const size_t n_tables = (cfg->agent == GRLX_AGENT_AC || cfg->agent == GRLX_AGENT_QV) ? 2 : 1;
   ctx->n_tables = (int)n_tables;
   const size_t table_bytes = ((size_t)N * n_tables * sizeof(Entry)) << logC;
 #define CTX_TRY(expr)                                                                        \
@@ -412,7 +426,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   //   memory*outputs uniforms drawn -> learning sampler Rand (global #2) -> test sampler Rand (global #3).
   std::vector<ReplicaState> hs((size_t)N);
   uint64_t table_draws = (uint64_t)cfg->projector.memory;              // outputs = 1
-  if (cfg->agent == GRLX_AGENT_AC) table_draws += (uint64_t)cfg->actor_projector.memory;
+  if (cfg->agent == GRLX_AGENT_AC || cfg->agent == GRLX_AGENT_QV) table_draws += (uint64_t)cfg->actor_projector.memory;
   for (int r = 0; r < N; ++r)
   {
     ReplicaState &s = hs[(size_t)r];
@@ -506,6 +520,8 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
     const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
     if (ctx->cfg.agent == GRLX_AGENT_AC)
       HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+    else if (ctx->cfg.agent == GRLX_AGENT_QV)
+      HIP_TRY(launch_rollout_qv(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else
       HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
   }

@@ -101,6 +101,7 @@ struct DevParams {
   int32_t  no_specialisation;   // tests: force the generic kernel even when a specialised instantiation matches
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
   double   kappa;               // predictor/critic/advantage: advantage scaling factor
+  double   beta;                // predictor/critic/qv: state-value learning rate
 };
 
 // ---------------------------------------------------------------------------
@@ -108,6 +109,7 @@ struct DevParams {
 // *variant (optional) receives the GRLX_KERNEL_* instantiation that was launched
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+hipError_t launch_rollout_qv(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);

@@ -505,6 +505,39 @@ struct ExpectedSARSAPredictor : TDPredictorBase {
   }
 };
 GRLX_REGISTER(ExpectedSARSAPredictor)
+// predictor/critic/qv (qv.cpp:35-64): Q(s,a) and V(s) tables, the trace on V
+struct QVPredictor : TDPredictorBase {
+  GRLX_TYPEINFO("predictor/critic/qv")
+  double beta = 0.1;
+  TileCodingProjector *v_projector = nullptr; LinearRepresentation *v_representation = nullptr;
+  int agent_id() const override { return GRLX_AGENT_QV; }
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("alpha", "State-action value learning rate", 0.2));
+    config->push_back(CRP("beta", "State value learning rate", 0.1));
+    config->push_back(CRP("gamma", "Discount rate", 0.97));
+    config->push_back(CRP("lambda", "Trace decay rate", 0.65));
+    config->push_back(CRP("q_projector", "projector.pair", "Projects observation-action pairs onto representation space", (Configurable *)nullptr));
+    config->push_back(CRP("q_representation", "representation.value/action", "State-action value representation (Q)", (Configurable *)nullptr));
+    config->push_back(CRP("v_projector", "projector.observation", "Projects observations onto representation space", (Configurable *)nullptr));
+    config->push_back(CRP("v_representation", "representation.value/state", "State value representation (V)", (Configurable *)nullptr));
+    config->push_back(CRP("trace", "trace", "Trace of projections", (Configurable *)nullptr, true));
+    config->push_back(CRP("importer", "importer", "Optional importer", (Configurable *)nullptr, true));
+    config->push_back(CRP("exporter", "exporter", "Optional exporter", (Configurable *)nullptr, true));
+  }
+  void configure(Configuration &config) override
+  {
+    alpha = config["alpha"]; beta = config["beta"]; gamma = config["gamma"]; lambda = config["lambda"];
+    projector = dynamic_cast<TileCodingProjector *>(config["q_projector"].ptr());
+    representation = dynamic_cast<LinearRepresentation *>(config["q_representation"].ptr());
+    v_projector = dynamic_cast<TileCodingProjector *>(config["v_projector"].ptr());
+    v_representation = dynamic_cast<LinearRepresentation *>(config["v_representation"].ptr());
+    trace = dynamic_cast<Trace *>(config["trace"].ptr());
+    if (!projector || !representation || !v_projector || !v_representation) throw Exception(path() + ": projectors/representations outside the accelerated path");
+    if (config["importer"].ptr() || config["exporter"].ptr()) throw Exception(path() + ": importer/exporter are outside the accelerated path");
+  }
+};
+GRLX_REGISTER(QVPredictor)
 // names from before the reference's predictor/critic/* rename, still used by its tests/pendulum-sarsa-tc.yaml
 struct SARSAPredictorLegacy : SARSAPredictor { GRLX_TYPEINFO("predictor/sarsa") };
 GRLX_REGISTER(SARSAPredictorLegacy)
@@ -857,16 +890,27 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     c->agent = pred->agent_id();
     c->alpha = pred->alpha; c->gamma = pred->gamma; c->lambda = pred->lambda; c->kappa = pred->kappa;
     c->trace = pred->trace ? pred->trace->kind() : GRLX_TRACE_NONE;
+    if (const QVPredictor *qv = dynamic_cast<const QVPredictor *>(pred))
+    { // second table: V(s); its weights are drawn from the thread-local stream after the Q table's
+      if (!(order_of(qv->v_representation) > at_repr))
+        throw Exception(qv->path() + ": v_representation must be instantiated after the policy's representation");
+      lower_tile(qv->v_projector, &c->actor_projector);
+      lower_linear(qv->v_representation, qv->v_projector, &c->actor_representation);
+      c->beta = qv->beta;
+    }
   }
 
-  // the parameterized representations of the agent in table order: 0 = Q / critic, 1 = actor
+  // the parameterized representations of the agent in table order: 0 = Q / critic, 1 = actor / V
   std::vector<const Configurable *> representations() const
   {
     std::vector<const Configurable *> reprs;
     if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
     { reprs.push_back(ac->critic->representation); reprs.push_back(ac->representation); }
     else
+    {
       reprs.push_back(dynamic_cast<const QPolicy *>(agent->policy)->representation);
+      if (const QVPredictor *qv = dynamic_cast<const QVPredictor *>(agent->predictor)) reprs.push_back(qv->v_representation);
+    }
     return reprs;
   }
 

@@ -42,7 +42,9 @@ enum { GRLX_AGENT_SARSA = 0,         /* agent/td + policy/discrete/q + predictor
        GRLX_AGENT_Q = 1,             /* ... + predictor/critic/q (advantage.cpp:71-110)                       */
        GRLX_AGENT_AC = 2,            /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */
        GRLX_AGENT_EXPECTED_SARSA = 3,/* ... + predictor/critic/expected_sarsa (sarsa.cpp:167-194)              */
-       GRLX_AGENT_ADVANTAGE = 4      /* ... + predictor/critic/advantage (advantage.cpp:222-268), `kappa`     */ };
+       GRLX_AGENT_ADVANTAGE = 4,     /* ... + predictor/critic/advantage (advantage.cpp:222-268), `kappa`     */
+       GRLX_AGENT_QV = 5             /* ... + predictor/critic/qv (qv.cpp:74-108): table 0 = Q, table 1 = V
+                                        (v_projector / v_representation in the actor_* fields), `beta`     */ };
 enum { GRLX_TRACE_NONE = 0, GRLX_TRACE_REPLACING = 1, GRLX_TRACE_ACCUMULATING = 2 };   /* trace.h:208-263 */
 
 #define GRLX_MAX_DIMS 8
@@ -110,6 +112,9 @@ typedef struct {
   double   negative_reward;           /* default -100  */
   /* predictor/critic/advantage (advantage.cpp:183-213) */
   double   kappa;                     /* advantage scaling factor (cfg/pendulum/advantage_tc.yaml: 0.2) */
+  /* predictor/critic/qv (qv.cpp:35-64): state-value learning rate; V's projector / representation
+   * are given in actor_projector / actor_representation (the second table of the context) */
+  double   beta;
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;

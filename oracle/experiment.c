@@ -434,6 +434,33 @@ static double ac_update(orc_exp *e, const double *prev_obs, double prev_action, 
   return critique;
 }
 
+static double qv_update(orc_exp *e, const double *prev_obs, double prev_action, double tau, double reward,
+                        const double *obs, int has_action, orc_proj *qpout, orc_proj *vpout)
+{ /* QVPredictor::criticize, qv.cpp:74-108: Q(s,a) and V(s) both move towards r + gamma^tau V(s');
+   * only V has a trace.  Table 0 = Q (the policy's), table 1 = V.  parity unpinned by reference tests. */
+  const orc_spec *s = &e->spec;
+  orc_proj qp, vp, vn;
+  project_sa(e, prev_obs, prev_action, &qp);
+  project_obs(&s->actor_projector, prev_obs, &vp);
+  project_obs(&s->actor_projector, obs, &vn);
+  const double vnext = lin_read(e, 1, &s->actor_representation, &vn);
+  double target = reward;
+  if (has_action)
+    target += orc_m_powtau(s, s->gamma, tau) * vnext;
+  double delta = target - lin_read(e, 1, &s->actor_representation, &vp);
+  lin_write(e, 0, &s->representation, &qp, target, s->alpha);            /* Q update */
+  lin_write(e, 1, &s->actor_representation, &vp, target, s->beta);       /* V update */
+  if (s->trace != ORC_TRACE_NONE)
+  {
+    double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
+    lin_update_trace(e, 1, &s->actor_representation, &e->trace, s->beta * delta, ee);
+    trace_add(&e->trace, s->trace, &vp, ee);
+  }
+  *qpout = qp;
+  *vpout = vp;
+  return delta;
+}
+
 /* ---------------------------------------------------------------- agent -- */
 typedef struct { double value; int index; double q[ORC_MAX_ACTIONS]; } act_t;
 
@@ -468,7 +495,8 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
 {
   if (orc_env_state_dims(spec->env) < 0) return NULL;             /* environments not restated yet */
   if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC && spec->agent != ORC_AGENT_EXPECTED_SARSA &&
-      spec->agent != ORC_AGENT_ADVANTAGE) return NULL;
+      spec->agent != ORC_AGENT_ADVANTAGE && spec->agent != ORC_AGENT_QV) return NULL;
+  if (spec->agent == ORC_AGENT_QV && (spec->actor_projector.dims != orc_env_obs_dims(spec->env) || spec->actor_projector.tilings > ORC_MAX_TILINGS)) return NULL;
   if (spec->agent == ORC_AGENT_ADVANTAGE && !(spec->kappa > 0)) return NULL;
   if (spec->agent == ORC_AGENT_AC)
   {
@@ -512,6 +540,12 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
   }
   e->w[0] = table_alloc_init(e, &spec->projector, &spec->representation);
   if (!e->w[0]) { free(e->w[1]); free(e); return NULL; }
+  if (spec->agent == ORC_AGENT_QV)
+  { /* cfg/pendulum/qv_tc.yaml order: the policy's Q representation first, then the predictor's
+     * v_representation; both draw from the same thread-local stream */
+    e->w[1] = table_alloc_init(e, &spec->actor_projector, &spec->actor_representation);
+    if (!e->w[1]) { free(e->w[0]); free(e); return NULL; }
+  }
   e->ac_decay = 1;
   e->eps_decay = 1;
   trace_clear(&e->trace);
@@ -616,6 +650,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
           else if (s->agent == ORC_AGENT_ADVANTAGE)
             delta = advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
+          else if (s->agent == ORC_AGENT_QV)
+            delta = qv_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
           else
             delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
         }
@@ -632,6 +668,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
           else if (s->agent == ORC_AGENT_ADVANTAGE)
             delta = advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
+          else if (s->agent == ORC_AGENT_QV)
+            delta = qv_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
           else
             delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
           memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);

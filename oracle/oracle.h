@@ -64,7 +64,7 @@ enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };
 
 /* ---------------------------------------------------------------- spec -- */
 enum { ORC_ENV_PENDULUM = 0, ORC_ENV_CART_POLE = 1, ORC_ENV_ACROBOT = 2, ORC_ENV_COMPASS_WALKER = 3 };
-enum { ORC_AGENT_SARSA = 0, ORC_AGENT_Q = 1, ORC_AGENT_AC = 2, ORC_AGENT_EXPECTED_SARSA = 3, ORC_AGENT_ADVANTAGE = 4 };
+enum { ORC_AGENT_SARSA = 0, ORC_AGENT_Q = 1, ORC_AGENT_AC = 2, ORC_AGENT_EXPECTED_SARSA = 3, ORC_AGENT_ADVANTAGE = 4, ORC_AGENT_QV = 5 };
 enum { ORC_TRACE_NONE = 0, ORC_TRACE_REPLACING = 1, ORC_TRACE_ACCUMULATING = 2 };
 enum { ORC_AC_PROPORTIONAL = 0, ORC_AC_CACLA = 1 };
 
@@ -124,6 +124,8 @@ typedef struct {
   int    tap_starts;                  /* 1: also record the start of every trial (terminal = -1) */
   /* predictor/critic/advantage */
   double kappa;                       /* advantage scaling factor (advantage.cpp:188, cfg: 0.2)  */
+  /* predictor/critic/qv: Q = projector/representation (table 0), V = actor_projector/actor_representation (table 1) */
+  double beta;                        /* state value learning rate (qv.cpp:40, cfg: 0.1)         */
 } orc_spec;
 
 /* fill with the values of the reference's tests/pendulum-sarsa-tc.yaml */

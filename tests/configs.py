@@ -77,3 +77,20 @@ def compass_walker(grlx, n, agent=1, **over):
     spec.action_min, spec.action_max, spec.action_steps = -1.2, 1.2, 3
     _set_tile(spec.projector, 16, 8388608, res, wrap)
     return cfg, spec
+
+
+def pendulum_qv(grlx, n, **over):
+    """cfg/pendulum/qv_tc.yaml: policy/discrete/value/q over the Q table (table 0), predictor/critic/qv with a
+    tile-coded state-value table V (table 1: the second projector / representation of the config), beta = 0.1."""
+    DBL_MAX = 1.7976931348623157e308
+    spec = ob.pendulum_sarsa_spec(agent=ob.AGENT_QV, beta=0.1)
+    _set_tile(spec.actor_projector, 16, 8388608, [0.31415, 3.1415], [6.283, 0])
+    ar = spec.actor_representation
+    ar.init_min, ar.init_max, ar.output_min, ar.output_max, ar.limit = 0.0, 1.0, -DBL_MAX, DBL_MAX, 1
+    cfg = None
+    if grlx is not None:
+        cfg = grlx.pendulum_sarsa_config(n, agent=5, beta=0.1, **over)
+        _set_tile(cfg.actor_projector, 16, 8388608, [0.31415, 3.1415], [6.283, 0])
+        cr = cfg.actor_representation
+        cr.init_min, cr.init_max, cr.output_min, cr.output_max, cr.limit = 0.0, 1.0, -DBL_MAX, DBL_MAX, 1
+    return cfg, spec

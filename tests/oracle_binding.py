@@ -16,7 +16,7 @@ LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 MAX_DIMS, MAX_STATE = 8, 12
 MATH_LIBM, MATH_PORTABLE = 0, 1
 ENV_PENDULUM = 0
-AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE = 0, 1, 2, 3, 4
+AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE, AGENT_QV = 0, 1, 2, 3, 4, 5
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
 
@@ -42,7 +42,7 @@ class Spec(C.Structure):
                 ("actor_projector", TileSpec), ("actor_representation", LinearSpec),
                 ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double),
-                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int), ("kappa", C.c_double)]
+                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int), ("kappa", C.c_double), ("beta", C.c_double)]
 
 
 class Row(C.Structure):

@@ -282,6 +282,87 @@ def test_advantage_learning_bit_exact(grlx):
         grlx.Runner(grlx.pendulum_sarsa_config(1, agent=4), [1])
 
 
+def test_qv_learning_bit_exact(grlx):
+    """predictor/critic/qv (qv.cpp:74-108; cfg/pendulum/qv_tc.yaml): Q table read by the policy and written
+    without a trace, V table with the trace.  Every step of one replica (both projections, Q(s', .), actions,
+    TD errors, trace length), rows / RNG / sampled weights of both tables of all; two launches."""
+    from tests import configs
+    seeds, trials, cap = [71, 72, 73, 74, 75], 23, 2400
+    cfg, spec = configs.pendulum_qv(grlx, len(seeds), tap_replica=1, tap_capacity=cap)
+    r = grlx.Runner(cfg, seeds)
+    r.run(12); r.run(11); r.sync()
+    rng = np.random.default_rng(5)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, otaps = e.run(trials, tap_cap=cap)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3]
+        assert_bit_equal(r.env_state(k), e.state(), "env state")
+        if k == 1:
+            gtaps = r.taps()
+            assert len(gtaps) == len(otaps) == trials * 100
+            for i, (gt, ot) in enumerate(zip(gtaps, otaps)):
+                try:
+                    assert list(gt.p_idx[16:32]) == list(ot.p_idx[16:32])
+                    _compare_taps(gt, ot)
+                except AssertionError as ex:
+                    raise AssertionError(f"step {i}: {ex}")
+            tq = np.unique(np.array([list(tp.p_idx[:16]) for tp in otaps if not tp.test]).ravel()).astype(np.uint32)
+            tv = np.unique(np.array([list(tp.p_idx[16:32]) for tp in otaps if not tp.test]).ravel()).astype(np.uint32)
+            assert_bit_equal(r.weights(k, tq, table=0), e.weights(tq, table=0), "Q weights touched")
+            assert_bit_equal(r.weights(k, tv, table=1), e.weights(tv, table=1), "V weights touched")
+        slots = rng.integers(0, 8388608, 1000).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots, table=0), e.weights(slots, table=0), "Q weights")
+        assert_bit_equal(r.weights(k, slots, table=1), e.weights(slots, table=1), "V weights")
+    r.close()
+    # many replicas, no taps, tiny hash memories (shared slots in both tables)
+    seeds = list(range(80, 93))
+    cfg, spec = configs.pendulum_qv(grlx, len(seeds))
+    cfg.projector.memory = spec.projector.memory = 4096
+    cfg.actor_projector.memory = spec.actor_projector.memory = 1024
+    r = grlx.Runner(cfg, seeds)
+    r.run(33); r.sync()
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, _ = e.run(33)
+        assert_bit_equal(r.rows(k)[2], [x.reward for x in rows], f"small-memory returns of seed {seed}")
+        assert_bit_equal(r.export_weights(k, table=0), e.all_weights(0), "Q table")
+        assert_bit_equal(r.export_weights(k, table=1), e.all_weights(1), "V table")
+    r.close()
+
+
+def test_deployer_qv_learning(grlx, tmp_path):
+    """grlxd with predictor/critic/qv (the predictor block of cfg/pendulum/qv_tc.yaml): rows = oracle's, and
+    save_every: run writes one .dat per representation (Q and V) equal to the oracle's dense tables."""
+    import subprocess
+    from grl_amd import _build
+    from tests import configs
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    old_block = "      projector: ../../policy/projector\n      representation: ../../policy/representation\n"
+    new_block = ("      beta: 0.1\n      q_projector: ../../policy/projector\n      q_representation: ../../policy/representation\n"
+                 "      v_projector:\n        type: projector/tile_coding\n        tilings: 16\n        memory: 8388608\n"
+                 "        resolution: [ 0.31415, 3.1415 ]\n        wrapping: [ 6.283, 0 ]\n"
+                 "      v_representation:\n        type: representation/parameterized/linear\n        init_min: [ 0 ]\n        init_max: [ 1 ]\n"
+                 "        memory: ../../v_projector/memory\n        outputs: 1\n        output_min: [ ]\n        output_max: [ ]\n")
+    assert old_block in text
+    text = text.replace(old_block, new_block).replace("      type: predictor/sarsa\n", "      type: predictor/critic/qv\n")
+    y = tmp_path / "qv.yaml"
+    y.write_text(text.replace("trials: 2000", "trials: 33").replace("save_every: never", "save_every: run"))
+    res = subprocess.run([grlxd, "-s", "8", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    _, spec = configs.pendulum_qv(None, 1)
+    e = ob.Experiment(spec, seed=8)
+    rows, _ = e.run(33)
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)
+    q = np.fromfile(tmp_path / "pendulum-sarsa-tc-run0-experiment_agent_policy_representation.dat", dtype="<f8")
+    v = np.fromfile(tmp_path / "pendulum-sarsa-tc-run0-experiment_agent_predictor_v_representation.dat", dtype="<f8")
+    assert_bit_equal(q, e.all_weights(0), "Q .dat")
+    assert_bit_equal(v, e.all_weights(1), "V .dat")
+
+
 def test_deployer_advantage_learning(grlx, tmp_path):
     """grlxd with predictor/critic/advantage (the predictor block of cfg/pendulum/advantage_tc.yaml): rows = oracle's."""
     import subprocess
