@@ -131,7 +131,13 @@ int make_params(const grlx_config &c, DevParams *P)
   if (c.integration_steps < 1) return fail(GRLX_ERR_INVALID, "model/dynamical:integration_steps");
   if (!ac && (c.action_steps < 1 || c.action_steps > GRLX_MAX_ACTIONS)) return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps (1..%d supported)", GRLX_MAX_ACTIONS);
   if (ac && c.trace != GRLX_TRACE_REPLACING && c.trace != GRLX_TRACE_NONE) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
-  if (c.trace != GRLX_TRACE_NONE && c.trace != GRLX_TRACE_REPLACING) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
+  if (c.trace == GRLX_TRACE_ACCUMULATING)
+  { // its own (uncached, read-modify-write) kernel: SARSA / Q / Expected SARSA on the pendulum and the acrobot
+    if ((c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_EXPECTED_SARSA) ||
+        (c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) || c.action_steps != 3)
+      return fail(GRLX_ERR_INVALID, "trace/enumerated/accumulating is built for SARSA / Q / Expected SARSA on the pendulum and the acrobot with 3 actions");
+  }
+  else if (c.trace != GRLX_TRACE_NONE && c.trace != GRLX_TRACE_REPLACING) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
 
   P->test_interval = c.test_interval;
   P->env = c.env;
@@ -205,6 +211,14 @@ int make_params(const grlx_config &c, DevParams *P)
   P->kappa = c.kappa;
   P->gamma = c.gamma;                     // pow(gamma, tau) with tau = 1
   P->gl = c.gamma * c.lambda;             // pow(gamma*lambda, tau) with tau = 1
+  if (c.trace == GRLX_TRACE_ACCUMULATING)
+  { // trace.h:249-261: pops while the total decay < 1e-4; the position trace holds 20 entries
+    if (!(P->gl > 0 && P->gl < 1)) return fail(GRLX_ERR_INVALID, "predictor: gamma*lambda must be in (0,1) with a trace");
+    double tot = 1;
+    int n = 0;
+    while (tot >= 0.0001 && n <= 20) { tot *= P->gl; n++; }
+    if (n > 20) return fail(GRLX_ERR_INVALID, "predictor: gamma*lambda = %g needs an accumulating trace longer than 20 entries", P->gl);
+  }
   if (c.trace == GRLX_TRACE_REPLACING)
   { // the register trace holds kMaxTrace entries: the reference pops while the total decay < 0.01 (trace.h:227-231)
     if (!(P->gl > 0 && P->gl < 1)) return fail(GRLX_ERR_INVALID, "predictor: gamma*lambda must be in (0,1) with a trace");
@@ -522,6 +536,8 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
       HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.agent == GRLX_AGENT_QV)
       HIP_TRY(launch_rollout_qv(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+    else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
+      HIP_TRY(launch_rollout_acc(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else
       HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
   }

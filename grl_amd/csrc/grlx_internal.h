@@ -110,6 +110,7 @@ struct DevParams {
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_qv(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);

@@ -8,7 +8,8 @@ import grl_amd
 from tests import configs
 
 name, n, warm, trials = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-make = {"pendulum": configs.pendulum, "pendulum_q": lambda g, k: configs.pendulum(g, k, agent=1), "cart_pole_ac": configs.cart_pole_ac,
+make = {"pendulum_acc": lambda g, k: configs.pendulum(g, k, trace=2), "pendulum_adv": lambda g, k: configs.pendulum(g, k, agent=4, kappa=0.2),
+        "pendulum_qv": configs.pendulum_qv, "pendulum": configs.pendulum, "pendulum_q": lambda g, k: configs.pendulum(g, k, agent=1), "cart_pole_ac": configs.cart_pole_ac,
         "acrobot": configs.acrobot, "compass_walker": configs.compass_walker}[name]
 cfg, _ = make(grl_amd, n)
 cfg.max_rows = 256
