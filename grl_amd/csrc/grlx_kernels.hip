@@ -1254,8 +1254,11 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
     }
     if (HOLD) ev.n = 2u;                                   // weights moved between lanes: not tracked
   }
-  // a shared slot is kept current in the table; an exclusive one only if no trace follows
-  if (p_sh || !u.use_trace) value_store(tab, p_pos, v);
+  // a shared slot is kept current in the table; an exclusive one only if no trace follows.  (Rare per-lane
+  // blocks sit behind a wave-uniform test: skipping an exec-masked block is a TAKEN branch, ~30 cycles for a
+  // lone wave; a not-taken scalar branch is one issue slot.)
+  if (rarely(__any(p_sh || !u.use_trace)))
+    if (p_sh || !u.use_trace) value_store(tab, p_pos, v);
 
   // trace_->add(p, decay) (trace.h:215-234)
   if (u.use_trace)
@@ -1282,12 +1285,39 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
     if (p_sh) tr.wt |= 1u;
     tr.len = (tr.len < kMaxTrace) ? tr.len + 1 : kMaxTrace;
     tr.total *= u.ee;
-    while (tr.total < u.cut && tr.len > 1)
-    {
-      tr.total /= u.ee;
-      tr.len--;
+    { // pop while the total decay is below the cut (trace.h:227-231): the first pop as selects, more in a rare loop
+      const bool pop = tr.total < u.cut && tr.len > 1;
+      const double undone = tr.total / u.ee;
+      tr.total = pop ? undone : tr.total;
+      tr.len = pop ? tr.len - 1 : tr.len;
+      if (rarely(__any(tr.total < u.cut && tr.len > 1)))
+        while (tr.total < u.cut && tr.len > 1)
+        {
+          tr.total /= u.ee;
+          tr.len--;
+        }
     }
-    // entries popped off the front of the reference's deque: write their weights back
+    // entries popped off the front of the reference's deque: write their weights back.  In the steady state
+    // of a full trace exactly the entry that was shifted into the last register falls off.
+    if (!rarely(__any(tr.len != kMaxTrace - 1)))
+    {
+      constexpr int e = kMaxTrace - 1;
+      const bool wb = tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u);
+      if (HOLD)
+      {
+        const bool hold = wb && ev.n == 0u;
+        if (rarely(__any(wb && !hold)))
+          if (wb && !hold) value_store(tab, tr.pos[e], tr.val[e]);
+        ev.pos = hold ? tr.pos[e] : ev.pos;
+        ev.val = hold ? tr.val[e] : ev.val;
+        ev.n += wb ? 1u : 0u;
+      }
+      else if (wb)
+        value_store(tab, tr.pos[e], tr.val[e]);
+      tr.pos[e] = kInvalidPos;
+      tr.wt &= ~(1u << e);
+    }
+    else
 #pragma unroll
     for (int e = 0; e < kMaxTrace; ++e)
       if (e >= tr.len)
