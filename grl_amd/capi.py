@@ -50,7 +50,7 @@ class Config(C.Structure):
 class Tap(C.Structure):
     _fields_ = [("test", C.c_int32), ("action_index", C.c_int32), ("terminal", C.c_int32), ("trace_len", C.c_int32),
                 ("obs", C.c_double * MAX_DIMS), ("action", C.c_double), ("reward", C.c_double), ("delta", C.c_double),
-                ("q", C.c_double * MAX_ACTIONS), ("p_idx", C.c_uint32 * 32)]
+                ("q", C.c_double * MAX_ACTIONS), ("p_idx", C.c_uint32 * 32), ("state", C.c_double * MAX_STATE)]
 
 
 class GrlxError(RuntimeError):

@@ -1978,6 +1978,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
               tp->reward = reward;
+              for (int i = 0; i < GRLX_MAX_STATE; ++i) tp->state[i] = (i < S) ? x[i] : 0.;
               tp->delta = delta;
               for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
 #pragma unroll
@@ -2389,6 +2390,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? a_next : action;
               tp->reward = reward;
+              for (int i = 0; i < GRLX_MAX_STATE; ++i) tp->state[i] = (i < S) ? x[i] : 0.;
               tp->delta = delta;
               for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
               tp->q[0] = has_next ? u_next : 0.;
@@ -2717,6 +2719,7 @@ __global__ __launch_bounds__(64) void rollout_qv_kernel(DevParams P, int n_trial
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
               tp->reward = reward;
+              for (int i = 0; i < GRLX_MAX_STATE; ++i) tp->state[i] = (i < S) ? x[i] : 0.;
               tp->delta = delta;
               for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
 #pragma unroll
@@ -3096,6 +3099,7 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
               for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
               tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
               tp->reward = reward;
+              for (int i = 0; i < GRLX_MAX_STATE; ++i) tp->state[i] = (i < S) ? x[i] : 0.;
               tp->delta = delta;
               for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
 #pragma unroll

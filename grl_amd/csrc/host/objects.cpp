@@ -234,6 +234,7 @@ struct ModeledEnvironment : Configurable {
   Model *model = nullptr;
   Task *task = nullptr;
   int discrete_time = 1;
+  Configurable *exporter = nullptr;     // optional exporter/csv for the transition log with the model state (modeled.cpp:67-71)
   void request(const std::string &, ConfigurationRequest *config) override
   {
     config->push_back(CRP("discrete_time", "Always report unit step time", 1));
@@ -254,7 +255,7 @@ struct ModeledEnvironment : Configurable {
     if (!model || !task) throw Exception(path() + ": model/task outside the accelerated path");
     if ((int)config["window"] != 1 || (int)config["stride"] != 1 || !config["delta"].v().empty())
       throw Exception(path() + ": window/stride/delta are not supported by the accelerated path");
-    if (config["exporter"].ptr()) throw Exception(path() + ": exporters are not supported by the accelerated path");
+    exporter = config["exporter"].ptr();
     if (discrete_time != 1) throw Exception(path() + ": discrete_time must be 1 on the accelerated path");
     if (model->env_id() != task->env_id()) throw Exception(path() + ": task does not match the model");
     // forward the task's provided parameters (modeled.cpp:79-114)
@@ -745,7 +746,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
   int runs = 1, run_offset = 0, trials = 0, steps = 0, test_interval = -1, test_trials = 1;
   std::string output, load_file, save_every;
   ModeledEnvironment *environment = nullptr; TDAgent *agent = nullptr; FixedAgent *test_agent = nullptr;
-  CSVExporter *exporter = nullptr;
+  CSVExporter *exporter = nullptr, *env_exporter = nullptr;
 
   void request(const std::string &, ConfigurationRequest *config) override
   { // online_learning.cpp:40-62
@@ -784,6 +785,9 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     exporter = dynamic_cast<CSVExporter *>(config["exporter"].ptr());
     if (config["exporter"].ptr() && !exporter) throw Exception(path() + ": only exporter/csv is available on the accelerated path");
     if (exporter) exporter->init({"time", "observation", "action", "reward", "terminal"});      // online_learning.cpp:74-75
+    env_exporter = dynamic_cast<CSVExporter *>(environment->exporter);
+    if (environment->exporter && !env_exporter) throw Exception(environment->path() + ": only exporter/csv is available on the accelerated path");
+    if (env_exporter) env_exporter->init({"time", "state", "observation", "action", "reward", "terminal"});   // modeled.cpp:70-71
   }
 
   // lower the instantiated graph to the C ABI's grlx_config; every assumption the fused kernels make is checked
@@ -925,7 +929,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     std::vector<double> curve;
     int obs_dims = 0, state_dims = 0;
     grlx_env_dims(c.env, &state_dims, &obs_dims);
-    if (exporter)
+    if (exporter || env_exporter)
     { // transition log of replica 0: every step and every trial start is tapped on the device and
       // written after the run (the reference writes one row per step, online_learning.cpp:183-206)
       const double per_trial = std::floor(c.timeout / c.control_step) + 3;
@@ -979,12 +983,43 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       if (rc != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
       double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 
-      if (exporter)
-      { // online_learning.cpp:127-131 (new numbered files per run), :164-165 (append per trial), :183-206 (rows)
-        std::vector<grlx_tap> taps((size_t)c.tap_capacity);
-        int ntaps = 0;
+      std::vector<grlx_tap> taps;
+      int ntaps = 0;
+      if (exporter || env_exporter)
+      {
+        taps.resize((size_t)c.tap_capacity);
         if (grlx_read_taps(ctx, taps.data(), c.tap_capacity, &ntaps) != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
         if (ntaps == c.tap_capacity) log(1, "transition log truncated at " + std::to_string(ntaps) + " rows");
+      }
+      if (env_exporter)
+      { // ModeledEnvironment's own log (modeled.cpp:156-157, 200-203): one row per step with the state the step started
+        // from and the environment's cumulative learn / test time BEFORE the step; a numbered file per variant is
+        // started by the first episode of that variant, later episodes append
+        double time_learn = 0, time_test = 0, applied_time_step = c.control_step;
+        std::vector<double> before((size_t)state_dims, 0.);
+        bool is_test = false;
+        for (int k = 0; k < ntaps; ++k)
+        {
+          const grlx_tap &tp = taps[(size_t)k];
+          if (tp.terminal == -1)
+          {
+            is_test = tp.test != 0;
+            env_exporter->open(is_test ? "test" : "learn", (is_test ? time_test : time_learn) != 0.0);
+          }
+          else
+          {
+            double &time = is_test ? time_test : time_learn;
+            const std::vector<double> obs(tp.obs, tp.obs + obs_dims);
+            // the action of this row is the one the step was taken with: the previous record's
+            env_exporter->write({{time}, before, obs, {taps[(size_t)k - 1].action}, {tp.reward}, {(double)tp.terminal}});
+            time += applied_time_step;                 // model tau = control_step (modeled.cpp:176, 203)
+          }
+          before.assign(tp.state, tp.state + state_dims);
+        }
+        env_exporter->close();
+      }
+      if (exporter)
+      { // online_learning.cpp:127-131 (new numbered files per run), :164-165 (append per trial), :183-206 (rows)
         exporter->open("test", false);
         exporter->open("learn", false);
         double total_time = 0, applied = 0;

@@ -127,6 +127,7 @@ typedef struct {
   double   action, reward, delta;
   double   q[GRLX_MAX_ACTIONS];
   uint32_t p_idx[32];
+  double   state[GRLX_MAX_STATE];     /* model state after this step (start record: the start state) */
 } grlx_tap;
 
 const char *grlx_last_error(void);

@@ -616,6 +616,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
       tp->action = act.value;
       tp->terminal = -1;
       tp->trace_len = e->trace.len;
+      memcpy(tp->state, e->state, sizeof(double) * (size_t)orc_env_state_dims(s->env));
       for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = act.q[a];
     }
 
@@ -691,6 +692,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
         tp->reward = reward;
         tp->terminal = terminal;
         tp->trace_len = e->trace.len;
+        memcpy(tp->state, e->state, sizeof(double) * (size_t)orc_env_state_dims(s->env));
         for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = act.q[a];
         tp->delta = delta;
         for (int j = 0; j < p.n && j < 16; ++j) tp->p_idx[j] = (uint32_t)p.idx[j];

@@ -166,6 +166,7 @@ typedef struct {
   double   q[8];                 /* Q(s', .) as seen by the policy            */
   double   delta;                /* TD error of the update (learning only)    */
   uint32_t p_idx[32];            /* indices of project(s, a) that was updated */
+  double   state[ORC_MAX_STATE]; /* model state after this step (start record: the start state) */
 } orc_tap;
 
 typedef struct {

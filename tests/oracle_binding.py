@@ -52,7 +52,7 @@ class Row(C.Structure):
 class Tap(C.Structure):
     _fields_ = [("test", C.c_int32), ("action_index", C.c_int32), ("obs", C.c_double * MAX_DIMS),
                 ("action", C.c_double), ("reward", C.c_double), ("terminal", C.c_int32), ("trace_len", C.c_int32),
-                ("q", C.c_double * 8), ("delta", C.c_double), ("p_idx", C.c_uint32 * 32)]
+                ("q", C.c_double * 8), ("delta", C.c_double), ("p_idx", C.c_uint32 * 32), ("state", C.c_double * MAX_STATE)]
 
 
 class Stats(C.Structure):

@@ -1001,6 +1001,45 @@ def test_deployer_compass_walker_rows_equal_oracle(grlx, tmp_path):
     assert (tmp_path / "compass_walker-q-tc-0.txt").read_text() == e.format_rows(rows)
 
 
+def test_deployer_environment_transition_log(grlx, tmp_path):
+    """environment/modeled:exporter (modeled.cpp:67-71, 156-157, 200-203): time, state, observation, action, reward,
+    terminal per step, where time is the environment's cumulative learn / test time before the step and state the
+    model state the step started from -- against the oracle's records.  Together with the experiment's own log."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    old_env = "    exporter: 0\n    type: environment/modeled\n"
+    assert old_env in text
+    text = text.replace(old_env, "    exporter:\n      type: exporter/csv\n      file: envlog\n    type: environment/modeled\n")
+    text = text.replace('  load_file: ""\n', '  exporter:\n    type: exporter/csv\n    file: explog\n    variant: test\n  load_file: ""\n')
+    y = tmp_path / "envlog.yaml"
+    y.write_text(text.replace("trials: 2000", "trials: 23"))
+    res = subprocess.run([grlxd, "-s", "4", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.Experiment(ob.pendulum_sarsa_spec(tap_starts=1), seed=4)
+    rows, otaps = e.run(23, tap_cap=3000)
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)
+    names = ["time", "state", "observation", "action", "reward", "terminal"]
+    width = {"time": 1, "state": 3, "observation": 2, "action": 1, "reward": 1, "terminal": 1}
+    header = ", ".join(f"{n}[{k}]" for n in names for k in range(width[n]))
+    want = {False: [header], True: [header]}
+    clock = {False: 0.0, True: 0.0}
+    before, applied, variant = None, 0.0, False
+    for tp in otaps:
+        if tp.terminal == -1:
+            variant = bool(tp.test)
+        else:
+            vals = [clock[variant]] + before + list(tp.obs[:2]) + [applied, tp.reward, float(tp.terminal)]
+            want[variant].append(", ".join(f"{v:11.6f}" for v in vals))
+            clock[variant] += 0.03
+        before, applied = list(tp.state[:3]), tp.action
+    for which, key in (("learn", False), ("test", True)):
+        assert (tmp_path / f"envlog-{which}-0.csv").read_text() == "".join(l + "\n" for l in want[key]), which
+    assert (tmp_path / "explog-test-0.csv").read_text() == _expected_csv(otaps, 2, "line", "", True)
+    assert not (tmp_path / "explog-learn-0.csv").exists()
+
+
 # ----------------------------------------------------------- edge cases -----
 def test_empty_batches_and_bad_arguments(grlx):
     """n = 0 is legal everywhere; out-of-range arguments come back as GRLX_ERR_INVALID, never a crash."""
