@@ -3,6 +3,25 @@ import numpy as np
 
 from tests import oracle_binding as ob
 
+# tools/ (profiling helpers) reuse these builders for the grlx_config half only: with NO_ORACLE set the
+# oracle is neither built nor loaded and the spec half is a placeholder that swallows assignments
+NO_ORACLE = False
+
+
+class _NoSpec:
+    def __getattr__(self, name):
+        return _NoSpec()
+
+    def __setattr__(self, name, value):
+        pass
+
+    def __setitem__(self, key, value):
+        pass
+
+
+def _spec(**kw):
+    return _NoSpec() if NO_ORACLE else ob.pendulum_sarsa_spec(**kw)
+
 
 def _set_tile(ts, tilings, memory, resolution, wrapping):
     ts.tilings, ts.memory, ts.dims = tilings, memory, len(resolution)
@@ -13,7 +32,7 @@ def _set_tile(ts, tilings, memory, resolution, wrapping):
 
 def pendulum(grlx, n, agent=0, **over):
     cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over)
-    spec = ob.pendulum_sarsa_spec(agent=agent)
+    spec = _spec(agent=agent)
     return cfg, spec
 
 
@@ -27,7 +46,7 @@ def acrobot(grlx, n, agent=1, **over):
     cfg.control_step, cfg.integration_steps, cfg.timeout = 0.05, 5, 20.0
     cfg.action_min, cfg.action_max, cfg.action_steps = -1.0, 1.0, 3
     _set_tile(cfg.projector, 16, 8388608, res, wrap)
-    spec = ob.pendulum_sarsa_spec(agent=agent)
+    spec = _spec(agent=agent)
     spec.env = 2
     spec.control_step, spec.integration_steps, spec.timeout = 0.05, 5, 20.0
     spec.action_min, spec.action_max, spec.action_steps = -1.0, 1.0, 3
@@ -39,7 +58,7 @@ def cart_pole_ac(grlx, n, **over):
     """cfg/cart_pole/ac_tc.yaml: dynamics/cart_pole + task/cart_pole/swingup, mapping/policy/action,
     predictor/ac/action with a predictor/critic/td critic; two 8,388,608-slot tables."""
     cfg = grlx.cart_pole_ac_config(n, **over)
-    spec = ob.pendulum_sarsa_spec()
+    spec = _spec()
     spec.env, spec.agent = 1, ob.AGENT_AC
     spec.control_step, spec.integration_steps, spec.timeout, spec.randomization = 0.05, 5, 9.99, 0.0
     spec.end_stop_penalty, spec.action_penalty = cfg.end_stop_penalty, cfg.action_penalty
@@ -55,7 +74,7 @@ def cart_pole_ac(grlx, n, **over):
     spec.actor_alpha, spec.sigma, spec.theta = 0.01, 5.0, 1.0
     spec.ac_decay_rate, spec.ac_decay_min, spec.ac_update_method, spec.ac_step_limit = 1.0, 0.0, 0, -1.0
     for k, v in over.items():
-        if hasattr(spec, k) and k not in ("tap_replica", "tap_capacity"):
+        if not NO_ORACLE and hasattr(spec, k) and k not in ("tap_replica", "tap_capacity"):
             setattr(spec, k, v)
     return cfg, spec
 
@@ -70,7 +89,7 @@ def compass_walker(grlx, n, agent=1, **over):
     cfg.slope_angle, cfg.initial_state_variation, cfg.negative_reward = 0.004, 0.2, -100.0
     cfg.action_min, cfg.action_max, cfg.action_steps = -1.2, 1.2, 3
     _set_tile(cfg.projector, 16, 8388608, res, wrap)
-    spec = ob.pendulum_sarsa_spec(agent=agent)
+    spec = _spec(agent=agent)
     spec.env = 3
     spec.control_step, spec.integration_steps, spec.timeout = 0.2, 20, 100.0
     spec.slope_angle, spec.initial_state_variation, spec.negative_reward = 0.004, 0.2, -100.0
@@ -83,7 +102,7 @@ def pendulum_qv(grlx, n, **over):
     """cfg/pendulum/qv_tc.yaml: policy/discrete/value/q over the Q table (table 0), predictor/critic/qv with a
     tile-coded state-value table V (table 1: the second projector / representation of the config), beta = 0.1."""
     DBL_MAX = 1.7976931348623157e308
-    spec = ob.pendulum_sarsa_spec(agent=ob.AGENT_QV, beta=0.1)
+    spec = _spec(agent=ob.AGENT_QV, beta=0.1)
     _set_tile(spec.actor_projector, 16, 8388608, [0.31415, 3.1415], [6.283, 0])
     ar = spec.actor_representation
     ar.init_min, ar.init_max, ar.output_min, ar.output_max, ar.limit = 0.0, 1.0, -DBL_MAX, DBL_MAX, 1

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import grl_amd
 from tests import configs
+configs.NO_ORACLE = True            # the grlx_config half of the builders only: the oracle is test infrastructure
 
 name, n, warm, trials = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 make = {"pendulum_acc": lambda g, k: configs.pendulum(g, k, trace=2), "pendulum_adv": lambda g, k: configs.pendulum(g, k, agent=4, kappa=0.2),

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import grl_amd
 from tests import configs
+configs.NO_ORACLE = True            # the grlx_config half of the builders only: the oracle is test infrastructure
 
 CASES = [("pendulum SARSA-tc", configs.pendulum, 4096, 110), ("pendulum Q-tc", lambda g, n: configs.pendulum(g, n, agent=1), 4096, 110),
          ("cart-pole AC-tc", configs.cart_pole_ac, 16384, 44), ("acrobot Q-tc", configs.acrobot, 8192, 110),
