@@ -2152,7 +2152,9 @@ __device__ __forceinline__ uint32_t tile_slot_obs(const TileParams &tp, const do
 
 #define SHA(row, k, g) sh_w[(((row) * 16 + (k)) << 2) + (g)]
 
-template <int ENV, typename SPEC>
+// DEFER: the critic's TD update of a step is applied one pass later, between the next step's table loads and
+// their first use (as in rollout_kernel); the taps need the in-place ordering.
+template <int ENV, typename SPEC, bool DEFER>
 __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trials)
 {
   // N: numeric parameters (compile-time constants in a specialised build); P: pointers and sizes
@@ -2221,6 +2223,10 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     }
   }
 
+  bool pd = false, pd_sh = false;          // pending critic update (DEFER)
+  double pd_dW = 0, pd_dT = 0, pd_wp = 0;
+  uint32_t pd_pos = kInvalidPos;
+
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
     const int ti = N.test_interval;
@@ -2240,7 +2246,13 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
 
     for (;;)
     {
-      if (!__any(running)) break;
+      if (!__any(running || pd)) break;
+      // state that lives across the deferred-update site
+      uint32_t slotA[1] = {0}, slotC[1] = {0};
+      Lookup lkA[1], lkC[1];
+      BucketRegs brA[1], brC[1];
+      double wap = 0, wpc = 0;
+      bool has_next = false, update = false, need_critic = false;
       if (running)
       {
         if (!first)
@@ -2249,30 +2261,50 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
           total_reward += reward;
           time += 1;
         }
-        const bool has_next = first || terminal != 2;
-        const bool update = !first && !test;
-        const bool need_critic = has_next && !test;
-
-        uint32_t slotA[1] = {0}, slotC[1] = {0}, posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
-        double wA[1] = {0}, wC[1] = {0};
-        bool shA[1] = {false}, shC[1] = {false};
+        has_next = first || terminal != 2;
+        update = !first && !test;
+        need_critic = has_next && !test;
         if (has_next)
         {
           slotA[0] = tile_slot_obs<T>(N.tile_actor, obs, D, j);
           slotC[0] = tile_slot_obs<T>(N.tile, obs, D, j);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        double wap = 0, wpc = 0;
         if (update)
         {
           wap = value_load(tabA, ap_pos);                // actor weights of project(prev_obs), current
           wpc = value_load(tabC, p_pos);                 // critic weights of project(prev_obs), as stored
         }
         // both tables' home buckets in flight together: one memory round trip for the two lookups
-        Lookup lkA[1], lkC[1];
-        BucketRegs brA[1], brC[1];
         if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
         if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
+      }
+
+      // -------- the PREVIOUS step's critic update, in the shadow of the loads just issued
+      Evicted ev;
+      ev.n = 0u; ev.pos = kInvalidPos; ev.val = 0;
+      if (DEFER)
+      {
+        if (pd)
+        {
+          sh_ppos[g * 16 + j] = pd_pos;
+          sh_fbflag[j * 4 + g] = 0u;
+        }
+        wave_sync();
+        if (pd)
+        {
+          up.dW = pd_dW;
+          up.dT = pd_dT;
+          td_update_lane<true>(tr, tabC, up, pd_pos, pd_sh, pd_wp, g, j, sh_ppos, sh_fb, sh_fbflag, status, ev);
+          pd = false;
+        }
+      }
+
+      if (running)
+      {
+        uint32_t posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
+        double wA[1] = {0}, wC[1] = {0};
+        bool shA[1] = {false}, shC[1] = {false};
         if (has_next)
         {
           table_get_finish<1>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
@@ -2283,21 +2315,37 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
           bool shared_event = false;
           table_get_finish<1>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
                        [&](uint32_t mp) {
+                         if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);
                          trace_share_event(tr, tabC, mp);
                          if (p_pos == mp) p_sh = true;
                          shared_event = true;
                        });
           if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, p_pos);
-          wC[0] = trace_forward(tr, posC[0], wC[0]);
         }
+        if (DEFER)
+        { // critic values loaded before the deferred update: reload where the update wrote the table, patch the held eviction
+          const bool risky = ev.n > 1u || (update && p_sh) || (need_critic && shC[0]);
+          if (rarely(__any(risky)))
+          {
+            if (need_critic) wC[0] = value_load(tabC, posC[0]);
+            if (update) wpc = value_load(tabC, p_pos);
+          }
+          const bool held = ev.pos != kInvalidPos;
+          wC[0] = (held && posC[0] == ev.pos) ? ev.val : wC[0];
+          wpc = (held && p_pos == ev.pos) ? ev.val : wpc;
+        }
+        if (need_critic) wC[0] = trace_forward(tr, posC[0], wC[0]);
         if (update) wpc = trace_forward(tr, p_pos, wpc);
         SHA(0, j, g) = wA[0];
         SHA(1, j, g) = wC[0];
         SHA(2, j, g) = wap;
         SHA(3, j, g) = wpc;
-        sh_ppos[g * 16 + j] = p_pos;
+        if (!DEFER)
+        {
+          sh_ppos[g * 16 + j] = p_pos;
+          sh_fbflag[j * 4 + g] = 0u;
+        }
         sh_apos[g * 16 + j] = ap_pos;
-        sh_fbflag[j * 4 + g] = 0u;
         wave_sync();
         double sums[4];
         { // lane r sums row r in the reference's order (linear.cpp:147-151); results shared through LDS
@@ -2347,10 +2395,22 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
           double target = reward;
           if (has_next) target += N.gamma * v_next;
           delta = target - v_prev;
-          up.dW = N.alpha * (target - v_prev);
-          up.dT = N.alpha * delta;
-          Evicted ev_unused;
-          td_update_lane<false>(tr, tabC, up, p_pos, p_sh, wpc, g, j, sh_ppos, sh_fb, sh_fbflag, status, ev_unused);
+          if (DEFER)
+          { // applied on the next pass, after that pass's loads are in flight
+            pd = true;
+            pd_dW = N.alpha * (target - v_prev);
+            pd_dT = N.alpha * delta;
+            pd_pos = p_pos;
+            pd_sh = p_sh;
+            pd_wp = wpc;
+          }
+          else
+          {
+            up.dW = N.alpha * (target - v_prev);
+            up.dT = N.alpha * delta;
+            Evicted ev_unused;
+            td_update_lane<false>(tr, tabC, up, p_pos, p_sh, wpc, g, j, sh_ppos, sh_fb, sh_fbflag, status, ev_unused);
+          }
           // actor
           if (N.ac_update_method == 0 || delta > 0)
           {
@@ -2373,7 +2433,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         }
 
         // -------- tap
-        if (tapped && (!first || P.tap_starts))
+        if (!DEFER && tapped && (!first || P.tap_starts))
         {
           uint32_t n = *P.tap_count;
           if (n < (uint32_t)P.tap_capacity)
@@ -2414,6 +2474,8 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         if (!first && terminal) running = false;
         first = false;
       }
+      // the eviction held back by the deferred update: nothing reads the table before the next pass
+      if (DEFER && ev.pos != kInvalidPos) value_store(tabC, ev.pos, ev.val);
     }
 
     // end of a learning trial: make the table current (test trials and the host read it); the
@@ -3185,21 +3247,27 @@ hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stre
 
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
 {
-  if (variant) *variant = GRLX_KERNEL_GENERIC;
+  const bool taps = P.tap_replica >= 0 && P.tap_capacity > 0;          // recorded by the in-place instantiation
+  if (variant) *variant = taps ? GRLX_KERNEL_IN_PLACE : GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
   switch (P.env)
   {
     case GRLX_ENV_CART_POLE:
-      if (!P.no_specialisation && !(P.tap_replica >= 0 && P.tap_capacity > 0) && SpecCartPoleAc::matches(P))
+      if (taps)
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecNone, false>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      else if (!P.no_specialisation && SpecCartPoleAc::matches(P))
       {
         if (variant) *variant = GRLX_KERNEL_SPECIALISED;
-        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecCartPoleAc>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecCartPoleAc, true>), dim3(waves), dim3(64), 0, stream, P, n_trials);
       }
       else
-        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_CART_POLE, SpecNone, true>), dim3(waves), dim3(64), 0, stream, P, n_trials);
       break;
     case GRLX_ENV_PENDULUM:
-      hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_PENDULUM, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      if (taps)
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_PENDULUM, SpecNone, false>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+      else
+        hipLaunchKernelGGL((rollout_ac_kernel<GRLX_ENV_PENDULUM, SpecNone, true>), dim3(waves), dim3(64), 0, stream, P, n_trials);
       break;
     default:
       return hipErrorInvalidValue;

@@ -712,6 +712,30 @@ def test_actor_critic_fused_bit_exact(grlx, over):
     r.close()
 
 
+def test_actor_critic_production_ordering_small_memory(grlx):
+    """The actor-critic kernel without taps applies the critic's TD update one pass later (in the shadow of the
+    next step's loads).  Tiny hash memories make most slots shared between tilings, so evictions, write-through
+    entries and reloads of that ordering run constantly: rows, RNG and both complete dense tables vs the oracle."""
+    from tests import configs
+    seeds = list(range(201, 208))
+    cfg, spec = configs.cart_pole_ac(grlx, len(seeds))
+    cfg.projector.memory = spec.projector.memory = 4096
+    cfg.actor_projector.memory = spec.actor_projector.memory = 2048
+    r = grlx.Runner(cfg, seeds)
+    for c in (25, 1, 30, 4):
+        r.run(c)
+    r.sync()
+    assert r.last_kernel() == 1
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=seed)
+        rows, _ = e.run(60)
+        assert_bit_equal(r.rows(k)[2], [x.reward for x in rows], f"returns of seed {seed}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        assert_bit_equal(r.export_weights(k, table=0), e.all_weights(0), "critic table")
+        assert_bit_equal(r.export_weights(k, table=1), e.all_weights(1), "actor table")
+    r.close()
+
+
 def test_deployer_actor_critic_rows_equal_oracle(grlx, tmp_path):
     """grlxd on the actor-critic yaml: the rows it writes are the oracle's, digit for digit."""
     import subprocess
