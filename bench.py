@@ -134,6 +134,9 @@ def main():
     for _ in range(args.warmup):
         runner.run(TRIALS_PER_STEP, sptr)
     runner.sync(sptr)
+    # warm the collective too (same shape and dtype as the timed one): communicator set-up and the first
+    # launch of the RCCL kernel belong to start-up, not to the job
+    parallel.reduce_curve(torch.zeros_like(curve), world)
 
     # per-launch kernel time: HIP events on the stream the kernel is launched on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
