@@ -3109,18 +3109,47 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           // write(p, target, alpha): every index of p, in tiling order where tilings share the slot
           if (!p_sh) add_to(p_pos, dW);
           serial_lanes(p_sh, [&]() { add_to(p_pos, dW); });
-          // update(trace, alpha*delta, e): newest entry first while its weight exceeds 0.001
-          double weight = 1.;
+          // update(trace, alpha*delta, e): newest entry first while its weight exceeds 0.001.  The slots this
+          // tiling owns alone are loaded together (one round trip); an entry whose slot occurred in a newer
+          // entry continues from that entry's result instead of its (stale) load, so every slot still
+          // receives its additions one after the other in entry order.  Shared slots: one lane at a time.
+          double cur[kAccTrace], de[kAccTrace];
+          bool mine[kAccTrace];
+          {
+            double weight = 1.;
+#pragma unroll
+            for (int e = 0; e < kAccTrace; ++e)
+            {
+              const bool go = e < tlen && weight > 0.001;
+              de[e] = weight * dT * ee;
+              mine[e] = go && ((tsh >> e) & 1u) == 0u;
+              cur[e] = mine[e] ? value_load(tab, tpos[e]) : 0.;
+              weight *= ee;
+            }
+          }
 #pragma unroll
           for (int e = 0; e < kAccTrace; ++e)
           {
-            const bool go = e < tlen && weight > 0.001;
-            const double de = weight * dT * ee;
-            const bool shared = ((tsh >> e) & 1u) != 0u;
-            if (go && !shared) add_to(tpos[e], de);
-            serial_lanes(go && shared, [&]() { add_to(tpos[e], de); });
-            weight *= ee;
-            if (!__any(go)) break;
+            double base = cur[e];
+#pragma unroll
+            for (int k = 0; k < e; ++k) base = (mine[k] && tpos[k] == tpos[e]) ? cur[k] : base;   // the latest newer occurrence wins
+            const double v = base + de[e];
+            cur[e] = limit ? clampd(v, out_min, out_max) : v;
+            if (mine[e]) value_store(tab, tpos[e], cur[e]);
+          }
+          {
+            double weight = 1.;
+#pragma unroll
+            for (int e = 0; e < kAccTrace; ++e)
+            {
+              const bool go = e < tlen && weight > 0.001;
+              const bool shared = ((tsh >> e) & 1u) != 0u;
+              const double d = de[e];
+              const uint32_t at = tpos[e];
+              if (rarely(__any(go && shared)))
+                serial_lanes(go && shared, [&]() { add_to(at, d); });
+              weight *= ee;
+            }
           }
           // trace_->add(p, e) (trace.h:245-262)
           if (ee < cut) { tlen = 0; ttotal = 1.; tsh = 0; }
