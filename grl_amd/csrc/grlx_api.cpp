@@ -800,7 +800,7 @@ int grlx_update(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t
 
 int grlx_math(int op, const double *x, const double *y, int n, double *out)
 {
-  if (!x || !out || n < 0 || op < 0 || op > 5 || (op == 3 && !y)) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!x || !out || n < 0 || op < 0 || op > 8 || (op == 3 && !y)) return fail(GRLX_ERR_INVALID, "bad argument");
   if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
   if (n == 0) return GRLX_OK;
   DevBuf dx, dy, dout;

@@ -695,8 +695,8 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
   __device__ static __forceinline__ double hip_x(const St &m) { return m.sfx - psin(m.sla); }
   __device__ static __forceinline__ double swing_y(const St &m) { return pcos(m.sla) - pcos(m.sla - m.ha); }
   // the same with the sine constants held in registers by model_step (20 sub-steps x 10 evaluations)
-  __device__ static __forceinline__ double hip_x(const SinConsts &k, const St &m) { return m.sfx - psin(m.sla, k); }
-  __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m) { return pcos(m.sla, k) - pcos(m.sla - m.ha, k); }
+  __device__ static __forceinline__ double hip_x(const SinConsts &k, const St &m) { return m.sfx - psin_s(m.sla, k); }
+  __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m) { return pcos_s(m.sla, k) - pcos_s(m.sla - m.ha, k); }
   __device__ static __forceinline__ void wrap(St &m)
   { // SWModel.h:48-59
     if (m.sla >= GRLX_PI) m.sla -= 2*GRLX_PI;
@@ -707,9 +707,9 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
   __device__ static __forceinline__ void accel(const DevParams &P, const SinConsts &k, const St &m, double torque, double &asl, double &ahip)
   { // SWModel.cpp:212-218
     double sn, cs;
-    psincos(m.sla - P.slope_angle, k, sn, cs);
+    psincos_s(m.sla - P.slope_angle, k, sn, cs);
     asl = sn;
-    ahip = psin(m.ha, k) * (m.slar*m.slar - cs) + asl;
+    ahip = psin_s(m.ha, k) * (m.slar*m.slar - cs) + asl;
     ahip += torque;
   }
   __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt)
@@ -3590,6 +3590,9 @@ __global__ void math_kernel(int op, const double *x, const double *y, int n, dou
     case 2: r = plog(v); break;
     case 3: r = pfmod(v, y[i]); break;
     case 5: r = div6(v); break;
+    case 6: r = psin_s(v, sin_consts<false>()); break;       // small-angle-aware forms (whole waves of small arguments take the short path)
+    case 7: r = pcos_s(v, sin_consts<false>()); break;
+    case 8: { double sn, cs; psincos_s(v, sin_consts<false>(), sn, cs); r = sn + cs; break; }
     default: r = __builtin_sqrt(v); break;
   }
   out[i] = r;

@@ -213,6 +213,76 @@ __device__ __forceinline__ void psincos(double x, const SinConsts &k, double &sn
   cs_out = ((q + 1) & 2) ? -vc : vc;
 }
 
+// Small-angle-aware forms for code whose angles mostly stay within a quarter turn (the compass walker):
+// when rint(x * 2/pi) is zero in EVERY lane of the wave the reduction is the identity (r = fma(-fn,P1,x),
+// t = +0: every term of it is a signed zero that sums to +0) and only the kernel that is asked for is
+// evaluated -- the same operations the general path would perform on (r, +0), hence the same bits;
+// fma(-hz,t,t) = +0 and fma(-r,t,tail) = tail are the values those operations have for t = +0.
+// Anything else takes the general path.  One wave-uniform test per call.
+__device__ __forceinline__ double psin_s(double x, const SinConsts &k)
+{
+  const double fn = __builtin_rint(x * k.invpio2);
+  if (__builtin_expect(__all(fn == 0.0), 1))
+  {
+    const double r = __builtin_fma(-fn, k.p1, x);
+    const double z = r * r, z2 = z * z, z4 = z2 * z2;
+    const double sa = __builtin_fma(z, k.s[1], k.s[0]);
+    const double sb = __builtin_fma(z, k.s[3], k.s[2]);
+    const double sc = __builtin_fma(z, k.s[5], k.s[4]);
+    const double sd = __builtin_fma(z, k.s[7], k.s[6]);
+    const double P = __builtin_fma(z4, __builtin_fma(z2, sd, sc), __builtin_fma(z2, sb, sa));
+    return r + __builtin_fma(z * r, P, 0.0);
+  }
+  return psin(x, k);
+}
+
+__device__ __forceinline__ double pcos_s(double x, const SinConsts &k)
+{
+  const double fn = __builtin_rint(x * k.invpio2);
+  if (__builtin_expect(__all(fn == 0.0), 1))
+  {
+    const double r = __builtin_fma(-fn, k.p1, x);
+    const double z = r * r, z2 = z * z, z4 = z2 * z2;
+    const double ca = __builtin_fma(z, k.c[1], k.c[0]);
+    const double cb = __builtin_fma(z, k.c[3], k.c[2]);
+    const double cc = __builtin_fma(z, k.c[5], k.c[4]);
+    const double cd = __builtin_fma(z, k.c[7], k.c[6]);
+    const double Q = __builtin_fma(z4, __builtin_fma(z2, cd, cc), __builtin_fma(z2, cb, ca));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double tail = (1.0 - w) - hz;
+    return w + __builtin_fma(z2, Q, tail);
+  }
+  return pcos(x, k);
+}
+
+__device__ __forceinline__ void psincos_s(double x, const SinConsts &k, double &sn_out, double &cs_out)
+{
+  const double fn = __builtin_rint(x * k.invpio2);
+  if (__builtin_expect(__all(fn == 0.0), 1))
+  {
+    const double r = __builtin_fma(-fn, k.p1, x);
+    const double z = r * r, z2 = z * z, z4 = z2 * z2;
+    const double sa = __builtin_fma(z, k.s[1], k.s[0]);
+    const double sb = __builtin_fma(z, k.s[3], k.s[2]);
+    const double sc = __builtin_fma(z, k.s[5], k.s[4]);
+    const double sd = __builtin_fma(z, k.s[7], k.s[6]);
+    const double P = __builtin_fma(z4, __builtin_fma(z2, sd, sc), __builtin_fma(z2, sb, sa));
+    const double ca = __builtin_fma(z, k.c[1], k.c[0]);
+    const double cb = __builtin_fma(z, k.c[3], k.c[2]);
+    const double cc = __builtin_fma(z, k.c[5], k.c[4]);
+    const double cd = __builtin_fma(z, k.c[7], k.c[6]);
+    const double Q = __builtin_fma(z4, __builtin_fma(z2, cd, cc), __builtin_fma(z2, cb, ca));
+    const double hz = 0.5 * z;
+    sn_out = r + __builtin_fma(z * r, P, 0.0);
+    const double w = 1.0 - hz;
+    const double tail = (1.0 - w) - hz;
+    cs_out = w + __builtin_fma(z2, Q, tail);
+    return;
+  }
+  psincos(x, k, sn_out, cs_out);
+}
+
 // Branch-free forms: callers guarantee |x| < 2^20 (checked once per environment step;
 // outside the domain the result is unspecified and the replica is flagged).
 __device__ __forceinline__ double psin(double x)

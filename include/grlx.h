@@ -236,7 +236,8 @@ int  grlx_update(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_
                  const double *delta);
 
 /* device math used by the environments (bit-identical to the documented
- * portable specification): op 0 sin, 1 cos, 2 log, 3 fmod(x, y[i]), 4 sqrt, 5 x/6 (the 3-operation exact form used by RK4) */
+ * portable specification): op 0 sin, 1 cos, 2 log, 3 fmod(x, y[i]), 4 sqrt, 5 x/6 (the 3-operation exact form used by RK4),
+ * 6 / 7 / 8 the small-angle-aware sin, cos and sin+cos the compass walker uses (bitwise equal to 0 / 1 / their sum) */
 int  grlx_math(int op, const double *x, const double *y, int n, double *out);
 
 /* Rand / RandGen streams (utils.h:84-137) evaluated on the device:

@@ -39,6 +39,23 @@ def test_device_math_bit_exact(grlx, oracle, op, name, lo, hi):
     assert_bit_equal(got, want, name)
 
 
+def test_small_angle_forms_equal_the_general_ones(grlx, oracle):
+    """psin_s / pcos_s / psincos_s take a short path when every lane of a wave has |x| within a quarter turn: it
+    must give the bits of the general path.  Whole waves of small arguments, mixed waves, boundaries, zeros."""
+    rng = np.random.default_rng(12)
+    small = rng.uniform(-0.78, 0.78, 64 * 300)
+    edge = np.concatenate([np.full(64, 0.0), np.full(64, -0.0), np.full(64, 0.7853981633974483), np.full(64, -0.7853981633974483),
+                           np.full(64, 0.7853981633974484), np.full(64, 0.78539816339744828), np.full(64, 1e-300), np.full(64, -5e-324)])
+    mixed = rng.uniform(-7, 7, 64 * 200)
+    tiny = rng.uniform(-1e-9, 1e-9, 64 * 20)
+    x = np.concatenate([small, edge, mixed, tiny, np.nextafter(0.7853981633974483, [0.0, 1.0] * 32)])
+    want_s = np.array([oracle.orc_psin(float(v)) for v in x])
+    want_c = np.array([oracle.orc_pcos(float(v)) for v in x])
+    assert_bit_equal(grlx.runner.device_math(6, x), want_s, "psin_s")
+    assert_bit_equal(grlx.runner.device_math(7, x), want_c, "pcos_s")
+    assert_bit_equal(grlx.runner.device_math(8, x), want_s + want_c, "psincos_s")
+
+
 def test_device_fmod_sqrt_exact(grlx):
     rng = np.random.default_rng(5)
     x = np.concatenate([rng.uniform(-500, 500, 100000), rng.uniform(-7, 7, 100000), [0.0, -0.0, 2 * np.pi, -2 * np.pi, 1e15]])
