@@ -1,0 +1,463 @@
+// grlx_envs.h -- environments: dynamics + tasks (pendulum, acrobot, cart-pole, compass walker), RK4 and the environment step
+// (modeled.cpp:132-276, pendulum.cpp, acrobot.cpp, cart_pole.cpp, compass_walker.cpp, SWModel.cpp).
+// Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
+#pragma once
+
+namespace grlx {
+
+// ----------------------------------------------------------- environments --
+template <int ENV> struct Env;
+
+// dynamics/pendulum + task/pendulum/swingup (pendulum.cpp:40-145)
+template <> struct Env<GRLX_ENV_PENDULUM> {
+  static constexpr int S = 3, D = 2;
+  // pendulum.cpp:40-49, 55-68; the constants are held in registers by the caller (rk4_step)
+  struct Consts { SinConsts k; double invJ, mgl, b, kkr, kr; };
+  template <bool PIN> __device__ static __forceinline__ Consts consts()
+  {
+    const double J = 0.000191, m = 0.055, g = 9.81, l = 0.042, b = 0.000003, K = 0.0536, R = 9.5;
+    Consts c;
+    c.k = sin_consts<PIN>();
+    c.invJ = math_const<PIN>(1 / J);
+    c.mgl = math_const<PIN>(m * g * l);
+    c.b = math_const<PIN>(b);
+    c.kkr = math_const<PIN>(K * K / R);
+    c.kr = math_const<PIN>(K / R);
+    return c;
+  }
+  __device__ static __forceinline__ void eom(const Consts &c, const double *x, double u, double *xd)
+  {
+    double a = x[0], ad = x[1];
+    double add = c.invJ * (c.mgl * psin(a, c.k) - c.b * ad - c.kkr * ad + c.kr * u);
+    xd[0] = ad;
+    xd[1] = add;
+    xd[2] = 1;
+  }
+  __device__ static __forceinline__ void start(const DevParams &P, int test, uint64_t &TL, uint64_t &, double *x)
+  { // pendulum.cpp:97-103 (the RandGen draw happens every episode)
+    TL = lcg_next(TL);
+    double r = lcg_double(TL);
+    x[0] = GRLX_PI + P.randomization * (test == 0) * r * 2 * GRLX_PI;
+    x[1] = 0;
+    x[2] = 0;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return fmin(fmax(a, -3.0), 3.0); }   // :105-109
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[0]) < 0x1p19; }
+  __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
+  { // :111-129
+    double a = pfmod(x[0] + GRLX_PI, GRLX_2PI);
+    if (a < 0) a += GRLX_2PI;
+    obs[0] = a;
+    obs[1] = x[1];
+    return x[2] > P.timeout ? 1 : 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &, const double *x, double action, const double *next)
+  { // :131-145; pow(v, 2) is v*v in the portable specification
+    double a = pfmod(__builtin_fabs(next[0]), GRLX_2PI);
+    if (a > GRLX_PI) a -= GRLX_2PI;
+    double reward = -5 * (a * a) - 0.1 * (next[1] * next[1]) - 1 * (action * action);
+    if ((next[2] - x[2]) != 1)
+      reward *= (next[2] - x[2]) / 0.03;
+    return reward;
+  }
+};
+
+// dynamics/acrobot + task/acrobot/balancing (acrobot.cpp:48-151); state = [theta1, theta2,
+// thetad1, thetad2, time].  No reference test pins it: parity is against the oracle only.
+template <> struct Env<GRLX_ENV_ACROBOT> {
+  static constexpr int S = 5, D = 4;
+  using Consts = SinConsts;                     // held in registers across the integration loop
+  template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
+  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
+  { // acrobot.cpp:48-79, expression for expression
+    const double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
+    const double theta1 = x[0], theta2 = x[1], thetad1 = x[2], thetad2 = x[3];
+    const double tau = u;
+    double sin2, cos2;
+    psincos(theta2, k, sin2, cos2);
+
+    double phi2 = m2*lc2*g*pcos(theta1+theta2-GRLX_PI/2, k);
+    double phi1 = -m2*l1*lc2*thetad2*thetad2*sin2-2*m2*l1*lc2*thetad2*thetad1*sin2 +
+                  (m1*lc1+m2*l1)*g*pcos(theta1-GRLX_PI/2, k)+phi2;
+    double d2 = m2*(lc2*lc2+l1*lc2*cos2)+I2;
+    double d1 = m1*lc1*lc1 + m2*(l1*l1+lc2*lc2+2*l1*lc2*cos2)+I1+I2;
+    double thetadd2 = (tau+d2*phi1/d1-m2*l1*lc2*thetad2*thetad2*sin2-phi2)/
+                      (m2*lc2*lc2+I2-d2*d2/d1);
+    double thetadd1 = -(d2*thetadd2+phi1)/d1;
+
+    if (thetad1 >  4*GRLX_PI) thetadd1 = fmin(thetadd1, 0.);
+    if (thetad1 < -4*GRLX_PI) thetadd1 = fmax(thetadd1, 0.);
+    if (thetad2 >  9*GRLX_PI) thetadd2 = fmin(thetadd2, 0.);
+    if (thetad2 < -9*GRLX_PI) thetadd2 = fmax(thetadd2, 0.);
+
+    xd[0] = thetad1;
+    xd[1] = thetad2;
+    xd[2] = thetadd1;
+    xd[3] = thetadd2;
+    xd[4] = 1;
+  }
+  __device__ static __forceinline__ bool failed(const double *x)
+  { // :147-151
+    return __builtin_fabs(x[0]-GRLX_PI) > 12*GRLX_PI/180 || __builtin_fabs(x[1]) > 12*GRLX_PI/180;
+  }
+  __device__ static __forceinline__ void start(const DevParams &, int, uint64_t &TL, uint64_t &, double *x)
+  { // :102-107
+    TL = lcg_next(TL);
+    const double r1 = lcg_double(TL);
+    TL = lcg_next(TL);
+    const double r2 = lcg_double(TL);
+    x[0] = GRLX_PI+r1*0.01-0.005;
+    x[1] = r2*0.01-0.005;
+    x[2] = 0; x[3] = 0; x[4] = 0;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return a; }                  // Task::actuate default (environment.h:94)
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[0]) < 0x1p18 && __builtin_fabs(x[1]) < 0x1p18; }
+  __device__ static __forceinline__ int observe(const DevParams &, const double *x, double *obs)
+  { // :109-125
+#pragma unroll
+    for (int i = 0; i < 4; ++i) obs[i] = x[i];
+    if (failed(x)) return 2;
+    return x[4] > 20 ? 1 : 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &, const double *, double, const double *next)
+  { // :127-133
+    return failed(next) ? 0. : 1.;
+  }
+};
+
+// dynamics/cart_pole (end_stop = 1) + task/cart_pole/swingup (cart_pole.cpp:41-237);
+// state = [x, theta, xd, thetad, time].  parity unpinned by reference tests.
+template <> struct Env<GRLX_ENV_CART_POLE> {
+  static constexpr int S = 5, D = 4;
+  using Consts = SinConsts;                     // held in registers across the integration loop
+  template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
+  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
+  { // cart_pole.cpp:58-108.  QUIRK reproduced on purpose: :65 reads dtheta = state[3-2*end_stop_],
+    // which for end_stop = 1 is state[1] -- the ANGLE, not its rate.
+    const double g = 9.8, mass_cart = 1.0, mass_pole = 0.1, length = 0.5;
+    const double total_mass = mass_cart + mass_pole, pole_mass_length = mass_pole * length;
+    const double theta = x[1], dtheta = x[3 - 2 * 1];
+    double costheta, sintheta;
+    psincos(theta, k, sintheta, costheta);
+    const double temp = (u + pole_mass_length * dtheta * dtheta * sintheta) / total_mass;
+    const double thetaacc = (g * sintheta - costheta * temp) /
+                            (length * ((4. / 3.) - mass_pole * costheta * costheta / total_mass));
+    const double acc = temp - pole_mass_length * thetaacc * costheta / total_mass;
+    xd[0] = x[2];
+    xd[1] = x[3];
+    xd[2] = acc;
+    xd[3] = thetaacc;
+    xd[4] = 1;
+    if (x[0] > 2.4 && x[2] > 0)
+    { // end stops, :93-105
+      xd[0] = 0;
+      if (acc > 0) xd[2] = 0;
+    }
+    else if (x[0] < -2.4 && x[2] < 0)
+    {
+      xd[0] = 0;
+      if (acc < 0) xd[2] = 0;
+    }
+  }
+  __device__ static __forceinline__ bool failed(const double *x) { return __builtin_fabs(x[0]) > 2.4; }   // :212-215
+  __device__ static __forceinline__ double potential(const double *x)
+  { // :232-238
+    double a = pfmod(__builtin_fabs(x[1]), GRLX_2PI);
+    if (a > GRLX_PI) a -= GRLX_2PI;
+    return -2 * (x[0] * x[0]) - 0.1 * (x[2] * x[2]) - (a * a) - 0.1 * (x[3] * x[3]);
+  }
+  __device__ static __forceinline__ void start(const DevParams &P, int, uint64_t &TL, uint64_t &, double *x)
+  { // :155-164
+    TL = lcg_next(TL);
+    const double r = lcg_double(TL);
+    x[0] = 0;
+    x[1] = GRLX_PI + P.randomization * ((r * 0.1) - 0.05);
+    x[2] = 0; x[3] = 0; x[4] = 0;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return a; }                  // Task::actuate default (environment.h:94)
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[1]) < 0x1p19; }
+  __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
+  { // :166-190
+    double a = pfmod(x[1] + GRLX_PI, GRLX_2PI);
+    if (a < 0) a += GRLX_2PI;
+    obs[0] = x[0];
+    obs[1] = a;
+    obs[2] = x[2];
+    obs[3] = x[3];
+    if (P.end_stop_penalty && failed(x)) return 2;
+    return x[4] > P.timeout ? 1 : 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &P, const double *, double action, const double *next)
+  { // :192-201, shaping = 0
+    const double a15 = action / 15;
+    return potential(next) - P.action_penalty * (a15 * a15) * 2 - P.end_stop_penalty * (failed(next) ? 1 : 0) * 10000;
+  }
+};
+
+// model/compass_walker + task/compass_walker/walk: the simplest walking model with its own
+// RK4 (velocities and angles staged separately), angle wrapping and heel-strike events located
+// by a secant search (SWModel.cpp:15-258, SWModel.h:40-59, compass_walker.cpp:63-94, 251-344).
+// state vector (compass_walker.h:40-42).  parity unpinned by reference tests.
+template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
+  static constexpr int S = 11, D = 5;
+  static constexpr bool kCustomModel = true;
+  enum { SLA = 0, HA, SLAR, HAR, CHANGED, SFX, LASTHIPX, HIPVEL, STEPDIST, TIME, TIMEOUT };
+  struct St { double sla, slar, ha, har, sfx; };
+
+  __device__ static __forceinline__ double hip_x(const St &m) { return m.sfx - psin(m.sla); }
+  __device__ static __forceinline__ double swing_y(const St &m) { return pcos(m.sla) - pcos(m.sla - m.ha); }
+  // the same with the sine constants held in registers by model_step (20 sub-steps x 10 evaluations)
+  __device__ static __forceinline__ double hip_x(const SinConsts &k, const St &m) { return m.sfx - psin_s(m.sla, k); }
+  __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m) { return pcos_s(m.sla, k) - pcos_s(m.sla - m.ha, k); }
+  __device__ static __forceinline__ void wrap(St &m)
+  { // SWModel.h:48-59
+    if (m.sla >= GRLX_PI) m.sla -= 2*GRLX_PI;
+    if (m.sla < -GRLX_PI) m.sla += 2*GRLX_PI;
+    if (m.ha >= GRLX_PI) m.ha -= 2*GRLX_PI;
+    if (m.ha < -GRLX_PI) m.ha += 2*GRLX_PI;
+  }
+  __device__ static __forceinline__ void accel(const DevParams &P, const SinConsts &k, const St &m, double torque, double &asl, double &ahip)
+  { // SWModel.cpp:212-218
+    double sn, cs;
+    psincos_s(m.sla - P.slope_angle, k, sn, cs);
+    asl = sn;
+    ahip = psin_s(m.ha, k) * (m.slar*m.slar - cs) + asl;
+    ahip += torque;
+  }
+  __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt)
+  { // SWModel.cpp:220-258
+    St s1 = state, s2 = state, s3 = state, s4 = state;
+    double k1s, k1h, k2s, k2h, k3s, k3h, k4s, k4h;
+    accel(P, k, s1, torque, k1s, k1h);
+    s2.slar = s1.slar + (dt/2)*k1s;
+    s2.har  = s1.har  + (dt/2)*k1h;
+    s2.sla  = s1.sla  + (dt/2)*s1.slar;
+    s2.ha   = s1.ha   + (dt/2)*s1.har;
+    accel(P, k, s2, torque, k2s, k2h);
+    s3.slar = s1.slar + (dt/2)*k2s;
+    s3.har  = s1.har  + (dt/2)*k2h;
+    s3.sla  = s1.sla  + (dt/2)*s2.slar;
+    s3.ha   = s1.ha   + (dt/2)*s2.har;
+    accel(P, k, s3, torque, k3s, k3h);
+    s4.slar = s1.slar + (dt)*k3s;
+    s4.har  = s1.har  + (dt)*k3h;
+    s4.sla  = s1.sla  + (dt)*s3.slar;
+    s4.ha   = s1.ha   + (dt)*s3.har;
+    accel(P, k, s4, torque, k4s, k4h);
+    state.slar = s1.slar + (dt/6)*(k1s + 2*k2s + 2*k3s + k4s);
+    state.har  = s1.har  + (dt/6)*(k1h + 2*k2h + 2*k3h + k4h);
+    state.sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
+    state.ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
+  }
+  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
+  { // SWModel.cpp:53-104
+    double timeLeft = 0;
+    St s0 = t0, s1 = t1;
+    double s0time = 0, s1time = dt;
+    const int maxIterations = 10;
+    int iIter;
+    for (iIter = 0; iIter < maxIterations; iIter++)
+    {
+      hs = s0;
+      const double y0 = swing_y(k, s0);
+      double newDt = (s1time - s0time) * y0 / (y0 - swing_y(k, s1));
+      rk4(P, k, hs, torque, newDt);
+      if (swing_y(k, hs) > 0)
+      {
+        s0 = hs;
+        s0time = s0time + newDt;
+      }
+      else
+      {
+        s1 = hs;
+        s1time = s0time + newDt;
+      }
+      if (swing_y(k, s0) < precision)
+      {
+        hs = s0;
+        timeLeft = dt - s0time;
+        break;
+      }
+      else if (-swing_y(k, s1) < precision)
+      {
+        hs = s1;
+        timeLeft = dt - s1time;
+        break;
+      }
+    }
+    if (iIter >= maxIterations)
+    {
+      if (swing_y(k, hs) > 0) timeLeft = dt - s0time;
+      else timeLeft = dt - s1time;
+    }
+    return timeLeft;
+  }
+  __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next)
+  { // CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210)
+    St st, prev, hs;
+    st.sfx = x[SFX]; st.sla = x[SLA]; st.slar = x[SLAR]; st.ha = x[HA]; st.har = x[HAR];
+    prev = st;
+    hs = st;
+    bool changed = false;
+    const double partial = P.walker_dt;
+    const SinConsts k = sin_consts<true>();
+    double y_prev = swing_y(k, prev);            // swing_y(prev) of the next sub-step is this sub-step's swing_y(st)
+    for (int i = 0; i < P.integration_steps; i++)
+    {
+      rk4(P, k, st, torque, partial);
+      wrap(st);
+      // detectEvents (SWModel.cpp:30-45)
+      double timeleft = 0;
+      bool struck = false;
+      const double y_now = swing_y(k, st);
+      if ((y_prev >= 0) && (y_now < 0))
+        if (((prev.ha < 0) && (st.ha < 0)) || ((prev.ha > 0) && (st.ha > 0)))
+          if ((st.slar < 0) && (st.ha < 0))
+          { // processStanceLegChange (:106-124)
+            struck = true;
+            timeleft = heelstrike_moment(P, k, prev, st, hs, torque, 1.0E-11, partial);
+            const double c2 = pcos(2.0*hs.sla, k);
+            st.har  = hs.slar*(c2*(1.0 - c2));
+            st.slar = hs.slar*(c2);
+            st.sfx  = hip_x(k, hs) + psin(hs.sla - hs.ha, k);
+            st.sla  = -hs.sla;
+            st.ha   = -2.0*hs.sla;
+          }
+      changed = changed || (timeleft > 0);
+      if (timeleft > 0)
+      {
+        rk4(P, k, st, torque, timeleft);
+        wrap(st);
+      }
+      // a pure function of the state: recomputed only where a heel strike replaced the state
+      y_prev = struck ? swing_y(k, st) : y_now;
+      prev = st;
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) next[i] = x[i];
+    next[SLA] = st.sla;
+    next[HA] = st.ha;
+    next[SLAR] = st.slar;
+    next[HAR] = st.har;
+    next[SFX] = st.sfx;
+    next[CHANGED] = changed ? 1. : 0.;
+    next[LASTHIPX] = changed ? hip_x(k, st) : x[LASTHIPX];
+    next[HIPVEL] = - st.slar * pcos(st.sla, k);
+    next[TIME] = x[TIME] + P.control_step;
+    next[TIMEOUT] = x[TIMEOUT];
+  }
+  __device__ static __forceinline__ void eom(const double *, double, double *) {}
+  __device__ static __forceinline__ void start(const DevParams &P, int test, uint64_t &, uint64_t &G, double *x)
+  { // compass_walker.cpp:251-290: rejection sampling on the GLOBAL drand48 stream
+    const double i_sla = 0.1534, i_slar = -0.1561, i_ha = 2.0*0.1534, i_har = -0.0073;
+    const double variation = (!test) ? P.initial_state_variation : 0;
+    const double cslope = pcos(P.slope_angle);
+    St sw;
+    sw.sfx = 0;
+    for (int guard = 0; guard < 100000; ++guard)
+    {
+      G = lcg_next(G); sw.sla  = i_sla  * (1.0 - variation + 2.0*variation*lcg_double(G));
+      G = lcg_next(G); sw.ha   = i_ha   * (1.0 - variation + 2.0*variation*lcg_double(G));
+      G = lcg_next(G); sw.slar = i_slar * (1.0 - variation + 2.0*variation*lcg_double(G));
+      G = lcg_next(G); sw.har  = i_har  * (1.0 - variation + 2.0*variation*lcg_double(G));
+      if (!(sw.slar*sw.slar/2.0 + pcos(sw.sla)*cslope < cslope)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) x[i] = 0;
+    x[SLA] = sw.sla;
+    x[HA] = sw.ha;
+    x[SLAR] = sw.slar;
+    x[HAR] = sw.har;
+    x[SFX] = sw.sfx;
+    x[LASTHIPX] = hip_x(sw);
+    x[HIPVEL] = -sw.slar * pcos(sw.sla);
+    x[TIMEOUT] = test ? 2*P.timeout : P.timeout;
+  }
+  __device__ static __forceinline__ double actuate(double a) { return a; }
+  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[SLA]) < 8. && __builtin_fabs(x[HA]) < 8. && __builtin_fabs(x[SLAR]) < 1e6; }
+  __device__ static __forceinline__ bool fallen(const double *x)
+  {
+    return __builtin_fabs(x[SLA]) > GRLX_PI/8 || __builtin_fabs(x[HA] - 2 * x[SLA]) > GRLX_PI/4;
+  }
+  __device__ static __forceinline__ int observe(const DevParams &, const double *x, double *obs)
+  { // :292-329, observe = [1,1,1,1,1,0,0], steps = 0
+    obs[0] = x[SLA];
+    obs[1] = x[HA] - 2 * x[SLA];
+    obs[2] = x[SLAR];
+    obs[3] = x[HAR] - 2 * x[SLAR];
+    obs[4] = x[CHANGED] > 0.5 ? 1. : 0.;
+    if (fallen(x)) return 2;
+    if (x[TIME] > x[TIMEOUT]) return 1;
+    return 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &P, const double *, double, const double *next)
+  { // :331-344
+    double reward = -1;
+    if (next[CHANGED] > 0.5) reward = fmin(50 * 4 * psin(next[SLA]), 30.);
+    if (fallen(next))
+      if (P.negative_reward != 0) reward = P.negative_reward;
+    return reward;
+  }
+};
+
+template <int ENV> struct HasCustomModel { static constexpr bool value = false; };
+template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bool value = true; };
+
+// DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps.
+// The last state component is time (xd = 1 in every supported dynamics, and no eom reads
+// it), so its stage values are the constant h and its update the constant
+// (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
+template <int ENV, bool PIN>
+__device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
+{
+  constexpr int S = Env<ENV>::S, SD = S - 1;
+  const double h = P.h;
+  const double tinc = (((h + 2 * h) + 2 * h) + h) / 6;
+  double xd[S], k1[SD], k2[SD], k3[SD], k4[SD], t[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) { next[i] = x[i]; t[i] = x[i]; }
+  const typename Env<ENV>::Consts ec = Env<ENV>::template consts<PIN>();   // PIN: constants held in vector registers
+  for (int ii = 0; ii < P.integration_steps; ++ii)
+  {
+    Env<ENV>::eom(ec, next, u, xd);
+#pragma unroll
+    for (int i = 0; i < SD; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
+    Env<ENV>::eom(ec, t, u, xd);
+#pragma unroll
+    for (int i = 0; i < SD; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
+    Env<ENV>::eom(ec, t, u, xd);
+#pragma unroll
+    for (int i = 0; i < SD; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
+    Env<ENV>::eom(ec, t, u, xd);
+#pragma unroll
+    for (int i = 0; i < SD; ++i)
+    {
+      k4[i] = h * xd[i];
+      next[i] = next[i] + div6(k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    }
+    next[SD] = next[SD] + tinc;
+  }
+}
+
+// ModeledEnvironment::step (modeled.cpp:160-213), window 1, no delta, discrete_time 1
+// PIN: hold the dynamics' constants in vector registers across the integration loop (pays at one
+// wave per SIMD, costs registers)
+template <int ENV, bool PIN = true>
+__device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal, uint32_t &status)
+{
+  constexpr int S = Env<ENV>::S;
+  double next[S];
+  if constexpr (HasCustomModel<ENV>::value)
+    Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next);     // model/compass_walker integrates itself
+  else
+    rk4_step<ENV, PIN>(P, x, Env<ENV>::actuate(action), next);
+  terminal = Env<ENV>::observe(P, next, obs);
+  reward = Env<ENV>::evaluate(P, x, action, next);
+  // the branch-free sin/cos need |angle| < 2^20; 2^19 at step ends leaves room for the stages
+  if (!Env<ENV>::in_domain(next)) status |= ST_DOMAIN;
+#pragma unroll
+  for (int i = 0; i < S; ++i) x[i] = next[i];
+}
+
+
+} // namespace grlx

@@ -8,11 +8,12 @@
 //    epsilon-greedy) is computed redundantly by the 16 lanes of the replica --
 //    the lanes would otherwise idle, and it removes every broadcast.
 //  * the eligibility trace lives in registers: lane j keeps, for each of the
-//    <= 10 trace entries, the table position and the current weight of tiling j
-//    (a write-through cache, so trace updates need no loads).
-//  * weights live in a per-replica open-addressing table in HBM/L2 (16-byte
-//    {slot, weight} entries), lazily initialised to the value the reference's
-//    8,388,608-draw initialisation gives that slot (LCG jump-ahead).
+//    <= 10 trace entries, the table position and the AUTHORITATIVE weight of tiling j
+//    (write-back: stored when the slot leaves the trace; grlx_update.h).
+//  * weights live in a per-replica open-addressing table in HBM (64-byte buckets of
+//    four entries, grlx_table.h), lazily initialised to the value the reference's
+//    8,388,608-draw initialisation gives that slot (LCG jump-ahead, grlx_rng.h).
+//  * the TD update of a step is applied one pass later, under the next step's loads.
 //  * sums over the 16 tilings are taken in the reference's serial order
 //    (linear.cpp:147-151) through a 4-way interleaved LDS tile, so Q-values are
 //    bit-identical to a scalar run.
@@ -21,1477 +22,26 @@
 // double without fused multiply-add (x86-64 baseline); only grlx_math.h fuses.
 #include "grlx_internal.h"
 #include "grlx_math.h"
+#include "grlx_rng.h"
+#include "grlx_tile.h"
+#include "grlx_table.h"
+#include "grlx_envs.h"
+#include "grlx_policy.h"
 
 namespace grlx {
 
-// ------------------------------------------------------------------ RNG ----
-// drand48 family (utils.h:84-137): X' = (A*X + C) mod 2^48.
-constexpr uint64_t kLcgA = 0x5DEECE66DULL, kLcgC = 0xBULL, kMask48 = (1ULL << 48) - 1;
-
-// Jump-ahead x -> A^n x + C_n by byte windows of n: entry [w][b] is the affine map of
-// b * 256^w draws, so a jump of up to 2^32 draws costs four multiply-adds.
-struct JumpTable { uint64_t a[4][256], c[4][256]; };
-constexpr JumpTable make_jump_table()
-{
-  JumpTable t{};
-  uint64_t sa = kLcgA, sc = kLcgC;                 // map of 256^w draws
-  for (int w = 0; w < 4; ++w)
-  {
-    uint64_t a = 1, c = 0;                         // identity = 0 draws
-    for (int b = 0; b < 256; ++b)
-    {
-      t.a[w][b] = a;
-      t.c[w][b] = c;
-      c = (sa * c + sc) & kMask48;                 // compose with one more window step
-      a = (sa * a) & kMask48;
-    }
-    sa = a;                                        // after 256 steps: map of 256^(w+1) draws
-    sc = c;
-  }
-  return t;
-}
-__device__ const JumpTable d_jump = make_jump_table();
-
-__device__ __forceinline__ uint64_t lcg_next(uint64_t x) { return (kLcgA * x + kLcgC) & kMask48; }
-__device__ __forceinline__ double   lcg_double(uint64_t x) { return (double)x * 0x1p-48; }
-__device__ __forceinline__ uint32_t lcg_long(uint64_t x) { return (uint32_t)(x >> 17); }
-
-__device__ inline uint64_t lcg_step_pow2(uint64_t x, uint64_t n)
-{ // generic O(log n) jump by repeated squaring (only for n >= 2^32)
-  uint64_t a = kLcgA, c = kLcgC;
-  while (n)
-  {
-    if (n & 1) x = (a * x + c) & kMask48;
-    c = ((a + 1) * c) & kMask48;
-    a = (a * a) & kMask48;
-    n >>= 1;
-  }
-  return x;
-}
-
-__device__ inline uint64_t lcg_jump(uint64_t x, uint64_t n)
-{
-#pragma unroll
-  for (int w = 0; w < 4; ++w)
-  {
-    const uint32_t b = (uint32_t)(n >> (8 * w)) & 0xFFu;
-    x = (d_jump.a[w][b] * x + d_jump.c[w][b]) & kMask48;
-  }
-  if (n >> 32) x = lcg_step_pow2(x, (n >> 32) << 32);
-  return x;
-}
-
-// the same jump with the table staged in LDS (rollout kernels: slot creation is frequent early in
-// learning and the table's eight loads are the latency of lazy_weight)
-__device__ __forceinline__ void jump_table_to_lds(uint64_t *sh_jump)
-{
-  const uint64_t *src = reinterpret_cast<const uint64_t *>(&d_jump);
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) sh_jump[i] = src[i];
-  __syncthreads();
-}
-
-__device__ __forceinline__ uint64_t lcg_jump_lds(const uint64_t *sh_jump, uint64_t x, uint64_t n)
-{
-  uint64_t a[4], c[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w)
-  {
-    const uint32_t b = (uint32_t)(n >> (8 * w)) & 0xFFu;
-    a[w] = sh_jump[w * 256 + b];
-    c[w] = sh_jump[1024 + w * 256 + b];
-  }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) x = (a[w] * x + c[w]) & kMask48;
-  if (n >> 32) x = lcg_step_pow2(x, (n >> 32) << 32);
-  return x;
-}
-
-// value the reference's dense initialisation gives `slot` (linear.cpp:117-120:
-// params_[ii] = rand->getUniform(init_min, init_max) in index order)
-__device__ inline double lazy_weight(uint64_t tl0, const LinearParams &lp, uint32_t slot)
-{
-  uint64_t x = lcg_next(lcg_jump(tl0, lp.draws_before + (uint64_t)slot));
-  return lp.init_min + lcg_double(x) * lp.init_range;
-}
-
-// initial value of a slot: the loaded image when there is one, else the reference's draw
-__device__ inline double initial_weight(const ReplicaState &rs, int table, const LinearParams &lp, uint32_t slot)
-{
-  const double *img = rs.lazy_base[table];
-  return img ? img[slot] : lazy_weight(rs.TL0, lp, slot);
-}
-
-__device__ __forceinline__ double lazy_weight_lds(const uint64_t *sh_jump, uint64_t tl0, const LinearParams &lp, uint32_t slot)
-{
-  uint64_t x = lcg_next(lcg_jump_lds(sh_jump, tl0, lp.draws_before + (uint64_t)slot));
-  return lp.init_min + lcg_double(x) * lp.init_range;
-}
-
-// ----------------------------------------------------------- tile coding ---
-__device__ __forceinline__ int smod(int x, int y)
-{ // utils.h:70-78
-  int r = x % y;
-  return r < 0 ? r + y : r;
-}
-
-__device__ __forceinline__ uint32_t murmur_mix(uint32_t h, int c)
-{ // tile_coding.h:96-107
-  const uint32_t m = 0x5bd1e995u;
-  uint32_t k = (uint32_t)c;
-  k *= m;
-  k ^= k >> 24;
-  k *= m;
-  h *= m;
-  h ^= k;
-  return h;
-}
-
-// the two halves of murmur_mix: the key's own scramble (depends on the coordinate only) and
-// its absorption into the running hash; murmur_mix(h, c) == murmur_absorb(h, murmur_key(c))
-__device__ __forceinline__ uint32_t murmur_key(int c)
-{
-  const uint32_t m = 0x5bd1e995u;
-  uint32_t k = (uint32_t)c;
-  k *= m;
-  k ^= k >> 24;
-  k *= m;
-  return k;
-}
-__device__ __forceinline__ uint32_t murmur_absorb(uint32_t h, uint32_t k) { return (h * 0x5bd1e995u) ^ k; }
-
-__device__ __forceinline__ uint32_t murmur_final(uint32_t h)
-{ // tile_coding.h:109-113
-  const uint32_t m = 0x5bd1e995u;
-  h ^= h >> 13;
-  h *= m;
-  h ^= h >> 15;
-  return h;
-}
-
-// coordinate of dimension i in tiling j (tile_coding.cpp:128-141)
-template <int T>
-__device__ __forceinline__ int tile_coord(const TileParams &tp, int i, int q, int j)
-{
-  int c = q - smod(q - j * (1 + 2 * i), T);
-  if (tp.wrap[i] != 0)
-    c = smod(c, tp.wrap[i]);
-  return c;
-}
-
-__device__ __forceinline__ int tile_quant(const TileParams &tp, int i, double x)
-{ // tile_coding.cpp:121-125
-  return (int)__builtin_floor(x * tp.scaling[i]);
-}
-
-// generic (runtime T) projection of one input for tiling j
-__device__ inline uint32_t tile_slot_generic(const TileParams &tp, const double *in, int j)
-{
-  uint32_t h = 449u ^ (uint32_t)(tp.D + 1);
-  for (int i = 0; i < tp.D; ++i)
-  {
-    int q = tile_quant(tp, i, in[i]);
-    int c = q - smod(q - j * (1 + 2 * i), tp.T);
-    if (tp.wrap[i] != 0)
-      c = smod(c, tp.wrap[i]);
-    h = murmur_mix(h, c);
-  }
-  h = murmur_mix(h, j);
-  return murmur_final(h) % (uint32_t)tp.memory;
-}
-
-// ---------------------------------------------------------- sparse table ---
-// One replica's weights: an open-addressing table of 64-byte buckets, 4 entries each,
-//   { key[4] (16 B) | aux[4] (16 B) | val[4] (32 B) }   = one fabric request per lookup.
-// key word: bits 0..25 reference slot index + 1 (0 = empty), bits 26..30 tiling that
-// created the entry, bit 31 "touched by a second tiling" (hash collision across tilings).
-// A lookup fetches the whole home bucket at once (3 x 16-byte loads in flight), so it
-// completes in ONE memory round trip unless the bucket is full (then: next bucket).
-// position = bucket * 4 + way; a position is stable for the life of the table.
-struct __attribute__((aligned(64))) Bucket {
-  uint32_t key[4];
-  uint32_t aux[4];
-  double   val[4];
-};
-static_assert(sizeof(Bucket) == 4 * sizeof(Entry), "a bucket is four 16-byte entries");
-
-constexpr uint32_t kKeyMask = 0x03FFFFFFu, kOwnerShift = 26, kSharedBit = 0x80000000u;
-
-struct Table {
-  Bucket  *base;
-  uint32_t bmask, shift;
-};
-
-__device__ __forceinline__ Table table_of(const DevParams &P, int table, int replica)
-{
-  Table t;
-  Entry *e = P.tables + (((size_t)table * (size_t)P.n_replicas + (size_t)replica) << P.logC);
-  t.base = reinterpret_cast<Bucket *>(e);
-  t.bmask = (1u << (P.logC - 2)) - 1u;
-  t.shift = 32u - (P.logC - 2);
-  return t;
-}
-
-__device__ __forceinline__ uint32_t table_home(const Table &t, uint32_t slot)
-{
-  return ((slot + 1u) * 0x9E3779B1u) >> t.shift;
-}
-
-struct BucketRegs { uint4 k; double v[4]; };
-
-__device__ __forceinline__ BucketRegs bucket_load(const Table &t, uint32_t b)
-{
-  BucketRegs r;
-  const Bucket *bp = &t.base[b];
-  r.k = *reinterpret_cast<const uint4 *>(bp->key);
-  const double2 v01 = *reinterpret_cast<const double2 *>(&bp->val[0]);
-  const double2 v23 = *reinterpret_cast<const double2 *>(&bp->val[2]);
-  r.v[0] = v01.x; r.v[1] = v01.y; r.v[2] = v23.x; r.v[3] = v23.y;
-  return r;
-}
-
-__device__ __forceinline__ uint4 bucket_keys(const Table &t, uint32_t b)
-{
-  return *reinterpret_cast<const uint4 *>(t.base[b].key);
-}
-
-__device__ __forceinline__ void value_store(const Table &t, uint32_t pos, double v) { t.base[pos >> 2].val[pos & 3u] = v; }
-__device__ __forceinline__ double value_load(const Table &t, uint32_t pos) { return t.base[pos >> 2].val[pos & 3u]; }
-
-__device__ __forceinline__ void entry_create(const Table &t, uint32_t pos, uint32_t slot, uint32_t owner, double v)
-{
-  Bucket *bp = &t.base[pos >> 2];
-  bp->key[pos & 3u] = (slot + 1u) | (owner << kOwnerShift);
-  bp->val[pos & 3u] = v;
-}
-
-// branch hint: the rare side is laid out of line, the common path falls through (a lone wave
-// has nothing to hide the fetch bubble of a taken branch behind)
-__device__ __forceinline__ bool rarely(bool c) { return __builtin_expect(c, false); }
-
-// order LDS / global accesses of the lanes of one wave (no instruction beyond waits)
-__device__ __forceinline__ void wave_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// way of `slot` in a loaded bucket (0..3) or -1; *empty = bit mask of empty ways
-__device__ __forceinline__ int bucket_find(const uint4 &k, uint32_t slot, uint32_t &empty)
-{
-  const uint32_t want = slot + 1u;
-  const uint32_t k0 = k.x & kKeyMask, k1 = k.y & kKeyMask, k2 = k.z & kKeyMask, k3 = k.w & kKeyMask;
-  empty = (k0 == 0u ? 1u : 0u) | (k1 == 0u ? 2u : 0u) | (k2 == 0u ? 4u : 0u) | (k3 == 0u ? 8u : 0u);
-  int way = -1;
-  way = (k3 == want) ? 3 : way;
-  way = (k2 == want) ? 2 : way;
-  way = (k1 == want) ? 1 : way;
-  way = (k0 == want) ? 0 : way;
-  return way;
-}
-
-// State of one lookup.  hit: pos/val valid.  miss: `bucket` is the first bucket of the
-// probe sequence with an empty way and `empty` its empty-way mask (as loaded).
-struct Lookup {
-  uint32_t bucket, empty, pos;
-  uint32_t kw;                  // key word of the entry found (owner tiling, shared bit); 0 when created by this lane
-  bool     miss;
-};
-
-__device__ __forceinline__ uint32_t bucket_kw(const uint4 &k, int way)
-{
-  return (way == 0) ? k.x : (way == 1) ? k.y : (way == 2) ? k.z : k.w;
-}
-
-// NP independent lookups of one lane, in two halves so that a caller can put independent work
-// between the loads and their first use: table_issue starts the home-bucket loads (all in
-// flight together), table_resolve consumes them.
-template <int NP>
-__device__ __forceinline__ void table_issue(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], BucketRegs (&br)[NP])
-{
-#pragma unroll
-  for (int i = 0; i < NP; ++i)
-  {
-    lk[i].bucket = table_home(t, slot[i]);
-    lk[i].pos = 0u;
-    br[i] = bucket_load(t, lk[i].bucket);
-  }
-}
-
-// way of `slot` in a loaded bucket, branch-free: *hit, and for a hit the way (0..3), the key
-// word and the value.  A slot occupies at most one way.
-__device__ __forceinline__ void bucket_select(const BucketRegs &b, uint32_t slot, bool &hit, uint32_t &way, uint32_t &kw, double &val)
-{
-  const uint32_t want = slot + 1u;
-  const uint32_t k0 = b.k.x & kKeyMask, k1 = b.k.y & kKeyMask, k2 = b.k.z & kKeyMask, k3 = b.k.w & kKeyMask;
-  const bool m0 = k0 == want, m1 = k1 == want, m2 = k2 == want, m3 = k3 == want;
-  way = m1 ? 1u : 0u;
-  kw = m1 ? b.k.y : b.k.x;
-  val = m1 ? b.v[1] : b.v[0];
-  way = m2 ? 2u : way;
-  kw = m2 ? b.k.z : kw;
-  val = m2 ? b.v[2] : val;
-  way = m3 ? 3u : way;
-  kw = m3 ? b.k.w : kw;
-  val = m3 ? b.v[3] : val;
-  hit = m0 || m1 || m2 || m3;
-}
-
-// bit mask of the empty ways of a loaded bucket
-__device__ __forceinline__ uint32_t bucket_empty(const uint4 &k)
-{
-  return ((k.x & kKeyMask) == 0u ? 1u : 0u) | ((k.y & kKeyMask) == 0u ? 2u : 0u) | ((k.z & kKeyMask) == 0u ? 4u : 0u) |
-         ((k.w & kKeyMask) == 0u ? 8u : 0u);
-}
-
-template <int NP>
-__device__ __forceinline__ void table_resolve(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], const BucketRegs (&br)[NP],
-                                              double (&val)[NP], uint32_t &status)
-{
-  bool pending[NP];
-  bool any = false, anynot = false;
-#pragma unroll
-  for (int i = 0; i < NP; ++i)
-  { // straight-line selects: nothing here is worth a branch
-    bool hit;
-    uint32_t way, kw;
-    double v;
-    bucket_select(br[i], slot[i], hit, way, kw, v);
-    lk[i].pos = hit ? ((lk[i].bucket << 2) | way) : lk[i].pos;
-    lk[i].kw = hit ? kw : 0u;
-    val[i] = hit ? v : val[i];
-    lk[i].miss = !hit;                                   // refined below
-    lk[i].empty = 0u;
-    pending[i] = false;
-    anynot = anynot || !hit;
-  }
-  if (rarely(__any(anynot)))
-  { // some lane did not find its slot: empty ways decide between "create here" and "walk on"
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-    {
-      const bool nohit = lk[i].miss;
-      lk[i].empty = bucket_empty(br[i].k);
-      lk[i].miss = nohit && lk[i].empty != 0u;
-      pending[i] = nohit && lk[i].empty == 0u;           // home bucket full of other slots: overflow chain
-      any = any || pending[i];
-    }
-  }
-  if (rarely(__any(any)))
-  { // rare: walk the following buckets
-    for (int it = 1; it < kMaxProbe; ++it)
-    {
-      bool more = false;
-#pragma unroll
-      for (int i = 0; i < NP; ++i)
-        if (pending[i])
-        {
-          lk[i].bucket = (lk[i].bucket + 1u) & t.bmask;
-          const BucketRegs b2 = bucket_load(t, lk[i].bucket);
-          const int way = bucket_find(b2.k, slot[i], lk[i].empty);
-          if (way >= 0)
-          {
-            lk[i].pos = (lk[i].bucket << 2) | (uint32_t)way;
-            lk[i].kw = bucket_kw(b2.k, way);
-            val[i] = (way == 0) ? b2.v[0] : (way == 1) ? b2.v[1] : (way == 2) ? b2.v[2] : b2.v[3];
-            pending[i] = false;
-          }
-          else if (lk[i].empty != 0u) { lk[i].miss = true; pending[i] = false; }
-          else more = true;
-        }
-      if (!__any(more)) break;
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (pending[i]) status |= ST_TABLE_FULL;
-  }
-}
-
-template <int NP>
-__device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&slot)[NP], Lookup (&lk)[NP], double (&val)[NP], uint32_t &status)
-{
-  BucketRegs br[NP];
-  table_issue<NP>(t, slot, lk, br);
-  table_resolve<NP>(t, slot, lk, br, val, status);
-}
-
-// Serialised insert (one lane per 16-lane group at a time), re-reading the bucket: used for
-// the lanes the parallel path could not place (conflicts), and by the fine-grained operators.
-__device__ __noinline__ void table_insert_serial(const Table &t, bool todo, uint32_t slot, uint32_t owner, double w0,
-                                           Lookup &lk, double &val, uint32_t &status, uint32_t &inserted)
-{
-  const int lane = threadIdx.x & 63;
-  unsigned long long pend = __ballot(todo);
-  while (pend != 0ull)
-  {
-    unsigned long long sel = 0ull;                 // lowest pending lane of every 16-lane group goes now
-#pragma unroll
-    for (int gg = 0; gg < 4; ++gg)
-    {
-      unsigned long long grp = pend & (0xFFFFull << (16 * gg));
-      sel |= grp & (~grp + 1ull);
-    }
-    if ((sel >> lane) & 1ull)
-    {
-      bool done = false;
-      uint32_t b = lk.bucket;
-      for (int it = 0; it < kMaxProbe; ++it)
-      {
-        const BucketRegs br = bucket_load(t, b);
-        uint32_t empty;
-        const int way = bucket_find(br.k, slot, empty);
-        if (way >= 0)
-        { // a sibling lane created it meanwhile
-          lk.pos = (b << 2) | (uint32_t)way;
-          lk.kw = bucket_kw(br.k, way);
-          val = (way == 0) ? br.v[0] : (way == 1) ? br.v[1] : (way == 2) ? br.v[2] : br.v[3];
-          done = true;
-          break;
-        }
-        if (empty != 0u)
-        {
-          const uint32_t w = (uint32_t)__builtin_ctz(empty);
-          lk.pos = (b << 2) | w;
-          lk.kw = 0u;
-          entry_create(t, lk.pos, slot, owner, w0);
-          val = w0;
-          inserted++;
-          done = true;
-          break;
-        }
-        b = (b + 1u) & t.bmask;
-      }
-      if (!done) status |= ST_TABLE_FULL;
-    }
-    pend &= ~sel;
-    // The next lane's probe must observe this insert.  Both are vector memory operations of
-    // the same wave issued in this order, which the hardware keeps for one address; the
-    // fence only stops the compiler from reordering them.
-    wave_sync();
-  }
-}
-
-// single lookup-or-create (fine-grained operators): lane = tiling
-__device__ inline void table_probe(const Table &t, const LinearParams &lp, const ReplicaState &rs, int table, bool active,
-                                   uint32_t slot, uint32_t &pos, double &val, uint32_t &status, uint32_t &inserted)
-{
-  uint32_t sl[1] = {slot};
-  Lookup lk[1];
-  lk[0].bucket = 0; lk[0].empty = 0; lk[0].pos = 0; lk[0].kw = 0; lk[0].miss = false;
-  double v[1] = {0};
-  if (active) table_lookup<1>(t, sl, lk, v, status);
-  const bool miss = active && lk[0].miss;
-  double w0 = 0;
-  if (__any(miss))
-  {
-    if (miss) w0 = initial_weight(rs, table, lp, slot);
-    table_insert_serial(t, miss, slot, (uint32_t)(threadIdx.x & 31), w0, lk[0], v[0], status, inserted);
-  }
-  // keep the "touched by a second tiling" bit current (the fused kernel relies on it)
-  if (active && lk[0].kw != 0u && ((lk[0].kw >> kOwnerShift) & 31u) != (uint32_t)(threadIdx.x & 31) && !(lk[0].kw & kSharedBit))
-    t.base[lk[0].pos >> 2].key[lk[0].pos & 3u] = lk[0].kw | kSharedBit;
-  pos = lk[0].pos;
-  val = v[0];
-}
-
-// ----------------------------------------------------------- environments --
-template <int ENV> struct Env;
-
-// dynamics/pendulum + task/pendulum/swingup (pendulum.cpp:40-145)
-template <> struct Env<GRLX_ENV_PENDULUM> {
-  static constexpr int S = 3, D = 2;
-  // pendulum.cpp:40-49, 55-68; the constants are held in registers by the caller (rk4_step)
-  struct Consts { SinConsts k; double invJ, mgl, b, kkr, kr; };
-  template <bool PIN> __device__ static __forceinline__ Consts consts()
-  {
-    const double J = 0.000191, m = 0.055, g = 9.81, l = 0.042, b = 0.000003, K = 0.0536, R = 9.5;
-    Consts c;
-    c.k = sin_consts<PIN>();
-    c.invJ = math_const<PIN>(1 / J);
-    c.mgl = math_const<PIN>(m * g * l);
-    c.b = math_const<PIN>(b);
-    c.kkr = math_const<PIN>(K * K / R);
-    c.kr = math_const<PIN>(K / R);
-    return c;
-  }
-  __device__ static __forceinline__ void eom(const Consts &c, const double *x, double u, double *xd)
-  {
-    double a = x[0], ad = x[1];
-    double add = c.invJ * (c.mgl * psin(a, c.k) - c.b * ad - c.kkr * ad + c.kr * u);
-    xd[0] = ad;
-    xd[1] = add;
-    xd[2] = 1;
-  }
-  __device__ static __forceinline__ void start(const DevParams &P, int test, uint64_t &TL, uint64_t &, double *x)
-  { // pendulum.cpp:97-103 (the RandGen draw happens every episode)
-    TL = lcg_next(TL);
-    double r = lcg_double(TL);
-    x[0] = GRLX_PI + P.randomization * (test == 0) * r * 2 * GRLX_PI;
-    x[1] = 0;
-    x[2] = 0;
-  }
-  __device__ static __forceinline__ double actuate(double a) { return fmin(fmax(a, -3.0), 3.0); }   // :105-109
-  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[0]) < 0x1p19; }
-  __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
-  { // :111-129
-    double a = pfmod(x[0] + GRLX_PI, GRLX_2PI);
-    if (a < 0) a += GRLX_2PI;
-    obs[0] = a;
-    obs[1] = x[1];
-    return x[2] > P.timeout ? 1 : 0;
-  }
-  __device__ static __forceinline__ double evaluate(const DevParams &, const double *x, double action, const double *next)
-  { // :131-145; pow(v, 2) is v*v in the portable specification
-    double a = pfmod(__builtin_fabs(next[0]), GRLX_2PI);
-    if (a > GRLX_PI) a -= GRLX_2PI;
-    double reward = -5 * (a * a) - 0.1 * (next[1] * next[1]) - 1 * (action * action);
-    if ((next[2] - x[2]) != 1)
-      reward *= (next[2] - x[2]) / 0.03;
-    return reward;
-  }
-};
-
-// dynamics/acrobot + task/acrobot/balancing (acrobot.cpp:48-151); state = [theta1, theta2,
-// thetad1, thetad2, time].  No reference test pins it: parity is against the oracle only.
-template <> struct Env<GRLX_ENV_ACROBOT> {
-  static constexpr int S = 5, D = 4;
-  using Consts = SinConsts;                     // held in registers across the integration loop
-  template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
-  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
-  { // acrobot.cpp:48-79, expression for expression
-    const double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
-    const double theta1 = x[0], theta2 = x[1], thetad1 = x[2], thetad2 = x[3];
-    const double tau = u;
-    double sin2, cos2;
-    psincos(theta2, k, sin2, cos2);
-
-    double phi2 = m2*lc2*g*pcos(theta1+theta2-GRLX_PI/2, k);
-    double phi1 = -m2*l1*lc2*thetad2*thetad2*sin2-2*m2*l1*lc2*thetad2*thetad1*sin2 +
-                  (m1*lc1+m2*l1)*g*pcos(theta1-GRLX_PI/2, k)+phi2;
-    double d2 = m2*(lc2*lc2+l1*lc2*cos2)+I2;
-    double d1 = m1*lc1*lc1 + m2*(l1*l1+lc2*lc2+2*l1*lc2*cos2)+I1+I2;
-    double thetadd2 = (tau+d2*phi1/d1-m2*l1*lc2*thetad2*thetad2*sin2-phi2)/
-                      (m2*lc2*lc2+I2-d2*d2/d1);
-    double thetadd1 = -(d2*thetadd2+phi1)/d1;
-
-    if (thetad1 >  4*GRLX_PI) thetadd1 = fmin(thetadd1, 0.);
-    if (thetad1 < -4*GRLX_PI) thetadd1 = fmax(thetadd1, 0.);
-    if (thetad2 >  9*GRLX_PI) thetadd2 = fmin(thetadd2, 0.);
-    if (thetad2 < -9*GRLX_PI) thetadd2 = fmax(thetadd2, 0.);
-
-    xd[0] = thetad1;
-    xd[1] = thetad2;
-    xd[2] = thetadd1;
-    xd[3] = thetadd2;
-    xd[4] = 1;
-  }
-  __device__ static __forceinline__ bool failed(const double *x)
-  { // :147-151
-    return __builtin_fabs(x[0]-GRLX_PI) > 12*GRLX_PI/180 || __builtin_fabs(x[1]) > 12*GRLX_PI/180;
-  }
-  __device__ static __forceinline__ void start(const DevParams &, int, uint64_t &TL, uint64_t &, double *x)
-  { // :102-107
-    TL = lcg_next(TL);
-    const double r1 = lcg_double(TL);
-    TL = lcg_next(TL);
-    const double r2 = lcg_double(TL);
-    x[0] = GRLX_PI+r1*0.01-0.005;
-    x[1] = r2*0.01-0.005;
-    x[2] = 0; x[3] = 0; x[4] = 0;
-  }
-  __device__ static __forceinline__ double actuate(double a) { return a; }                  // Task::actuate default (environment.h:94)
-  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[0]) < 0x1p18 && __builtin_fabs(x[1]) < 0x1p18; }
-  __device__ static __forceinline__ int observe(const DevParams &, const double *x, double *obs)
-  { // :109-125
-#pragma unroll
-    for (int i = 0; i < 4; ++i) obs[i] = x[i];
-    if (failed(x)) return 2;
-    return x[4] > 20 ? 1 : 0;
-  }
-  __device__ static __forceinline__ double evaluate(const DevParams &, const double *, double, const double *next)
-  { // :127-133
-    return failed(next) ? 0. : 1.;
-  }
-};
-
-// dynamics/cart_pole (end_stop = 1) + task/cart_pole/swingup (cart_pole.cpp:41-237);
-// state = [x, theta, xd, thetad, time].  parity unpinned by reference tests.
-template <> struct Env<GRLX_ENV_CART_POLE> {
-  static constexpr int S = 5, D = 4;
-  using Consts = SinConsts;                     // held in registers across the integration loop
-  template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
-  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
-  { // cart_pole.cpp:58-108.  QUIRK reproduced on purpose: :65 reads dtheta = state[3-2*end_stop_],
-    // which for end_stop = 1 is state[1] -- the ANGLE, not its rate.
-    const double g = 9.8, mass_cart = 1.0, mass_pole = 0.1, length = 0.5;
-    const double total_mass = mass_cart + mass_pole, pole_mass_length = mass_pole * length;
-    const double theta = x[1], dtheta = x[3 - 2 * 1];
-    double costheta, sintheta;
-    psincos(theta, k, sintheta, costheta);
-    const double temp = (u + pole_mass_length * dtheta * dtheta * sintheta) / total_mass;
-    const double thetaacc = (g * sintheta - costheta * temp) /
-                            (length * ((4. / 3.) - mass_pole * costheta * costheta / total_mass));
-    const double acc = temp - pole_mass_length * thetaacc * costheta / total_mass;
-    xd[0] = x[2];
-    xd[1] = x[3];
-    xd[2] = acc;
-    xd[3] = thetaacc;
-    xd[4] = 1;
-    if (x[0] > 2.4 && x[2] > 0)
-    { // end stops, :93-105
-      xd[0] = 0;
-      if (acc > 0) xd[2] = 0;
-    }
-    else if (x[0] < -2.4 && x[2] < 0)
-    {
-      xd[0] = 0;
-      if (acc < 0) xd[2] = 0;
-    }
-  }
-  __device__ static __forceinline__ bool failed(const double *x) { return __builtin_fabs(x[0]) > 2.4; }   // :212-215
-  __device__ static __forceinline__ double potential(const double *x)
-  { // :232-238
-    double a = pfmod(__builtin_fabs(x[1]), GRLX_2PI);
-    if (a > GRLX_PI) a -= GRLX_2PI;
-    return -2 * (x[0] * x[0]) - 0.1 * (x[2] * x[2]) - (a * a) - 0.1 * (x[3] * x[3]);
-  }
-  __device__ static __forceinline__ void start(const DevParams &P, int, uint64_t &TL, uint64_t &, double *x)
-  { // :155-164
-    TL = lcg_next(TL);
-    const double r = lcg_double(TL);
-    x[0] = 0;
-    x[1] = GRLX_PI + P.randomization * ((r * 0.1) - 0.05);
-    x[2] = 0; x[3] = 0; x[4] = 0;
-  }
-  __device__ static __forceinline__ double actuate(double a) { return a; }                  // Task::actuate default (environment.h:94)
-  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[1]) < 0x1p19; }
-  __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
-  { // :166-190
-    double a = pfmod(x[1] + GRLX_PI, GRLX_2PI);
-    if (a < 0) a += GRLX_2PI;
-    obs[0] = x[0];
-    obs[1] = a;
-    obs[2] = x[2];
-    obs[3] = x[3];
-    if (P.end_stop_penalty && failed(x)) return 2;
-    return x[4] > P.timeout ? 1 : 0;
-  }
-  __device__ static __forceinline__ double evaluate(const DevParams &P, const double *, double action, const double *next)
-  { // :192-201, shaping = 0
-    const double a15 = action / 15;
-    return potential(next) - P.action_penalty * (a15 * a15) * 2 - P.end_stop_penalty * (failed(next) ? 1 : 0) * 10000;
-  }
-};
-
-// model/compass_walker + task/compass_walker/walk: the simplest walking model with its own
-// RK4 (velocities and angles staged separately), angle wrapping and heel-strike events located
-// by a secant search (SWModel.cpp:15-258, SWModel.h:40-59, compass_walker.cpp:63-94, 251-344).
-// state vector (compass_walker.h:40-42).  parity unpinned by reference tests.
-template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
-  static constexpr int S = 11, D = 5;
-  static constexpr bool kCustomModel = true;
-  enum { SLA = 0, HA, SLAR, HAR, CHANGED, SFX, LASTHIPX, HIPVEL, STEPDIST, TIME, TIMEOUT };
-  struct St { double sla, slar, ha, har, sfx; };
-
-  __device__ static __forceinline__ double hip_x(const St &m) { return m.sfx - psin(m.sla); }
-  __device__ static __forceinline__ double swing_y(const St &m) { return pcos(m.sla) - pcos(m.sla - m.ha); }
-  // the same with the sine constants held in registers by model_step (20 sub-steps x 10 evaluations)
-  __device__ static __forceinline__ double hip_x(const SinConsts &k, const St &m) { return m.sfx - psin_s(m.sla, k); }
-  __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m) { return pcos_s(m.sla, k) - pcos_s(m.sla - m.ha, k); }
-  __device__ static __forceinline__ void wrap(St &m)
-  { // SWModel.h:48-59
-    if (m.sla >= GRLX_PI) m.sla -= 2*GRLX_PI;
-    if (m.sla < -GRLX_PI) m.sla += 2*GRLX_PI;
-    if (m.ha >= GRLX_PI) m.ha -= 2*GRLX_PI;
-    if (m.ha < -GRLX_PI) m.ha += 2*GRLX_PI;
-  }
-  __device__ static __forceinline__ void accel(const DevParams &P, const SinConsts &k, const St &m, double torque, double &asl, double &ahip)
-  { // SWModel.cpp:212-218
-    double sn, cs;
-    psincos_s(m.sla - P.slope_angle, k, sn, cs);
-    asl = sn;
-    ahip = psin_s(m.ha, k) * (m.slar*m.slar - cs) + asl;
-    ahip += torque;
-  }
-  __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt)
-  { // SWModel.cpp:220-258
-    St s1 = state, s2 = state, s3 = state, s4 = state;
-    double k1s, k1h, k2s, k2h, k3s, k3h, k4s, k4h;
-    accel(P, k, s1, torque, k1s, k1h);
-    s2.slar = s1.slar + (dt/2)*k1s;
-    s2.har  = s1.har  + (dt/2)*k1h;
-    s2.sla  = s1.sla  + (dt/2)*s1.slar;
-    s2.ha   = s1.ha   + (dt/2)*s1.har;
-    accel(P, k, s2, torque, k2s, k2h);
-    s3.slar = s1.slar + (dt/2)*k2s;
-    s3.har  = s1.har  + (dt/2)*k2h;
-    s3.sla  = s1.sla  + (dt/2)*s2.slar;
-    s3.ha   = s1.ha   + (dt/2)*s2.har;
-    accel(P, k, s3, torque, k3s, k3h);
-    s4.slar = s1.slar + (dt)*k3s;
-    s4.har  = s1.har  + (dt)*k3h;
-    s4.sla  = s1.sla  + (dt)*s3.slar;
-    s4.ha   = s1.ha   + (dt)*s3.har;
-    accel(P, k, s4, torque, k4s, k4h);
-    state.slar = s1.slar + (dt/6)*(k1s + 2*k2s + 2*k3s + k4s);
-    state.har  = s1.har  + (dt/6)*(k1h + 2*k2h + 2*k3h + k4h);
-    state.sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
-    state.ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
-  }
-  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
-  { // SWModel.cpp:53-104
-    double timeLeft = 0;
-    St s0 = t0, s1 = t1;
-    double s0time = 0, s1time = dt;
-    const int maxIterations = 10;
-    int iIter;
-    for (iIter = 0; iIter < maxIterations; iIter++)
-    {
-      hs = s0;
-      const double y0 = swing_y(k, s0);
-      double newDt = (s1time - s0time) * y0 / (y0 - swing_y(k, s1));
-      rk4(P, k, hs, torque, newDt);
-      if (swing_y(k, hs) > 0)
-      {
-        s0 = hs;
-        s0time = s0time + newDt;
-      }
-      else
-      {
-        s1 = hs;
-        s1time = s0time + newDt;
-      }
-      if (swing_y(k, s0) < precision)
-      {
-        hs = s0;
-        timeLeft = dt - s0time;
-        break;
-      }
-      else if (-swing_y(k, s1) < precision)
-      {
-        hs = s1;
-        timeLeft = dt - s1time;
-        break;
-      }
-    }
-    if (iIter >= maxIterations)
-    {
-      if (swing_y(k, hs) > 0) timeLeft = dt - s0time;
-      else timeLeft = dt - s1time;
-    }
-    return timeLeft;
-  }
-  __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next)
-  { // CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210)
-    St st, prev, hs;
-    st.sfx = x[SFX]; st.sla = x[SLA]; st.slar = x[SLAR]; st.ha = x[HA]; st.har = x[HAR];
-    prev = st;
-    hs = st;
-    bool changed = false;
-    const double partial = P.walker_dt;
-    const SinConsts k = sin_consts<true>();
-    double y_prev = swing_y(k, prev);            // swing_y(prev) of the next sub-step is this sub-step's swing_y(st)
-    for (int i = 0; i < P.integration_steps; i++)
-    {
-      rk4(P, k, st, torque, partial);
-      wrap(st);
-      // detectEvents (SWModel.cpp:30-45)
-      double timeleft = 0;
-      bool struck = false;
-      const double y_now = swing_y(k, st);
-      if ((y_prev >= 0) && (y_now < 0))
-        if (((prev.ha < 0) && (st.ha < 0)) || ((prev.ha > 0) && (st.ha > 0)))
-          if ((st.slar < 0) && (st.ha < 0))
-          { // processStanceLegChange (:106-124)
-            struck = true;
-            timeleft = heelstrike_moment(P, k, prev, st, hs, torque, 1.0E-11, partial);
-            const double c2 = pcos(2.0*hs.sla, k);
-            st.har  = hs.slar*(c2*(1.0 - c2));
-            st.slar = hs.slar*(c2);
-            st.sfx  = hip_x(k, hs) + psin(hs.sla - hs.ha, k);
-            st.sla  = -hs.sla;
-            st.ha   = -2.0*hs.sla;
-          }
-      changed = changed || (timeleft > 0);
-      if (timeleft > 0)
-      {
-        rk4(P, k, st, torque, timeleft);
-        wrap(st);
-      }
-      // a pure function of the state: recomputed only where a heel strike replaced the state
-      y_prev = struck ? swing_y(k, st) : y_now;
-      prev = st;
-    }
-#pragma unroll
-    for (int i = 0; i < S; ++i) next[i] = x[i];
-    next[SLA] = st.sla;
-    next[HA] = st.ha;
-    next[SLAR] = st.slar;
-    next[HAR] = st.har;
-    next[SFX] = st.sfx;
-    next[CHANGED] = changed ? 1. : 0.;
-    next[LASTHIPX] = changed ? hip_x(k, st) : x[LASTHIPX];
-    next[HIPVEL] = - st.slar * pcos(st.sla, k);
-    next[TIME] = x[TIME] + P.control_step;
-    next[TIMEOUT] = x[TIMEOUT];
-  }
-  __device__ static __forceinline__ void eom(const double *, double, double *) {}
-  __device__ static __forceinline__ void start(const DevParams &P, int test, uint64_t &, uint64_t &G, double *x)
-  { // compass_walker.cpp:251-290: rejection sampling on the GLOBAL drand48 stream
-    const double i_sla = 0.1534, i_slar = -0.1561, i_ha = 2.0*0.1534, i_har = -0.0073;
-    const double variation = (!test) ? P.initial_state_variation : 0;
-    const double cslope = pcos(P.slope_angle);
-    St sw;
-    sw.sfx = 0;
-    for (int guard = 0; guard < 100000; ++guard)
-    {
-      G = lcg_next(G); sw.sla  = i_sla  * (1.0 - variation + 2.0*variation*lcg_double(G));
-      G = lcg_next(G); sw.ha   = i_ha   * (1.0 - variation + 2.0*variation*lcg_double(G));
-      G = lcg_next(G); sw.slar = i_slar * (1.0 - variation + 2.0*variation*lcg_double(G));
-      G = lcg_next(G); sw.har  = i_har  * (1.0 - variation + 2.0*variation*lcg_double(G));
-      if (!(sw.slar*sw.slar/2.0 + pcos(sw.sla)*cslope < cslope)) break;
-    }
-#pragma unroll
-    for (int i = 0; i < S; ++i) x[i] = 0;
-    x[SLA] = sw.sla;
-    x[HA] = sw.ha;
-    x[SLAR] = sw.slar;
-    x[HAR] = sw.har;
-    x[SFX] = sw.sfx;
-    x[LASTHIPX] = hip_x(sw);
-    x[HIPVEL] = -sw.slar * pcos(sw.sla);
-    x[TIMEOUT] = test ? 2*P.timeout : P.timeout;
-  }
-  __device__ static __forceinline__ double actuate(double a) { return a; }
-  __device__ static __forceinline__ bool in_domain(const double *x) { return __builtin_fabs(x[SLA]) < 8. && __builtin_fabs(x[HA]) < 8. && __builtin_fabs(x[SLAR]) < 1e6; }
-  __device__ static __forceinline__ bool fallen(const double *x)
-  {
-    return __builtin_fabs(x[SLA]) > GRLX_PI/8 || __builtin_fabs(x[HA] - 2 * x[SLA]) > GRLX_PI/4;
-  }
-  __device__ static __forceinline__ int observe(const DevParams &, const double *x, double *obs)
-  { // :292-329, observe = [1,1,1,1,1,0,0], steps = 0
-    obs[0] = x[SLA];
-    obs[1] = x[HA] - 2 * x[SLA];
-    obs[2] = x[SLAR];
-    obs[3] = x[HAR] - 2 * x[SLAR];
-    obs[4] = x[CHANGED] > 0.5 ? 1. : 0.;
-    if (fallen(x)) return 2;
-    if (x[TIME] > x[TIMEOUT]) return 1;
-    return 0;
-  }
-  __device__ static __forceinline__ double evaluate(const DevParams &P, const double *, double, const double *next)
-  { // :331-344
-    double reward = -1;
-    if (next[CHANGED] > 0.5) reward = fmin(50 * 4 * psin(next[SLA]), 30.);
-    if (fallen(next))
-      if (P.negative_reward != 0) reward = P.negative_reward;
-    return reward;
-  }
-};
-
-template <int ENV> struct HasCustomModel { static constexpr bool value = false; };
-template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bool value = true; };
-
-// DynamicalModel::step (modeled.cpp:254-276): classical RK4 sub-steps.
-// The last state component is time (xd = 1 in every supported dynamics, and no eom reads
-// it), so its stage values are the constant h and its update the constant
-// (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
-template <int ENV, bool PIN>
-__device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
-{
-  constexpr int S = Env<ENV>::S, SD = S - 1;
-  const double h = P.h;
-  const double tinc = (((h + 2 * h) + 2 * h) + h) / 6;
-  double xd[S], k1[SD], k2[SD], k3[SD], k4[SD], t[S];
-#pragma unroll
-  for (int i = 0; i < S; ++i) { next[i] = x[i]; t[i] = x[i]; }
-  const typename Env<ENV>::Consts ec = Env<ENV>::template consts<PIN>();   // PIN: constants held in vector registers
-  for (int ii = 0; ii < P.integration_steps; ++ii)
-  {
-    Env<ENV>::eom(ec, next, u, xd);
-#pragma unroll
-    for (int i = 0; i < SD; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
-    Env<ENV>::eom(ec, t, u, xd);
-#pragma unroll
-    for (int i = 0; i < SD; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
-    Env<ENV>::eom(ec, t, u, xd);
-#pragma unroll
-    for (int i = 0; i < SD; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
-    Env<ENV>::eom(ec, t, u, xd);
-#pragma unroll
-    for (int i = 0; i < SD; ++i)
-    {
-      k4[i] = h * xd[i];
-      next[i] = next[i] + div6(k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
-    }
-    next[SD] = next[SD] + tinc;
-  }
-}
-
-// ModeledEnvironment::step (modeled.cpp:160-213), window 1, no delta, discrete_time 1
-// PIN: hold the dynamics' constants in vector registers across the integration loop (pays at one
-// wave per SIMD, costs registers)
-template <int ENV, bool PIN = true>
-__device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal, uint32_t &status)
-{
-  constexpr int S = Env<ENV>::S;
-  double next[S];
-  if constexpr (HasCustomModel<ENV>::value)
-    Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next);     // model/compass_walker integrates itself
-  else
-    rk4_step<ENV, PIN>(P, x, Env<ENV>::actuate(action), next);
-  terminal = Env<ENV>::observe(P, next, obs);
-  reward = Env<ENV>::evaluate(P, x, action, next);
-  // the branch-free sin/cos need |angle| < 2^20; 2^19 at step ends leaves room for the stages
-  if (!Env<ENV>::in_domain(next)) status |= ST_DOMAIN;
-#pragma unroll
-  for (int i = 0; i < S; ++i) x[i] = next[i];
-}
-
-// ------------------------------------------------------------ samplers -----
-// GreedySampler::findmax (greedy.cpp:47-61); loops are unrolled over the
-// compile-time action count so Q-values stay in registers
-template <int NA>
-__device__ __forceinline__ void findmax(const double (&v)[NA], int &mai, int &man, double &best)
-{
-  best = v[0];
-  mai = 0;
-  man = 1;
-#pragma unroll
-  for (int i = 1; i < NA; ++i)
-  {
-    if (v[i] > best) { best = v[i]; mai = i; man = 1; }
-    else if (v[i] == best) man++;
-  }
-}
-
-// random tie break (greedy.cpp:77-85): the (jj+1)-th maximal entry, jj = lrand48() % man;
-// getInteger draws from the GLOBAL stream (utils.h:127-130)
-template <int NA>
-__device__ __forceinline__ int tie_break(const double (&v)[NA], double best, int man, uint64_t &G)
-{
-  G = lcg_next(G);
-  int jj = (int)(lcg_long(G) % (uint32_t)man);
-  int res = 0;
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-    if (v[i] == best)
-    {
-      if (jj == 0) res = i;
-      --jj;
-    }
-  return res;
-}
-
-__device__ __forceinline__ double   in_reg(double v)   { asm volatile("" : "+v"(v)); return v; }
-__device__ __forceinline__ uint32_t in_reg(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
-__device__ __forceinline__ bool     in_reg(bool v)     { uint32_t t = v ? 1u : 0u; asm volatile("" : "+v"(t)); return t != 0u; }
-
-// arr[idx] for a register array: every candidate is pinned in a register first, otherwise the
-// compiler rewrites the select chain as a dynamically indexed load from a stack copy (scratch memory)
-template <typename Tv, int NA>
-__device__ __forceinline__ Tv pick(const Tv (&arr)[NA], int idx)
-{
-  Tv v = in_reg(arr[0]);
-#pragma unroll
-  for (int a = 1; a < NA; ++a)
-  {
-    const Tv c = in_reg(arr[a]);
-    v = (a == idx) ? c : v;
-  }
-  return v;
-}
-
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // ------------------------------------------------------- fused rollout -----
 // LDS tile shared by the 4 replicas of the wave; index (row*16 + tiling)*4 + group
 // makes both the per-lane writes and the 4 simultaneous broadcast reads conflict-free.
 #define SHW(row, k, g) sh_w[(((row) * 16 + (k)) << 2) + (g)]
 
-// ------------------------------------------------------- register trace ----
-// Replacing eligibility trace (trace.h:208-235) of one tiling, newest first, kept in
-// registers.  val is the AUTHORITATIVE weight of the slot while it is in the trace: it is
-// written back to the table only when the slot leaves the trace (write-back), unless the
-// slot is shared with another tiling (bit e of wt): then every update is also stored
-// (write-through) so that the other lane's loads see it.
-struct TraceRegs {
-  uint32_t pos[kMaxTrace];
-  double   val[kMaxTrace];
-  uint32_t cnt2;                // occurrences of the slot in its projection minus 1, two bits per entry
-  uint32_t wt;
-  bool     dup;                 // some entry occurs twice in its projection (sticky until cleared)
-  int      len;
-  double   total;
-};
 
-__device__ __forceinline__ uint32_t trace_cnt(const TraceRegs &tr, int e) { return ((tr.cnt2 >> (2 * e)) & 3u) + 1u; }
+} // namespace grlx
 
-__device__ __forceinline__ void trace_init(TraceRegs &tr)
-{
-#pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e) { tr.pos[e] = kInvalidPos; tr.val[e] = 0; }
-  tr.cnt2 = 0;
-  tr.wt = 0;
-  tr.dup = false;
-  tr.len = 0;
-  tr.total = 1.;
-}
+#include "grlx_update.h"
 
-// write every cached weight back; optionally forget the entries (EnumeratedTrace::clear)
-__device__ __forceinline__ void trace_flush(TraceRegs &tr, const Table &tab, bool clear)
-{
-#pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e)
-  {
-    if (tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u)) value_store(tab, tr.pos[e], tr.val[e]);
-    if (clear) tr.pos[e] = kInvalidPos;
-  }
-  if (clear)
-  {
-    tr.wt = 0;
-    tr.dup = false;
-    tr.len = 0;
-    tr.total = 1.;
-  }
-}
-
-// a slot that is in this lane's trace has its current weight in val, not (yet) in the table
-__device__ __forceinline__ double trace_forward(const TraceRegs &tr, uint32_t pos, double w)
-{
-#pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e) w = (tr.pos[e] == pos) ? tr.val[e] : w;
-  return w;
-}
-
-// slot `mp` has just become shared between tilings: the owner writes its cached weight back
-// and keeps the table current from now on
-__device__ __forceinline__ void trace_share_event(TraceRegs &tr, const Table &tab, uint32_t mp)
-{
-#pragma unroll
-  for (int e = 0; e < kMaxTrace; ++e)
-    if (tr.pos[e] == mp && !((tr.wt >> e) & 1u))
-    {
-      value_store(tab, mp, tr.val[e]);
-      tr.wt |= 1u << e;
-    }
-}
-
-struct UpdateParams {
-  double dW, dT, ee, cut, out_min, out_max;
-  bool   limit, use_trace;
-};
-
-__device__ __forceinline__ double add_clamped(const UpdateParams &u, double v, double d)
-{
-  return u.limit ? clampd(v + d, u.out_min, u.out_max) : v + d;
-}
-
-// One TD update of a linear representation with a replacing trace, as the reference orders it:
-//   write(p, target, alpha)            -> every slot of p gets +dW          (linear.cpp:186-216)
-//   update(trace, alpha*delta, e)      -> entry k gets +weight_k*dT*ee      (representation.h:79-83)
-//   trace->add(p, e)                   -> ssub, push, pop                   (trace.h:215-234)
-// Lane j handles tiling j.  Returns nothing; p's final weight becomes trace entry 0.
-// sh_ppos / sh_fb / sh_fbflag: LDS scratch of the wave (see rollout kernels).
-// Eviction: a weight that leaves the trace is written back to the table.  With HOLD the first
-// write-back of the call is handed to the caller instead ({pos, val} in ev; the caller stores it
-// later; pos = kInvalidPos: nothing held); ev.n counts the write-backs of the call (n > 1, or a
-// path that does not count: n = 2, tells the caller that table values it loaded before this call
-// may be stale).
-struct Evicted { uint32_t n, pos; double val; };
-
-template <bool HOLD>
-__device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, const UpdateParams &u, uint32_t p_pos, bool p_sh, double wp,
-                                               int g, int j, const uint32_t *sh_ppos, double *sh_fb, uint32_t *sh_fbflag, uint32_t &status,
-                                               Evicted &ev)
-{
-  // Aliasing between p and the trace (IndexProjection::ssub, projection.h:94-104).  Inside a
-  // lane it is a register compare.  Across lanes it needs a p that is a slot shared between
-  // tilings (only such a slot can sit in another lane's trace, or twice in p): those lanes'
-  // positions are compared through LDS -- usually none.
-  const uint32_t shmask = (uint32_t)((__ballot(p_sh) >> (16 * g)) & 0xFFFFull);
-  uint32_t cp = 1;                                     // occurrences of my slot inside p
-  double v;                                            // final weight of p's slot after this step
-  bool cross = tr.dup;                                 // does this lane see an alias that crosses lanes?
-  if (rarely(__any(shmask != 0u)))
-  { // some lane's p is a shared slot: compare those few positions (usually one) with my trace and my p
-    for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
-    {
-      const int k = __builtin_ctz(mm);
-      const uint32_t ppk = sh_ppos[g * 16 + k];
-      if (k != j)
-      {
-        if (ppk == p_pos) cross = true;
-#pragma unroll
-        for (int e = 0; e < kMaxTrace; ++e)
-          if (e < tr.len && tr.pos[e] == ppk) cross = true;
-      }
-    }
-  }
-  if (!rarely(__any(cross)))
-  { // ---- common case: no alias crosses lanes in this wave; aliasing is a register compare inside
-    // the lane; straight-line code, no exec-mask branches
-    // Entries at e >= len are always invalid (pos == kInvalidPos), so validity alone decides; the
-    // weight sequence 1, ee, ee^2, ... does not depend on the data (a compile-time table in a
-    // specialised build).
-    double a_val = 0, a_de = 0;
-    bool a_upd = false;
-    uint32_t doitmask = 0, ownmask = 0;
-    if (u.use_trace)
-    {
-      double weight = 1.;
-      bool upd = true;
-#pragma unroll
-      for (int e = 0; e < kMaxTrace; ++e)
-      {
-        upd = upd && (weight > 0.001);                   // representation.h:81
-        const double de = weight * u.dT * u.ee;
-        const bool own = tr.pos[e] == p_pos;             // p_pos is a valid position
-        const bool doit = tr.pos[e] != kInvalidPos && !own && upd;
-        const double vv = add_clamped(u, tr.val[e], de);
-        tr.val[e] = doit ? vv : tr.val[e];
-        doitmask |= doit ? (1u << e) : 0u;
-        ownmask |= own ? (1u << e) : 0u;
-        a_val = own ? tr.val[e] : a_val;
-        a_de = own ? de : a_de;
-        a_upd = own ? upd : a_upd;
-        tr.pos[e] = own ? kInvalidPos : tr.pos[e];       // ssub: the slot leaves the trace
-        weight *= u.ee;
-      }
-    }
-    const bool aliased = ownmask != 0u;
-    const uint32_t stmask = doitmask & tr.wt;            // write-through entries that changed
-    tr.wt &= ~ownmask;
-    // p's write first, then the aliased entry's update (if it is still being updated)
-    const double base = aliased ? a_val : wp;
-    const double v1 = add_clamped(u, base, u.dW);
-    const double v2 = add_clamped(u, v1, a_de);
-    v = (aliased && a_upd) ? v2 : v1;
-    if (rarely(__any(stmask != 0u)))
-    {
-#pragma unroll
-      for (int e = 0; e < kMaxTrace; ++e)
-        if ((stmask >> e) & 1u) value_store(tab, tr.pos[e], tr.val[e]);   // shared slot: keep the table current
-    }
-  }
-  else
-  { // ---- general case: some alias crosses lanes (a slot shared between tilings is involved)
-    uint32_t xm[kMaxTrace];                              // lanes k != j whose p equals my trace slot e
-#pragma unroll
-    for (int e = 0; e < kMaxTrace; ++e) xm[e] = 0u;
-    for (uint32_t mm = shmask; mm != 0u; mm &= mm - 1u)
-    {
-      const int k = __builtin_ctz(mm);
-      const uint32_t ppk = sh_ppos[g * 16 + k];
-      if (k != j)
-      {
-        if (ppk == p_pos) cp++;
-#pragma unroll
-        for (int e = 0; e < kMaxTrace; ++e) xm[e] |= (e < tr.len && tr.pos[e] == ppk) ? (1u << k) : 0u;
-      }
-    }
-    double v_alias = 0;
-    bool aliased = false;
-    if (u.use_trace)
-    { // trace entries, newest first (representation.h:79-83, trace.h:150-178)
-      double weight = 1.;
-      bool upd = true;
-#pragma unroll
-      for (int e = 0; e < kMaxTrace; ++e)
-        if (e < tr.len)
-        {
-          upd = upd && (weight > 0.001);
-          const double de = weight * u.dT * u.ee;
-          if (tr.pos[e] != kInvalidPos)
-          {
-            const bool own = tr.pos[e] == p_pos;
-            if (!own && xm[e] == 0u)
-            {
-              if (upd)
-              { // LinearRepresentation::update (linear.cpp:198-216); a slot that occurs twice in
-                // its projection is updated twice
-                double vv = add_clamped(u, tr.val[e], de);
-                if ((tr.wt >> e) & 1u)
-                {
-                  for (uint32_t c = 1; c < trace_cnt(tr, e); ++c) vv = add_clamped(u, vv, de);
-                  value_store(tab, tr.pos[e], vv);
-                }
-                tr.val[e] = vv;
-              }
-            }
-            else
-            { // the slot is also written through p: p's write comes first, then this entry's
-              // update; the slot leaves the trace
-              if (upd)
-              {
-                double vv = tr.val[e];
-                const uint32_t cpx = (own ? 1u : 0u) + (uint32_t)__builtin_popcount(xm[e]);
-                for (uint32_t c = 0; c < cpx; ++c) vv = add_clamped(u, vv, u.dW);
-                for (uint32_t c = 0; c < trace_cnt(tr, e); ++c) vv = add_clamped(u, vv, de);
-                if (own) { v_alias = vv; aliased = true; }
-                for (uint32_t mm = xm[e]; mm != 0u; mm &= mm - 1u)
-                {
-                  const int k = __builtin_ctz(mm);
-                  sh_fb[k * 4 + g] = vv;
-                  sh_fbflag[k * 4 + g] = 1u;
-                }
-              }
-              tr.pos[e] = kInvalidPos;
-              tr.wt &= ~(1u << e);
-            }
-          }
-          weight *= u.ee;
-        }
-    }
-    wave_sync();
-    if (aliased)
-      v = v_alias;
-    else if (shmask != 0u && sh_fbflag[j * 4 + g] != 0u)
-      v = sh_fb[j * 4 + g];
-    else
-    {
-      v = wp;
-      for (uint32_t c = 0; c < cp; ++c) v = add_clamped(u, v, u.dW);
-    }
-    if (HOLD) ev.n = 2u;                                   // weights moved between lanes: not tracked
-  }
-  // a shared slot is kept current in the table; an exclusive one only if no trace follows.  (Rare per-lane
-  // blocks sit behind a wave-uniform test: skipping an exec-masked block is a TAKEN branch, ~30 cycles for a
-  // lone wave; a not-taken scalar branch is one issue slot.)
-  if (rarely(__any(p_sh || !u.use_trace)))
-    if (p_sh || !u.use_trace) value_store(tab, p_pos, v);
-
-  // trace_->add(p, decay) (trace.h:215-234)
-  if (u.use_trace)
-  {
-    if (u.ee < u.cut)
-    { // decay below the cut: clear() first
-      trace_flush(tr, tab, true);
-      if (HOLD) ev.n = 2u;
-    }
-    if (tr.len >= kMaxTrace) status |= ST_TRACE_OVERFLOW;  // cannot happen: validated at create
-#pragma unroll
-    for (int e = kMaxTrace - 1; e > 0; --e)
-    {
-      tr.pos[e] = tr.pos[e - 1];
-      tr.val[e] = tr.val[e - 1];
-    }
-    tr.wt = (tr.wt << 1) & ((1u << kMaxTrace) - 1u);
-    tr.cnt2 = (tr.cnt2 << 2) & ((1u << (2 * kMaxTrace)) - 1u);
-    tr.pos[0] = p_pos;
-    tr.val[0] = v;
-    if (cp > 4u) status |= ST_TRACE_OVERFLOW;              // more than four tilings on one slot: not representable
-    tr.cnt2 |= (cp - 1u) & 3u;
-    tr.dup = tr.dup || cp > 1u;
-    if (p_sh) tr.wt |= 1u;
-    tr.len = (tr.len < kMaxTrace) ? tr.len + 1 : kMaxTrace;
-    tr.total *= u.ee;
-    { // pop while the total decay is below the cut (trace.h:227-231): the first pop as selects, more in a rare loop
-      const bool pop = tr.total < u.cut && tr.len > 1;
-      const double undone = tr.total / u.ee;
-      tr.total = pop ? undone : tr.total;
-      tr.len = pop ? tr.len - 1 : tr.len;
-      if (rarely(__any(tr.total < u.cut && tr.len > 1)))
-        while (tr.total < u.cut && tr.len > 1)
-        {
-          tr.total /= u.ee;
-          tr.len--;
-        }
-    }
-    // entries popped off the front of the reference's deque: write their weights back.  In the steady state
-    // of a full trace exactly the entry that was shifted into the last register falls off.
-    if (!rarely(__any(tr.len != kMaxTrace - 1)))
-    {
-      constexpr int e = kMaxTrace - 1;
-      const bool wb = tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u);
-      if (HOLD)
-      {
-        const bool hold = wb && ev.n == 0u;
-        if (rarely(__any(wb && !hold)))
-          if (wb && !hold) value_store(tab, tr.pos[e], tr.val[e]);
-        ev.pos = hold ? tr.pos[e] : ev.pos;
-        ev.val = hold ? tr.val[e] : ev.val;
-        ev.n += wb ? 1u : 0u;
-      }
-      else if (wb)
-        value_store(tab, tr.pos[e], tr.val[e]);
-      tr.pos[e] = kInvalidPos;
-      tr.wt &= ~(1u << e);
-    }
-    else
-#pragma unroll
-    for (int e = 0; e < kMaxTrace; ++e)
-      if (e >= tr.len)
-      {
-        const bool wb = tr.pos[e] != kInvalidPos && !((tr.wt >> e) & 1u);
-        if (HOLD)
-        {
-          const bool hold = wb && ev.n == 0u;
-          if (wb && !hold) value_store(tab, tr.pos[e], tr.val[e]);
-          ev.pos = hold ? tr.pos[e] : ev.pos;
-          ev.val = hold ? tr.val[e] : ev.val;
-          ev.n += wb ? 1u : 0u;
-        }
-        else if (wb)
-          value_store(tab, tr.pos[e], tr.val[e]);
-        tr.pos[e] = kInvalidPos;
-        tr.wt &= ~(1u << e);
-      }
-  }
-}
-
-// Lookup-or-create of NP slots of one lane in one table, all first-round loads in flight
-// together; creates missing slots (parallel LDS-ranked claims, serialised fallback) and
-// resolves new cross-tiling sharing events.  sh[i]: the slot is shared between tilings.
-// on_share(mp): called in every lane of the group for each slot position that just became shared.
-// table_get_finish: the part after the loads of table_issue (lk, br).
-template <int NP, typename OnShare>
-__device__ __forceinline__ void table_get_finish(const Table &tab, const LinearParams &lp, const ReplicaState &rs, int table, const uint32_t (&slot)[NP],
-                                                 Lookup (&lk)[NP], const BucketRegs (&br)[NP],
-                                                 uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
-                                                 uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
-                                                 uint32_t &status, uint32_t &inserted, OnShare on_share)
-{
-  const int lane = threadIdx.x & 63;
-  table_resolve<NP>(tab, slot, lk, br, w, status);
-  bool anymiss = false;
-#pragma unroll
-  for (int a = 0; a < NP; ++a) anymiss = anymiss || lk[a].miss;
-  if (rarely(__any(anymiss)))
-  { // Create the missing slots.  All lookups of this call are complete, so every lane that
-    // misses into bucket B saw the same empty ways of B.  Claims are ranked in the fixed order
-    // (index, tiling) through LDS: the r-th claimant of a bucket takes its r-th empty way -- no
-    // reload, all lanes in parallel.  Equal slots claimed twice (a hash collision inside one
-    // state) or a bucket with too few empty ways fall back to the serialised path.
-    double w0[NP];
-    bool slow[NP];
-    uint32_t claims[NP];                                  // lanes of my group that claim a bucket, per index
-#pragma unroll
-    for (int a = 0; a < NP; ++a)
-    {
-      sh_mb[g * (NP * 16) + a * 16 + j] = lk[a].miss ? lk[a].bucket : 0xFFFFFFFFu;
-      sh_ms[g * (NP * 16) + a * 16 + j] = slot[a];
-      claims[a] = (uint32_t)((__ballot(lk[a].miss) >> (16 * g)) & 0xFFFFull);
-      w0[a] = 0;
-      slow[a] = false;
-      if (lk[a].miss)
-      { // a loaded policy image replaces the drawn initial value (read here, on the rare path, so
-        // that the hot path carries no pointer for it)
-        const double *img = rs.lazy_base[table];
-        w0[a] = img ? img[slot[a]] : lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int a = 0; a < NP; ++a)
-      if (lk[a].miss)
-      {
-        const int me = a * 16 + j;
-        uint32_t rank = 0;
-        bool dup = false;
-#pragma unroll
-        for (int a2 = 0; a2 < NP; ++a2)
-          for (uint32_t mm = claims[a2]; mm != 0u; mm &= mm - 1u)
-          { // only the (index, tiling) pairs that actually claim something
-            const int k = a2 * 16 + __builtin_ctz(mm);
-            const uint32_t ob = sh_mb[g * (NP * 16) + k], os = sh_ms[g * (NP * 16) + k];
-            if (ob == lk[a].bucket && k != me)
-            {
-              if (os == slot[a]) dup = true;
-              else if (k < me) rank++;
-            }
-          }
-        uint32_t e = lk[a].empty;
-        for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;      // drop the ways taken by earlier claimants
-        if (dup || e == 0u)
-          slow[a] = true;
-        else
-        {
-          lk[a].pos = (lk[a].bucket << 2) | (uint32_t)__builtin_ctz(e);
-          lk[a].kw = 0u;
-          entry_create(tab, lk[a].pos, slot[a], (uint32_t)j, w0[a]);
-          w[a] = w0[a];
-          inserted++;
-        }
-      }
-    wave_sync();
-#pragma unroll
-    for (int a = 0; a < NP; ++a)
-      if (rarely(__any(slow[a])))
-      { // out-of-line and rare: work on copies so that nothing of the hot path has its address taken
-        Lookup tmp = lk[a];
-        double tv = w[a];
-        uint32_t tst = 0, tins = 0;
-        table_insert_serial(tab, slow[a], slot[a], (uint32_t)j, w0[a], tmp, tv, tst, tins);
-        lk[a] = tmp;
-        w[a] = tv;
-        status |= tst;
-        inserted += tins;
-      }
-  }
-
-  // ---- slots shared between tilings (a collision of the reference's hash across tilings,
-  // ~70 per replica and run).  A slot found with a foreign owner and no shared bit yet is a
-  // NEW sharing event: mark it in the table and tell the owner's lane, whose trace may hold
-  // the only current copy of the weight.
-  bool fresh[NP];
-  bool anyfresh = false;
-#pragma unroll
-  for (int a = 0; a < NP; ++a)
-  {
-    pos[a] = lk[a].pos;
-    const bool found = lk[a].kw != 0u;
-    const bool foreign = found && ((lk[a].kw >> kOwnerShift) & 31u) != (uint32_t)j;
-    sh[a] = found && (foreign || (lk[a].kw & kSharedBit) != 0u);
-    fresh[a] = foreign && (lk[a].kw & kSharedBit) == 0u;
-    anyfresh = anyfresh || fresh[a];
-  }
-  if (rarely(__any(anyfresh)))
-  {
-#pragma unroll
-    for (int a = 0; a < NP; ++a)
-    {
-      if (fresh[a]) tab.base[pos[a] >> 2].key[pos[a] & 3u] = lk[a].kw | kSharedBit;
-      unsigned long long pend = __ballot(fresh[a]);
-      while (pend != 0ull)
-      { // one event per 16-lane group at a time
-        unsigned long long sel = 0ull;
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg)
-        {
-          unsigned long long grp = pend & (0xFFFFull << (16 * gg));
-          sel |= grp & (~grp + 1ull);
-        }
-        const bool mine = ((sel >> lane) & 1ull) != 0ull;
-        const bool grp_has = (sel & gmask) != 0ull;
-        if (mine) sh_mail[g] = pos[a];
-        wave_sync();
-        if (grp_has)
-        {
-          const uint32_t mp = sh_mail[g];
-          on_share(mp);                                   // owner side: write back, switch to write-through
-#pragma unroll
-          for (int b2 = 0; b2 < NP; ++b2)
-            if (pos[b2] == mp) sh[b2] = true;
-        }
-        wave_sync();
-        if (mine) w[a] = value_load(tab, pos[a]);         // the value the owner just wrote back
-        pend &= ~sel;
-      }
-    }
-  }
-}
-
-template <int NP, typename OnShare>
-__device__ __forceinline__ void table_get(const Table &tab, const LinearParams &lp, const ReplicaState &rs, int table, const uint32_t (&slot)[NP],
-                                          uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
-                                          uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail, const uint64_t *sh_jump,
-                                          uint32_t &status, uint32_t &inserted, OnShare on_share)
-{
-  Lookup lk[NP];
-  BucketRegs br[NP];
-  table_issue<NP>(tab, slot, lk, br);
-  table_get_finish<NP>(tab, lp, rs, table, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, on_share);
-}
+namespace grlx {
 
 // in-kernel stamps (diagnostic instantiation only; cdna_hip_programming.md section 7)
 __device__ __forceinline__ unsigned long long stamp()
