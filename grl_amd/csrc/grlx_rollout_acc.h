@@ -1,0 +1,407 @@
+// grlx_rollout_acc.h -- accumulating-trace rollout: rollout_acc_kernel and its launcher.
+// Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
+#pragma once
+
+namespace grlx {
+
+// ------------------------------------------------- accumulating-trace rollout ---
+// trace/enumerated/accumulating (trace.h:238-263): no ssub, cut 1e-4 -- up to 19 entries in which a slot may
+// occur many times, every occurrence adding to the weight in the reference's order (entry-major, newest first;
+// tiling-minor).  Nothing is cached here: the trace holds table positions only and every update is a
+// read-modify-write of the table, entry after entry (same-address accesses of one wave complete in issue
+// order); slots shared between tilings are updated one lane at a time in tiling order.  SARSA, Q-learning and
+// Expected SARSA over one Q table; TD update in place.  A plain, correct path -- about 3x the time of the
+// replacing-trace kernel.
+constexpr int kAccTrace = 20;
+
+// f() in the flagged lanes of every 16-lane group, one lane of a group at a time, ascending
+template <typename F>
+__device__ __forceinline__ void serial_lanes(bool flag, F f)
+{
+  const int lane = threadIdx.x & 63;
+  unsigned long long pend = __ballot(flag);
+  while (pend != 0ull)
+  {
+    unsigned long long sel = 0ull;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg)
+    {
+      unsigned long long grp = pend & (0xFFFFull << (16 * gg));
+      sel |= grp & (~grp + 1ull);
+    }
+    if ((sel >> lane) & 1ull) f();
+    pend &= ~sel;
+    wave_sync();
+  }
+}
+
+template <int ENV, int NA>
+__global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_trials)
+{
+  constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
+  __shared__ double   sh_w[(NA + 1) * 16 * 4];
+  __shared__ uint32_t sh_mb[4 * NA * 16];
+  __shared__ uint32_t sh_ms[4 * NA * 16];
+  __shared__ uint32_t sh_mail[4];
+  __shared__ double   sh_res[4 * 16];
+  __shared__ uint64_t sh_jump[2048];
+  jump_table_to_lds(sh_jump);
+
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  const int r_raw = blockIdx.x * kReplicasPerWave + g;
+  const bool live = r_raw < P.n_replicas;
+  const int r = live ? r_raw : 0;
+  const bool tapped = live && (r == P.tap_replica);
+  const unsigned long long gmask = 0xFFFFull << (16 * g);
+
+  ReplicaState &RS = P.states[r];
+  double x[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) x[i] = RS.x[i];
+  uint64_t G = RS.G, TL = RS.TL, S1 = RS.S1;
+  double eps_decay = RS.eps_decay;
+  int64_t tt = RS.tt, ss = RS.ss;
+  uint64_t test_steps = RS.test_steps;
+  uint32_t status = RS.status, rows = RS.rows, inserted = 0;
+
+  const Table tab = table_of(P, 0, r);
+  const double out_min = P.lin.out_min, out_max = P.lin.out_max;
+  const bool limit = P.lin.limit != 0;
+  const double ee = P.gl, cut = 0.0001;
+
+  double acts[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acts[a] = P.actions[a];
+  uint32_t key_act[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+    key_act[a] = in_reg(murmur_key(tile_coord<T>(P.tile, D, tile_quant(P.tile, D, P.actions[a]), j)));
+  const uint32_t key_j = in_reg(murmur_key(j));
+
+  // the trace of this lane's tiling: positions newest first, bit e of tsh = entry e is a slot shared between tilings
+  uint32_t tpos[kAccTrace];
+#pragma unroll
+  for (int e = 0; e < kAccTrace; ++e) tpos[e] = kInvalidPos;
+  uint32_t tsh = 0;
+  int tlen = 0;
+  double ttotal = 1.;
+  int tr_len_ref = 0;
+
+  auto add_to = [&](uint32_t pos, double d) {       // LinearRepresentation::update of one index (linear.cpp:198-216)
+    const double v = value_load(tab, pos) + d;
+    value_store(tab, pos, limit ? clampd(v, out_min, out_max) : v);
+  };
+
+  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  {
+    const int ti = P.test_interval;
+    const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
+    double obs[D], reward = 0, total_reward = 0;
+    int terminal = 0;
+    bool running = live;
+    if (live)
+    {
+      Env<ENV>::start(P, test, TL, G, x);
+      Env<ENV>::observe(P, x, obs);
+    }
+    double time = 0, action = 0;
+    int action_index = 0;
+    uint32_t p_pos = kInvalidPos, p_slot = 0;
+    bool p_sh = false;
+    if (!test)
+    { // TDAgent::start -> predictor->finalize() -> trace_->clear() (td.cpp:54, sarsa.cpp:126-132)
+#pragma unroll
+      for (int e = 0; e < kAccTrace; ++e) tpos[e] = kInvalidPos;
+      tsh = 0; tlen = 0; ttotal = 1.; tr_len_ref = 0;
+    }
+    bool first = true;
+
+    for (;;)
+    {
+      if (!__any(running)) break;
+      if (running)
+      {
+        if (!first)
+        {
+          env_step<ENV>(P, x, action, obs, reward, terminal, status);
+          total_reward += reward;
+          time += 1;
+        }
+        const bool has_next = first || terminal != 2;
+        const bool update = !first && !test;
+
+        uint32_t slot[NA], pos[NA];
+        double w[NA];
+        bool sh[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { slot[a] = 0; pos[a] = kInvalidPos; w[a] = 0; sh[a] = false; }
+        if (has_next)
+        {
+          uint32_t hpre = 449u ^ (uint32_t)(D + 2);
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+            hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, tile_quant(P.tile, i, obs[i]), j));
+          const uint32_t hpm = hpre * 0x5bd1e995u;
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+          {
+            uint32_t h = murmur_absorb(hpm ^ key_act[a], key_j);
+            const uint32_t hm = murmur_final(h), mem = (uint32_t)P.tile.memory;
+            slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (has_next)
+          table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+                        [&](uint32_t mp) { // a slot became shared: every entry that refers to it is updated serially from now on
+                          if (p_pos == mp) p_sh = true;
+#pragma unroll
+                          for (int e = 0; e < kAccTrace; ++e) tsh |= (tpos[e] == mp) ? (1u << e) : 0u;
+                        });
+        double wp = 0;
+        if (update) wp = value_load(tab, p_pos);          // the table is always current here
+#pragma unroll
+        for (int a = 0; a < NA; ++a) SHW(a, j, g) = w[a];
+        SHW(NA, j, g) = wp;
+        wave_sync();
+        {
+          const int row = (j <= NA) ? j : 0;
+          double sum = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sum += SHW(row, k, g);
+          sh_res[g * 16 + j] = sum / 16;
+        }
+        wave_sync();
+        double q[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) q[a] = has_next ? clampd(sh_res[g * 16 + a], out_min, out_max) : 0.;
+        const double qsa = clampd(sh_res[g * 16 + NA], out_min, out_max);
+
+        // -------- sampler (greedy.cpp:63-86, 144-218)
+        int a_next = 0, mai = 0, man = 1;
+        double best = 0;
+        if (has_next)
+        {
+          findmax<NA>(q, mai, man, best);
+          if (test)
+            a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
+          else
+          {
+            if (time == 0.) eps_decay = fmax(eps_decay * P.decay_rate, P.decay_min);
+            S1 = lcg_next(S1);
+            const double rnd = lcg_double(S1);
+            if (rnd < eps_decay * P.epsilon)
+            {
+              G = lcg_next(G);
+              a_next = (int)(lcg_long(G) % (uint32_t)NA);
+            }
+            else
+              a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
+          }
+        }
+
+        // -------- predictor update (sarsa.cpp:98-124, 167-194 / advantage.cpp:71-110)
+        double delta = 0;
+        if (update)
+        {
+          double target = reward;
+          if (has_next)
+          {
+            if (P.agent == GRLX_AGENT_SARSA)
+              target += P.gamma * pick<double, NA>(q, a_next);
+            else if (P.agent == GRLX_AGENT_EXPECTED_SARSA)
+            {
+              const double de = eps_decay * P.epsilon;
+              double v = 0;
+#pragma unroll
+              for (int kk = 0; kk < NA; ++kk)
+              {
+                double d = (q[kk] == best) ? 1. / man : 0.;
+                if (d == 1) d = 1 - de;
+                d += de / NA;
+                v += q[kk] * d;
+              }
+              target += P.gamma * v;
+            }
+            else
+            {
+              double v = -__builtin_inf();
+#pragma unroll
+              for (int kk = 0; kk < NA; ++kk) v = fmax(v, q[kk]);
+              target += P.gamma * v;
+            }
+          }
+          delta = target - qsa;
+          const double dW = P.alpha * (target - qsa);
+          const double dT = P.alpha * delta;
+          // write(p, target, alpha): every index of p, in tiling order where tilings share the slot
+          if (!p_sh) add_to(p_pos, dW);
+          serial_lanes(p_sh, [&]() { add_to(p_pos, dW); });
+          // update(trace, alpha*delta, e): newest entry first while its weight exceeds 0.001.  The slots this
+          // tiling owns alone are loaded together (one round trip); an entry whose slot occurred in a newer
+          // entry continues from that entry's result instead of its (stale) load, so every slot still
+          // receives its additions one after the other in entry order.  Shared slots: one lane at a time.
+          double cur[kAccTrace], de[kAccTrace];
+          bool mine[kAccTrace];
+          {
+            double weight = 1.;
+#pragma unroll
+            for (int e = 0; e < kAccTrace; ++e)
+            {
+              const bool go = e < tlen && weight > 0.001;
+              de[e] = weight * dT * ee;
+              mine[e] = go && ((tsh >> e) & 1u) == 0u;
+              cur[e] = mine[e] ? value_load(tab, tpos[e]) : 0.;
+              weight *= ee;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < kAccTrace; ++e)
+          {
+            double base = cur[e];
+#pragma unroll
+            for (int k = 0; k < e; ++k) base = (mine[k] && tpos[k] == tpos[e]) ? cur[k] : base;   // the latest newer occurrence wins
+            const double v = base + de[e];
+            cur[e] = limit ? clampd(v, out_min, out_max) : v;
+            if (mine[e]) value_store(tab, tpos[e], cur[e]);
+          }
+          {
+            double weight = 1.;
+#pragma unroll
+            for (int e = 0; e < kAccTrace; ++e)
+            {
+              const bool go = e < tlen && weight > 0.001;
+              const bool shared = ((tsh >> e) & 1u) != 0u;
+              const double d = de[e];
+              const uint32_t at = tpos[e];
+              if (rarely(__any(go && shared)))
+                serial_lanes(go && shared, [&]() { add_to(at, d); });
+              weight *= ee;
+            }
+          }
+          // trace_->add(p, e) (trace.h:245-262)
+          if (ee < cut) { tlen = 0; ttotal = 1.; tsh = 0; }
+          if (tlen >= kAccTrace) status |= ST_TRACE_OVERFLOW;       // cannot happen: validated at create
+#pragma unroll
+          for (int e = kAccTrace - 1; e > 0; --e) tpos[e] = tpos[e - 1];
+          tsh = (tsh << 1) & ((1u << kAccTrace) - 1u);
+          tpos[0] = p_pos;
+          if (p_sh) tsh |= 1u;
+          tlen = (tlen < kAccTrace) ? tlen + 1 : kAccTrace;
+          ttotal *= ee;
+          while (ttotal < cut && tlen > 1)
+          {
+            ttotal /= ee;
+            tlen--;
+          }
+#pragma unroll
+          for (int e = 0; e < kAccTrace; ++e)
+            if (e >= tlen) { tpos[e] = kInvalidPos; tsh &= ~(1u << e); }
+          tr_len_ref = tlen;
+        }
+
+        // -------- tap
+        if (tapped && (!first || P.tap_starts))
+        {
+          uint32_t n = *P.tap_count;
+          if (n < (uint32_t)P.tap_capacity)
+          {
+            grlx_tap *tp = &P.taps[n];
+            tp->p_idx[j] = update ? p_slot : 0u;
+            tp->p_idx[16 + j] = 0u;
+            if (j == 0)
+            {
+              tp->test = test;
+              tp->action_index = has_next ? a_next : action_index;
+              tp->terminal = first ? -1 : terminal;
+              tp->trace_len = tr_len_ref;
+              for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
+              tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
+              tp->reward = reward;
+              for (int i = 0; i < GRLX_MAX_STATE; ++i) tp->state[i] = (i < S) ? x[i] : 0.;
+              tp->delta = delta;
+              for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
+#pragma unroll
+              for (int a = 0; a < NA; ++a) tp->q[a] = has_next ? q[a] : 0.;
+            }
+          }
+          wave_sync();
+          if (j == 0) *P.tap_count = n + 1u;
+        }
+
+        if (!first)
+        {
+          if (test) test_steps++;
+          else ss++;
+        }
+        if (has_next)
+        {
+          action_index = a_next;
+          action = pick<double, NA>(acts, a_next);
+          p_pos = pick<uint32_t, NA>(pos, a_next);
+          p_slot = pick<uint32_t, NA>(slot, a_next);
+          p_sh = pick<bool, NA>(sh, a_next);
+        }
+        if (!first && terminal) running = false;
+        first = false;
+      }
+    }
+
+    if (live && (ti >= 0 ? test : 1))
+    {
+      if (rows < (uint32_t)P.max_rows)
+      {
+        if (j == 0)
+        {
+          size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
+          P.row_reward[at] = total_reward;
+          P.row_time[at] = time;
+          P.row_steps[at] = ss;
+          P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
+        }
+        rows++;
+      }
+      else
+        status |= ST_ROWS_FULL;
+    }
+  }
+
+  uint32_t ins = inserted;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) ins += __shfl_xor(ins, off, 16);
+  if (live && j == 0)
+  {
+#pragma unroll
+    for (int i = 0; i < S; ++i) RS.x[i] = x[i];
+    RS.G = G;
+    RS.TL = TL;
+    RS.S1 = S1;
+    RS.eps_decay = eps_decay;
+    RS.tt = tt;
+    RS.ss = ss;
+    RS.test_steps = test_steps;
+    RS.n_slots[0] += ins;
+    RS.rows = rows;
+  }
+  uint32_t st = status;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+  if (live && j == 0) RS.status = st;
+}
+
+hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
+{
+  if (variant) *variant = GRLX_KERNEL_IN_PLACE;
+  int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (P.env == GRLX_ENV_PENDULUM && P.A == 3)
+    hipLaunchKernelGGL((rollout_acc_kernel<GRLX_ENV_PENDULUM, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+  else if (P.env == GRLX_ENV_ACROBOT && P.A == 3)
+    hipLaunchKernelGGL((rollout_acc_kernel<GRLX_ENV_ACROBOT, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+
+} // namespace grlx
