@@ -36,17 +36,114 @@ BYTES_PER_TEST_STEP = 384                 # A*T 8-byte reads
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
 
-def measured_traffic(n_replicas: int):
-    """HBM-side bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
-    inside this process); only valid for the configuration it was measured on, else None."""
+def measured_pmc(key: str, n_replicas: int, trials_per_launch: int):
+    """What the PMC passes committed under profiles/ measured for this workload (rocprofv3 cannot run inside
+    this process): HBM-side bytes per launch and the issue share of the wave cycles.  Only valid for the
+    configuration it was measured on, else (None, None).  Written by tools/pmc_to_json.py."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)
-        if t.get("replicas") == n_replicas and t.get("trials_per_launch") == TRIALS_PER_STEP:
-            return float(t["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
+            t = json.load(f)["workloads"][key]
+        if t.get("replicas") == n_replicas and t.get("trials_per_launch") == trials_per_launch:
+            return float(t["hbm_bytes_per_launch"]), t.get("issue")
+    except (OSError, ValueError, KeyError, TypeError):
         pass
-    return None
+    return None, None
+
+
+# ---- the other single-GPU configurations of BASELINE.json (configs[2], per-GPU share of configs[3]) ------------
+# Reported under "secondary" of the same JSON line, N = 1 only.  Algorithmic bytes per step: the figure of
+# SURVEY.md 8(d) for the Q agents (3 actions, 16 tilings: 768 B of reads + 16 B x 91.2 read-modify-writes = 2228 B per
+# learning step, 384 B per test step); actor-critic (DESIGN.md 4.1b): 512 B of reads + 16 B x (16 + 16 + 75) = 2224 B
+# per learning step, 128 B per test step.
+SECONDARY = [
+    dict(key="cart_pole_ac", replicas=16384, trials=11, steps=5, warmup=1, bytes_learn=2224, bytes_test=128,
+         workload="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml), 16384 replicas, 11 trials (2200 env-steps) per replica per step",
+         kernel="rollout_ac_kernel<cart_pole, SpecCartPoleAc, deferred update>", want_kernel=2),
+    dict(key="acrobot_q", replicas=8192, trials=22, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
+         workload="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 22 trials per replica per step",
+         kernel="rollout_kernel<acrobot, 3 actions, generic, deferred update>", want_kernel=1),
+    dict(key="compass_walker_q", replicas=8192, trials=11, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
+         workload="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 11 trials per replica per step",
+         kernel="rollout_kernel<compass_walker, 3 actions, generic, deferred update>", want_kernel=1),
+]
+
+
+def secondary_config(key, n):
+    import grl_amd
+    if key == "cart_pole_ac":
+        return grl_amd.cart_pole_ac_config(n)
+    if key == "acrobot_q":
+        return grl_amd.acrobot_q_config(n)
+    if key == "compass_walker_q":
+        return grl_amd.compass_walker_q_config(n)
+    raise KeyError(key)
+
+
+def secondary_cpu_baseline(key, budget_s=4.0):
+    """The oracle on ONE host core on the same experiment graph (libm arithmetic = the reference's own)."""
+    from tests import configs, oracle_binding as ob
+    make = {"cart_pole_ac": configs.cart_pole_ac, "acrobot_q": configs.acrobot, "compass_walker_q": configs.compass_walker}[key]
+    _, spec = make(None, 1)
+    spec.math = ob.MATH_LIBM
+    e = ob.Experiment(spec, seed=1)
+    trials = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        e.run(22)
+        trials += 22
+    dt = time.perf_counter() - t0
+    st = e.stats()
+    steps = int(st.learn_steps + st.test_steps)
+    e.close()
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (C restatement of grl's scalar path, libm arithmetic), 1 replica seed 1, {trials} trials = {steps} env-steps in {dt:.1f} s, weight init excluded"}
+
+
+def run_secondary(w, torch, no_cpu_baseline, replicas=None):
+    """One secondary workload on the current GPU: `warmup` untimed launches, then `steps` timed launches of
+    `trials` trials of every replica (HIP events per launch on the launch stream, wall clock around the lot).
+    Episode lengths vary (absorbing states), so env-steps are counted by the device, not assumed."""
+    import numpy as np
+    import grl_amd
+    n = replicas or w["replicas"]
+    cfg = secondary_config(w["key"], n)
+    cfg.max_rows = (w["steps"] + w["warmup"]) * w["trials"] + 1
+    runner = grl_amd.Runner(cfg, np.arange(1, n + 1))
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+    for _ in range(w["warmup"]):
+        runner.run(w["trials"], sptr)
+    runner.sync(sptr)
+    l0, t0s = runner.step_counts()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(w["steps"])]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(w["steps"]):
+        ev[k][0].record(stream)
+        runner.run(w["trials"], sptr)
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    runner.sync(sptr)                                          # raises on table overflow etc.
+    l1, t1s = runner.step_counts()
+    variant = runner.last_kernel()
+    runner.close()
+    learn, test = l1 - l0, t1s - t0s
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    alg_bytes = (learn * w["bytes_learn"] + test * w["bytes_test"]) / w["steps"]
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    traffic, issue = measured_pmc(w["key"], n, w["trials"])
+    out = {"workload": w["workload"], "value": (learn + test) / elapsed, "unit": "env-steps/s", "steps": w["steps"], "warmup": w["warmup"],
+           "ms_per_step": 1e3 * elapsed / w["steps"], "replicas": n, "trials_per_step": w["trials"],
+           "env_steps_per_step": (learn + test) / w["steps"], "learn_steps": learn, "test_steps": test, "dtype": "f64", "data": "synthetic",
+           "last_kernel": variant, "kernel_is_expected_instantiation": variant == w["want_kernel"],
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "issue": issue, "kernel": w["kernel"], "kernel_ms_avg": avg_ms,
+                        "algorithmic_bytes_per_launch": alg_bytes}}
+    if not no_cpu_baseline:
+        out["cpu_baseline"] = secondary_cpu_baseline(w["key"])
+    return out
 
 
 def cpu_baseline(budget_s: float = 12.0):
@@ -95,6 +192,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations (cart-pole AC, acrobot, walker)")
+    ap.add_argument("--only", default="", help="profiling: run only this secondary workload (cart_pole_ac | acrobot_q | compass_walker_q) and print its entry")
+    ap.add_argument("--secondary-replicas", type=int, default=0, help="tests: override the replica count of the secondary workloads")
     ap.add_argument("--table-log2", type=int, default=17)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
@@ -114,6 +214,12 @@ def main():
     from grl_amd import parallel
 
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if args.only:
+        w = [x for x in SECONDARY if x["key"] == args.only]
+        if not w:
+            raise SystemExit("--only: unknown workload " + args.only)
+        print(json.dumps(run_secondary(w[0], torch, args.no_cpu_baseline, args.secondary_replicas or None)))
+        return
     parallel.init_distributed(args.backend)
 
     n = args.replicas
@@ -169,6 +275,7 @@ def main():
         alg_bytes = n * (LEARN_STEPS_PER_STEP * BYTES_PER_LEARN_STEP + TEST_STEPS_PER_STEP * BYTES_PER_TEST_STEP)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         mean_curve = (curve[:, 0] / curve[:, 2]).cpu().numpy()
+        traffic, issue = measured_pmc("pendulum_sarsa", n, TRIALS_PER_STEP)
         out = {
             "metric": "env-steps/sec (batched rollouts), pendulum SARSA-tc",
             "value": total_env_steps / elapsed,
@@ -187,15 +294,19 @@ def main():
                        "replicas_per_gpu": n, "trials_per_step": TRIALS_PER_STEP, "env_steps_per_step": env_steps_per_step * world,
                        "tilings": 16, "memory": 8388608, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "issue": issue,
                          "kernel": "rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    runner.close()                                             # frees this workload's tables before the next one allocates
+    if rank == 0:
+        if world == 1 and not args.no_secondary:
+            # the other single-GPU configurations BASELINE.json names, each timed the same way on this GPU
+            out["secondary"] = [run_secondary(w, torch, args.no_cpu_baseline, args.secondary_replicas or None) for w in SECONDARY]
         print(json.dumps(out))
-    runner.close()
     if world > 1:
         dist.destroy_process_group()
 

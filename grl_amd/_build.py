@@ -19,8 +19,21 @@ HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
+FLAGS_FILE = LIB + ".flags"      # the flags the library was built with: a change of flags makes it stale
+
+
+def _flags() -> str:
+    return " ".join(FLAGS + os.environ.get("GRLX_EXTRA_FLAGS", "").split())
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
+        return True
+    try:
+        with open(FLAGS_FILE) as f:
+            if f.read().strip() != _flags():
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -42,6 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(FLAGS_FILE, "w") as f:
+        f.write(_flags() + "\n")
     return LIB
 
 

@@ -12,7 +12,7 @@ from . import _build
 MAX_DIMS, MAX_STATE, MAX_ACTIONS = 8, 12, 8
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TABLE_FULL, ERR_DOMAIN, ERR_ROWS_FULL, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7
-ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER = 0, 1, 2, 3
+ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER, ENV_CART_POLE_BALANCING = 0, 1, 2, 3, 4
 AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE, AGENT_QV = 0, 1, 2, 3, 4, 5
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 

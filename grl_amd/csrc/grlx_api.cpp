@@ -69,6 +69,7 @@ int env_dims(int env, int *S, int *D)
     case GRLX_ENV_ACROBOT: *S = 5; *D = 4; return GRLX_OK;
     case GRLX_ENV_CART_POLE: *S = 5; *D = 4; return GRLX_OK;
     case GRLX_ENV_COMPASS_WALKER: *S = 11; *D = 5; return GRLX_OK;
+    case GRLX_ENV_CART_POLE_BALANCING: *S = 5; *D = 4; return GRLX_OK;
     default: return GRLX_ERR_INVALID;
   }
 }
@@ -128,8 +129,27 @@ int make_params(const grlx_config &c, DevParams *P)
   if (ac && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
   if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");
   if (!(c.control_step >= 0.00001)) return fail(GRLX_ERR_INVALID, "model/dynamical:control_step");
-  if (c.integration_steps < 1) return fail(GRLX_ERR_INVALID, "model/dynamical:integration_steps");
+  if (c.integration_steps < 1 || c.integration_steps > 1000) return fail(GRLX_ERR_INVALID, "model/dynamical:integration_steps (1..1000 supported)");
+  // The rollout kernels leave the step loop only when the task reports a terminal state, i.e. (at the
+  // latest) on time > timeout: a non-finite or huge timeout would be a kernel that never ends -- on a
+  // GPU a hang, not a killable loop.  Episodes are capped at GRLX_MAX_EPISODE_STEPS control steps.
+  if (!std::isfinite(c.timeout) || c.timeout < 0) return fail(GRLX_ERR_INVALID, "task:timeout must be finite and >= 0");
+  if (!std::isfinite(c.control_step) || c.control_step > 1e6) return fail(GRLX_ERR_INVALID, "model/dynamical:control_step");
+  {
+    const double horizon = (c.env == GRLX_ENV_COMPASS_WALKER) ? 2 * c.timeout : c.timeout;   // test episodes of the walker: 2 x timeout
+    if (std::ceil(horizon / c.control_step) + 1 > (double)GRLX_MAX_EPISODE_STEPS)
+      return fail(GRLX_ERR_INVALID, "task:timeout / control_step = %.0f steps per episode exceeds GRLX_MAX_EPISODE_STEPS (%d)",
+                  std::ceil(horizon / c.control_step), GRLX_MAX_EPISODE_STEPS);
+  }
   if (!ac && (c.action_steps < 1 || c.action_steps > GRLX_MAX_ACTIONS)) return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps (1..%d supported)", GRLX_MAX_ACTIONS);
+  if (!ac && !qv && c.agent != GRLX_AGENT_ADVANTAGE && c.trace != GRLX_TRACE_ACCUMULATING && c.env != GRLX_ENV_CART_POLE_BALANCING)
+  { // the instantiations of rollout_kernel (launch_rollout): anything else has no kernel to run
+    const bool built = (c.env == GRLX_ENV_PENDULUM && (c.action_steps == 3 || c.action_steps == 5)) ||
+                       ((c.env == GRLX_ENV_ACROBOT || c.env == GRLX_ENV_CART_POLE || c.env == GRLX_ENV_COMPASS_WALKER) && c.action_steps == 3);
+    if (!built)
+      return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps = %d is not built for this environment (pendulum: 3 or 5 actions; "
+                                    "acrobot, cart-pole, compass walker: 3 actions)", c.action_steps);
+  }
   if (ac && c.trace != GRLX_TRACE_REPLACING && c.trace != GRLX_TRACE_NONE) return fail(GRLX_ERR_INVALID, "trace type %d is not supported by the fused path", c.trace);
   if (c.trace == GRLX_TRACE_ACCUMULATING)
   { // its own (uncached, read-modify-write) kernel: SARSA / Q / Expected SARSA on the pendulum and the acrobot
@@ -245,7 +265,12 @@ struct grlx_ctx {
   uint64_t     *scratch = nullptr;        // 8 x u64
   unsigned long long *diag = nullptr;
   uint32_t     *trace_state = nullptr;
-  std::vector<double *> images;           // loaded policy images (grlx_load_weights), freed with the context
+  // loaded policy images (grlx_load_weights): image k serves the replicas r with image_of[table][r] == k;
+  // an image no replica refers to any more is freed at the next load, the rest with the context
+  std::vector<double *> images;
+  std::vector<int>      image_of[2];
+  hipStream_t  run_stream = nullptr;      // stream of the last grlx_run / grlx_curve_stats
+  bool         run_pending = false;       // ... with work possibly still in flight on it
   int          n_tables = 1;
   int64_t      trials_run = 0;
   int          last_kernel = GRLX_KERNEL_NONE;
@@ -260,6 +285,23 @@ struct DevBuf {
   template <typename T> T *as() { return (T *)p; }
 };
 }
+
+// Read-back and fine-grained entry points run on the NULL stream or copy synchronously: wait for the rollouts
+// of the last grlx_run first (its stream may be non-blocking with respect to the NULL stream).
+static int drain(grlx_ctx *ctx)
+{
+  if (ctx->run_pending)
+  {
+    HIP_TRY(hipStreamSynchronize(ctx->run_stream));
+    ctx->run_pending = false;
+  }
+  return GRLX_OK;
+}
+#define DRAIN(ctx)                          \
+  do {                                      \
+    int rc__ = drain(ctx);                  \
+    if (rc__ != GRLX_OK) return rc__;       \
+  } while (0)
 
 extern "C" {
 
@@ -379,6 +421,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   DevParams P;
   int rc = make_params(*cfg, &P);
   if (rc != GRLX_OK) return rc;
+  if (cfg->env == GRLX_ENV_CART_POLE_BALANCING)
+    return fail(GRLX_ERR_INVALID, "task/cart_pole/balancing is served by grlx_env_step only (no fused TD rollout is built for it)");
   if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
 
   grlx_ctx *ctx = new grlx_ctx();
@@ -415,6 +459,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMalloc((void **)&ctx->row_steps, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->row_trial, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMemset(ctx->row_reward, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMemset(ctx->row_steps, 0, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
+  CTX_TRY(hipMemset(ctx->row_trial, 0, sizeof(int64_t) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->row_time, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMemset(ctx->row_time, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
@@ -491,7 +537,8 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->diag);
   (void)hipFree(ctx->trace_state);
-  for (double *img : ctx->images) (void)hipFree(img);
+  for (double *img : ctx->images)
+    if (img) (void)hipFree(img);
   delete ctx;
   return GRLX_OK;
 }
@@ -516,6 +563,7 @@ int grlx_read_diag(grlx_ctx *ctx, uint64_t *out, int cap_waves, int *n_waves)
   if (!ctx->diag) return fail(GRLX_ERR_INVALID, "diagnostics are not enabled");
   int waves = (ctx->P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
   if (waves > cap_waves) waves = cap_waves;
+  DRAIN(ctx);
   HIP_TRY(hipMemcpy(out, ctx->diag, (size_t)waves * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   *n_waves = waves;
   return GRLX_OK;
@@ -528,7 +576,13 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
   // One launch per <= kTrialsPerLaunch trials: replica state (and the actor-critic trace) persists in
   // HBM between launches, so results do not depend on the chunking (tested), and no single kernel
   // runs for minutes (compass walker: up to 1000 steps per episode).
-  const int kTrialsPerLaunch = 32;
+  // A launch also never holds more than ~kStepsPerLaunch control steps of one replica (long episodes: fewer trials).
+  const double kStepsPerLaunch = 65536;
+  const double horizon = (ctx->cfg.env == GRLX_ENV_COMPASS_WALKER ? 2 : 1) * ctx->cfg.timeout / ctx->cfg.control_step + 1;
+  int kTrialsPerLaunch = 32;
+  if (horizon * kTrialsPerLaunch > kStepsPerLaunch) kTrialsPerLaunch = (int)fmax(1., floor(kStepsPerLaunch / horizon));
+  ctx->run_stream = (hipStream_t)stream;
+  ctx->run_pending = true;
   for (int done = 0; done < n_trials; done += kTrialsPerLaunch)
   {
     const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
@@ -549,6 +603,7 @@ static int status_to_error(uint64_t st)
 {
   if (st & ST_TABLE_FULL) return fail(GRLX_ERR_TABLE_FULL, "a replica's sparse weight table overflowed: raise table_log2_capacity");
   if (st & ST_TRACE_OVERFLOW) return fail(GRLX_ERR_INVALID, "register trace overflow");
+  if (st & ST_BAD_POS) return fail(GRLX_ERR_INVALID, "internal error: a TD update was queued without a table position");
   if (st & ST_DOMAIN) return fail(GRLX_ERR_DOMAIN, "sin/cos argument outside |x| < 2^20");
   if (st & ST_ROWS_FULL) return fail(GRLX_ERR_ROWS_FULL, "more test rows than max_rows");
   return GRLX_OK;
@@ -558,9 +613,11 @@ int grlx_sync(grlx_ctx *ctx, void *stream)
 {
   if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
   uint64_t h[3];
+  if ((hipStream_t)stream != ctx->run_stream) DRAIN(ctx);
   HIP_TRY(launch_step_counts(ctx->P, ctx->scratch, (hipStream_t)stream));
   HIP_TRY(hipMemcpyAsync(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if ((hipStream_t)stream == ctx->run_stream) ctx->run_pending = false;
   return status_to_error(h[2]);
 }
 
@@ -568,6 +625,7 @@ int grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps)
 {
   if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
   uint64_t h[3];
+  DRAIN(ctx);
   HIP_TRY(launch_step_counts(ctx->P, ctx->scratch, nullptr));
   HIP_TRY(hipMemcpy(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost));
   if (learn_steps) *learn_steps = h[0];
@@ -579,6 +637,7 @@ int grlx_rows(grlx_ctx *ctx)
 {
   if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
   ReplicaState s;
+  DRAIN(ctx);
   if (hipMemcpy(&s, ctx->states, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) return fail(GRLX_ERR_HIP, "hipMemcpy failed");
   return (int)s.rows;
 }
@@ -589,6 +648,7 @@ int grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count, int64_t *tr
     return fail(GRLX_ERR_INVALID, "bad argument");
   const size_t N = (size_t)ctx->P.n_replicas;
   if (count == 0) return GRLX_OK;
+  DRAIN(ctx);
   // rows are stored [row][replica]: one strided copy per column
   const size_t at = (size_t)first * N + (size_t)replica;
   if (reward) HIP_TRY(hipMemcpy2D(reward, sizeof(double), ctx->row_reward + at, N * sizeof(double), sizeof(double), (size_t)count, hipMemcpyDeviceToHost));
@@ -605,6 +665,7 @@ int grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, double
     return fail(GRLX_ERR_INVALID, "bad argument");
   const size_t N = (size_t)ctx->P.n_replicas;
   if (count == 0) return GRLX_OK;
+  DRAIN(ctx);
   HIP_TRY(hipMemcpy2D(episode_time, sizeof(double), ctx->row_time + (size_t)first * N + (size_t)replica, N * sizeof(double), sizeof(double),
                       (size_t)count, hipMemcpyDeviceToHost));
   return GRLX_OK;
@@ -613,6 +674,7 @@ int grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, double
 int grlx_curve_stats(grlx_ctx *ctx, int first, int count, double *out_dev, void *stream)
 {
   if (!ctx || !out_dev || first < 0 || count < 0 || first + count > ctx->P.max_rows) return fail(GRLX_ERR_INVALID, "bad argument");
+  if ((hipStream_t)stream != ctx->run_stream) DRAIN(ctx);
   HIP_TRY(launch_curve_stats(ctx->P, first, count, out_dev, (hipStream_t)stream));
   return GRLX_OK;
 }
@@ -621,6 +683,7 @@ int grlx_get_env_state(grlx_ctx *ctx, int replica, double *state)
 {
   if (!ctx || !state || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   ReplicaState s;
+  DRAIN(ctx);
   HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
   memcpy(state, s.x, sizeof(double) * GRLX_MAX_STATE);
   return GRLX_OK;
@@ -630,6 +693,7 @@ int grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4])
 {
   if (!ctx || !out || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   ReplicaState s;
+  DRAIN(ctx);
   HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
   out[0] = s.G; out[1] = s.TL; out[2] = s.S1; out[3] = s.S2;
   return GRLX_OK;
@@ -639,6 +703,7 @@ int grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_use
 {
   if (!ctx || !n_slots_used || table < 0 || table >= ctx->n_tables || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   ReplicaState s;
+  DRAIN(ctx);
   HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
   *n_slots_used = s.n_slots[table];
   return GRLX_OK;
@@ -648,6 +713,7 @@ int grlx_read_taps(grlx_ctx *ctx, grlx_tap *out, int cap, int *n)
 {
   if (!ctx || !out || !n) return fail(GRLX_ERR_INVALID, "bad argument");
   uint32_t cnt = 0;
+  DRAIN(ctx);
   HIP_TRY(hipMemcpy(&cnt, ctx->tap_count, sizeof(cnt), hipMemcpyDeviceToHost));
   int m = (int)cnt < cap ? (int)cnt : cap;
   if (m > ctx->P.tap_capacity) m = ctx->P.tap_capacity;
@@ -660,6 +726,7 @@ int grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slot
 {
   if (!ctx || !slots || !out || n < 0 || table < 0 || table >= ctx->n_tables || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n == 0) return GRLX_OK;
+  DRAIN(ctx);
   DevBuf ds, dout;
   HIP_TRY(ds.alloc(sizeof(uint32_t) * (size_t)n));
   HIP_TRY(dout.alloc(sizeof(double) * (size_t)n));
@@ -673,6 +740,7 @@ int grlx_export_weights(grlx_ctx *ctx, int table, int replica, double *out)
 {
   if (!ctx || !out || table < 0 || table >= ctx->n_tables || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
   const size_t memory = (size_t)(table == 1 ? ctx->P.tile_actor.memory : ctx->P.tile.memory);
+  DRAIN(ctx);
   DevBuf dout;
   HIP_TRY(dout.alloc(sizeof(double) * memory));
   HIP_TRY(launch_export_weights(ctx->P, table, replica, dout.as<double>(), nullptr));
@@ -693,9 +761,16 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
     return fail(GRLX_ERR_INVALID, "actor-critic: load before the first run (the critic's trace refers to table positions)");
   if (n_replicas == 0) return GRLX_OK;
   HIP_TRY(hipDeviceSynchronize());
+  ctx->run_pending = false;
   double *img = nullptr;
   if (hipMalloc((void **)&img, sizeof(double) * memory) != hipSuccess) return fail(GRLX_ERR_OOM, "no device memory for a %zu-weight policy image", memory);
   ctx->images.push_back(img);
+  {
+    std::vector<int> &of = ctx->image_of[table];
+    if (of.empty()) of.assign((size_t)N, -1);
+    const int mine = (int)ctx->images.size() - 1;
+    for (int r = first_replica; r < first_replica + n_replicas; ++r) of[(size_t)r] = mine;
+  }
   HIP_TRY(hipMemcpy(img, dense, sizeof(double) * memory, hipMemcpyHostToDevice));
   // setParams() overwrites every weight: forget the sparse tables of these replicas; every slot is
   // re-created on first touch from the image
@@ -704,6 +779,20 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
   HIP_TRY(hipMemset(base, 0, per_replica * (size_t)n_replicas));
   HIP_TRY(launch_set_lazy_base(ctx->P, table, first_replica, n_replicas, img, nullptr));
   HIP_TRY(hipDeviceSynchronize());
+  // an earlier image that no replica of any table refers to any more goes now (repeated loads do not accumulate)
+  for (size_t k = 0; k + 1 < ctx->images.size(); ++k)
+  {
+    if (!ctx->images[k]) continue;
+    bool used = false;
+    for (int t = 0; t < 2 && !used; ++t)
+      for (int v : ctx->image_of[t])
+        if (v == (int)k) { used = true; break; }
+    if (!used)
+    {
+      (void)hipFree(ctx->images[k]);
+      ctx->images[k] = nullptr;
+    }
+  }
   return GRLX_OK;
 }
 
@@ -766,6 +855,7 @@ static int table_op(grlx_ctx *ctx, int table, int op, const int32_t *replica, co
   const uint32_t mem = (uint32_t)(table == 1 ? ctx->P.tile_actor.memory : ctx->P.tile.memory);
   for (size_t i = 0; i < (size_t)n * (size_t)T; ++i)
     if (idx[i] != 0xFFFFFFFFu && idx[i] >= mem) return fail(GRLX_ERR_INVALID, "slot index out of range");
+  DRAIN(ctx);
   DevBuf dr, di, da, dout;
   HIP_TRY(dr.alloc(sizeof(int32_t) * (size_t)n));
   HIP_TRY(di.alloc(sizeof(uint32_t) * (size_t)n * T));

@@ -194,6 +194,36 @@ template <> struct Env<GRLX_ENV_CART_POLE> {
   }
 };
 
+// dynamics/cart_pole (end_stop = 1) + task/cart_pole/balancing (cart_pole.cpp:239-320): the same dynamics under the
+// task of the reference's tests/cart_pole_balancing-pid.yaml, whose golden file pins them (fine-grained
+// grlx_env_step only: the reference drives it with a PID policy, not with a TD agent).
+template <> struct Env<GRLX_ENV_CART_POLE_BALANCING> : Env<GRLX_ENV_CART_POLE> {
+  __device__ static __forceinline__ bool failed(const double *x)
+  { // :317-320
+    return __builtin_fabs(x[0]) > 2.4 || __builtin_fabs(x[1]) > 12*GRLX_PI/180;
+  }
+  __device__ static __forceinline__ void start(const DevParams &, int, uint64_t &TL, uint64_t &, double *x)
+  { // :264-273
+    TL = lcg_next(TL);
+    const double r = lcg_double(TL);
+    x[0] = 0;
+    x[1] = (r * 0.1) - 0.05;
+    x[2] = 0; x[3] = 0; x[4] = 0;
+  }
+  __device__ static __forceinline__ int observe(const DevParams &P, const double *x, double *obs)
+  { // :275-296
+#pragma unroll
+    for (int i = 0; i < 4; ++i) obs[i] = x[i];
+    if (failed(x)) return 2;
+    return x[4] > P.timeout ? 1 : 0;
+  }
+  __device__ static __forceinline__ double evaluate(const DevParams &, const double *x, double, const double *next)
+  { // :298-307: the reward looks at the state BEFORE the step
+    if (failed(next)) return 0.;
+    return 1 - (__builtin_fabs(x[0]) + __builtin_fabs(x[1])) / (2.4 + 12*GRLX_PI/180);
+  }
+};
+
 // model/compass_walker + task/compass_walker/walk: the simplest walking model with its own
 // RK4 (velocities and angles staged separately), angle wrapping and heel-strike events located
 // by a secant search (SWModel.cpp:15-258, SWModel.h:40-59, compass_walker.cpp:63-94, 251-344).

@@ -14,7 +14,8 @@ constexpr uint32_t kInvalidPos = 0xFFFFFFFFu;
 constexpr int kMaxProbe = 2048;
 
 // status bits (sticky, per replica)
-enum : uint32_t { ST_TABLE_FULL = 1u, ST_DOMAIN = 2u, ST_ROWS_FULL = 4u, ST_TRACE_OVERFLOW = 8u };
+enum : uint32_t { ST_TABLE_FULL = 1u, ST_DOMAIN = 2u, ST_ROWS_FULL = 4u, ST_TRACE_OVERFLOW = 8u,
+                  ST_BAD_POS = 16u };     // a TD update was queued for "no position": internal error, never a silent access
 
 // One slot of a replica's sparse weight table.  The reference's table is a
 // dense double[memory] (linear.cpp:86) of which a run touches ~0.2 %; here a

@@ -203,6 +203,10 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
       hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_COMPASS_WALKER>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
                          obs_dev, reward_dev, terminal_dev, err_dev);
       break;
+    case GRLX_ENV_CART_POLE_BALANCING:
+      hipLaunchKernelGGL(env_step_kernel<GRLX_ENV_CART_POLE_BALANCING>, dim3(blocks), dim3(64), 0, stream, P, state_dev, action_dev, n,
+                         obs_dev, reward_dev, terminal_dev, err_dev);
+      break;
     default:
       return hipErrorInvalidValue;
   }
@@ -261,10 +265,12 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
     for (int off = 32; off > 0; off >>= 1) ins += __shfl_xor(ins, off, 64);
     if (lane == 0 && ins) P.states[r].n_slots[table] += ins;
     inserted = 0;
+    // sticky status of the replica this row worked on (not of the first row's)
+    uint32_t st = status;
+    for (int off = 32; off > 0; off >>= 1) st |= __shfl_xor(st, off, 64);
+    if (lane == 0 && st) atomicOr(&P.states[r].status, st);
+    status = 0;
   }
-  uint32_t st = status;
-  for (int off = 32; off > 0; off >>= 1) st |= __shfl_xor(st, off, 64);
-  if (lane == 0 && st && n > 0) atomicOr(&P.states[replica[0]].status, st);
 }
 
 hipError_t launch_table_op(const DevParams &P, int table, int op, const int32_t *replica_dev, const uint32_t *idx_dev, int n,

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
             pd_dW = dW;
             pd_dT = dT;
             pd_pos = p_pos;
+            status |= (p_pos == kInvalidPos) ? ST_BAD_POS : 0u;      // assert: an update always follows an action taken
             pd_sh = p_sh;
             pd_wp = wp;
           }

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
             pd_dW = N.alpha * (target - v_prev);
             pd_dT = N.alpha * delta;
             pd_pos = p_pos;
+            status |= (p_pos == kInvalidPos) ? ST_BAD_POS : 0u;      // assert: an update always follows an action taken
             pd_sh = p_sh;
             pd_wp = wpc;
           }

@@ -60,12 +60,15 @@ __device__ __forceinline__ uint4 bucket_keys(const Table &t, uint32_t b)
   return *reinterpret_cast<const uint4 *>(t.base[b].key);
 }
 
-__device__ __forceinline__ void value_store(const Table &t, uint32_t pos, double v) { t.base[pos >> 2].val[pos & 3u] = v; }
-__device__ __forceinline__ double value_load(const Table &t, uint32_t pos) { return t.base[pos >> 2].val[pos & 3u]; }
+// Positions are masked into the replica's own table: whatever a caller passes (kInvalidPos included -- "nothing
+// held", "no previous step"), an access can never leave the allocation.  A wrong position is then a parity
+// failure (and ST_BAD_POS where the kernels check it), not a memory fault that takes the process down.
+__device__ __forceinline__ void value_store(const Table &t, uint32_t pos, double v) { t.base[(pos >> 2) & t.bmask].val[pos & 3u] = v; }
+__device__ __forceinline__ double value_load(const Table &t, uint32_t pos) { return t.base[(pos >> 2) & t.bmask].val[pos & 3u]; }
 
 __device__ __forceinline__ void entry_create(const Table &t, uint32_t pos, uint32_t slot, uint32_t owner, double v)
 {
-  Bucket *bp = &t.base[pos >> 2];
+  Bucket *bp = &t.base[(pos >> 2) & t.bmask];
   bp->key[pos & 3u] = (slot + 1u) | (owner << kOwnerShift);
   bp->val[pos & 3u] = v;
 }
@@ -294,7 +297,7 @@ __device__ inline void table_probe(const Table &t, const LinearParams &lp, const
   }
   // keep the "touched by a second tiling" bit current (the fused kernel relies on it)
   if (active && lk[0].kw != 0u && ((lk[0].kw >> kOwnerShift) & 31u) != (uint32_t)(threadIdx.x & 31) && !(lk[0].kw & kSharedBit))
-    t.base[lk[0].pos >> 2].key[lk[0].pos & 3u] = lk[0].kw | kSharedBit;
+    t.base[(lk[0].pos >> 2) & t.bmask].key[lk[0].pos & 3u] = lk[0].kw | kSharedBit;
   pos = lk[0].pos;
   val = v[0];
 }

@@ -447,7 +447,7 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
 #pragma unroll
     for (int a = 0; a < NP; ++a)
     {
-      if (fresh[a]) tab.base[pos[a] >> 2].key[pos[a] & 3u] = lk[a].kw | kSharedBit;
+      if (fresh[a]) tab.base[(pos[a] >> 2) & tab.bmask].key[pos[a] & 3u] = lk[a].kw | kSharedBit;
       unsigned long long pend = __ballot(fresh[a]);
       while (pend != 0ull)
       { // one event per 16-lane group at a time

@@ -31,6 +31,37 @@ def cart_pole_ac_config(n_replicas=1, **overrides) -> capi.Config:
     return cfg
 
 
+def _set_tile(ts, tilings, memory, resolution, wrapping):
+    ts.tilings, ts.memory, ts.dims = tilings, memory, len(resolution)
+    for i in range(capi.MAX_DIMS):
+        ts.resolution[i] = resolution[i] if i < len(resolution) else 0.0
+        ts.wrapping[i] = wrapping[i] if i < len(wrapping) else 0.0
+
+
+def acrobot_q_config(n_replicas=1, agent=capi.AGENT_Q, **overrides) -> capi.Config:
+    """dynamics/acrobot + task/acrobot/balancing (acrobot.cpp) under the TD agent block of the reference's
+    cfg/pendulum/q_tc.yaml -- the reference ships no TD yaml for the acrobot: 3 torques
+    over [-1, 1], control step 0.05 s, tile resolution [0.05, 0.05, 0.2, 0.4 | 1.0]."""
+    cfg = pendulum_sarsa_config(n_replicas, agent=agent, **overrides)
+    cfg.env = capi.ENV_ACROBOT
+    cfg.control_step, cfg.integration_steps, cfg.timeout = 0.05, 5, 20.0
+    cfg.action_min, cfg.action_max, cfg.action_steps = -1.0, 1.0, 3
+    _set_tile(cfg.projector, 16, 8388608, [0.05, 0.05, 0.2, 0.4, 1.0], [0] * 5)
+    return cfg
+
+
+def compass_walker_q_config(n_replicas=1, agent=capi.AGENT_Q, **overrides) -> capi.Config:
+    """The reference's cfg/compass_walker/qlearning_walk.yaml: model/compass_walker + task/compass_walker/walk,
+    Q-learning over a 6-input tile coding, 3 hip torques over [-1.2, 1.2], control step 0.2 s (20 sub-steps)."""
+    cfg = pendulum_sarsa_config(n_replicas, agent=agent, **overrides)
+    cfg.env = capi.ENV_COMPASS_WALKER
+    cfg.control_step, cfg.integration_steps, cfg.timeout = 0.2, 20, 100.0
+    cfg.slope_angle, cfg.initial_state_variation, cfg.negative_reward = 0.004, 0.2, -100.0
+    cfg.action_min, cfg.action_max, cfg.action_steps = -1.2, 1.2, 3
+    _set_tile(cfg.projector, 16, 8388608, [0.0838, 0.1047, 0.1111, 0.2222, 10, 1.2], [0] * 6)
+    return cfg
+
+
 def _ptr(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
 

@@ -37,7 +37,9 @@ enum {
 enum { GRLX_ENV_PENDULUM = 0,        /* dynamics/pendulum + task/pendulum/swingup   (pendulum.cpp)       */
        GRLX_ENV_CART_POLE = 1,       /* dynamics/cart_pole + task/cart_pole/swingup (cart_pole.cpp)      */
        GRLX_ENV_ACROBOT = 2,         /* dynamics/acrobot + task/acrobot/balancing   (acrobot.cpp)        */
-       GRLX_ENV_COMPASS_WALKER = 3   /* sandbox/compass_walker (walk task)          (compass_walker.cpp) */ };
+       GRLX_ENV_COMPASS_WALKER = 3,  /* sandbox/compass_walker (walk task)          (compass_walker.cpp) */
+       GRLX_ENV_CART_POLE_BALANCING = 4 /* dynamics/cart_pole + task/cart_pole/balancing (cart_pole.cpp:239-320): the task of the
+                                        reference's tests/cart_pole_balancing-pid.yaml; grlx_env_step only (grlx_create refuses it) */ };
 enum { GRLX_AGENT_SARSA = 0,         /* agent/td + policy/discrete/q + predictor/critic/sarsa (sarsa.cpp)     */
        GRLX_AGENT_Q = 1,             /* ... + predictor/critic/q (advantage.cpp:71-110)                       */
        GRLX_AGENT_AC = 2,            /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */
@@ -50,6 +52,10 @@ enum { GRLX_TRACE_NONE = 0, GRLX_TRACE_REPLACING = 1, GRLX_TRACE_ACCUMULATING = 
 #define GRLX_MAX_DIMS 8
 #define GRLX_MAX_STATE 12
 #define GRLX_MAX_ACTIONS 8
+/* An episode ends on the task's terminal state, at the latest on time > timeout; the fused kernels have no
+ * other exit, so grlx_create refuses a non-finite or negative timeout and more control steps per episode
+ * (timeout / control_step; twice that for the compass walker's test episodes) than this. */
+#define GRLX_MAX_EPISODE_STEPS 100000
 
 /* projector/tile_coding (tile_coding.cpp:34-80): tilings, memory, resolution, wrapping; safe = 0 */
 typedef struct {
@@ -154,6 +160,11 @@ int  grlx_destroy(grlx_ctx *ctx);
 int  grlx_run(grlx_ctx *ctx, int n_trials, void *stream);
 /* Wait for the stream, then report sticky per-replica error flags (table full, ...). */
 int  grlx_sync(grlx_ctx *ctx, void *stream);
+/* Stream contract: grlx_run and grlx_curve_stats are asynchronous on the caller's stream.  Every entry point
+ * that reads a context back to the host or works on its tables (grlx_rows, grlx_read_rows, grlx_read_row_times,
+ * grlx_step_counts, grlx_get_*, grlx_table_load, grlx_export_weights, grlx_load_weights, grlx_read_taps,
+ * grlx_read_diag, grlx_read / _write / _update) first waits for the stream of the context's last grlx_run,
+ * so it never observes rollouts in flight -- also on a hipStreamNonBlocking stream. */
 
 /* Test rows written so far (same for every replica). */
 int  grlx_rows(grlx_ctx *ctx);

@@ -5,7 +5,9 @@
  * Acrobot dynamics + balancing task:         base/src/environments/acrobot.cpp:48-151
  *   (no reference test pins the acrobot: parity unpinned by reference tests)
  * Cart-pole dynamics + swing-up task:        base/src/environments/cart_pole.cpp:58-237
- *   (the reference's cart-pole test yaml is stale: parity unpinned by reference tests)
+ *   (the swing-up TASK is unpinned; the DYNAMICS -- end_stop = 1, incl. the :65 quirk -- and DynamicalModel::step
+ *   are pinned by tests/template/cart_pole_balancing-pid-0.txt through the balancing task below)
+ * Cart-pole balancing task:                  base/src/environments/cart_pole.cpp:239-320
  * Compass walker model + walk task:          base/src/environments/compass_walker/SWModel.cpp:15-258,
  *   base/include/grl/environments/compass_walker/SWModel.h:40-59, compass_walker.cpp:41-95, 198-344
  *   (parity unpinned by reference tests)
@@ -39,6 +41,7 @@ int orc_env_state_dims(int env)
     case ORC_ENV_PENDULUM: return 3;
     case ORC_ENV_ACROBOT: return 5;
     case ORC_ENV_CART_POLE: return 5;
+    case ORC_ENV_CART_POLE_BALANCING: return 5;
     case ORC_ENV_COMPASS_WALKER: return 11;
     default: return -1;
   }
@@ -51,6 +54,7 @@ int orc_env_obs_dims(int env)
     case ORC_ENV_PENDULUM: return 2;
     case ORC_ENV_ACROBOT: return 4;
     case ORC_ENV_CART_POLE: return 4;
+    case ORC_ENV_CART_POLE_BALANCING: return 4;
     case ORC_ENV_COMPASS_WALKER: return 5;
     default: return -1;
   }
@@ -212,6 +216,37 @@ static double cart_pole_evaluate(const orc_spec *s, const double *x, double acti
 { /* :192-201, shaping = 0 */
   (void)x;
   return cart_pole_potential(s, next) - s->action_penalty * orc_m_sqr(s, action / 15) * 2 - s->end_stop_penalty * cart_pole_failed(next) * 10000;
+}
+
+/* ------------------------------------------------- cart-pole balancing -- */
+static int balancing_failed(const double *x)
+{ /* cart_pole.cpp:317-320 */
+  return fabs(x[0]) > 2.4 || fabs(x[1]) > 12*M_PI/180;
+}
+
+static void balancing_start(orc_exp *e, double *x)
+{ /* cart_pole.cpp:264-273: one RandGen draw every episode */
+  x[0] = 0;
+  x[1] = (orc_drand48(&e->TL) * 0.1) - 0.05;
+  x[2] = 0;
+  x[3] = 0;
+  x[4] = 0;
+}
+
+static int balancing_observe(const orc_spec *s, const double *x, double *obs)
+{ /* cart_pole.cpp:275-296 */
+  obs[0] = x[0];
+  obs[1] = x[1];
+  obs[2] = x[2];
+  obs[3] = x[3];
+  if (balancing_failed(x)) return 2;
+  return x[4] > s->timeout ? 1 : 0;
+}
+
+static double balancing_evaluate(const double *x, const double *next)
+{ /* cart_pole.cpp:298-307: the reward is taken at the state BEFORE the step */
+  if (balancing_failed(next)) return 0;
+  return 1 - (fabs(x[0]) + fabs(x[1])) / (2.4 + 12*M_PI/180);
 }
 
 /* -------------------------------------------------------- compass walker -- */
@@ -440,6 +475,7 @@ static void env_eom(const orc_spec *s, const double *x, double u, double *xd)
     case ORC_ENV_PENDULUM: pendulum_eom(s, x, u, xd); break;
     case ORC_ENV_ACROBOT: acrobot_eom(s, x, u, xd); break;
     case ORC_ENV_CART_POLE: cart_pole_eom(s, x, u, xd); break;
+    case ORC_ENV_CART_POLE_BALANCING: cart_pole_eom(s, x, u, xd); break;     /* the same dynamics/cart_pole, end_stop = 1 */
   }
 }
 
@@ -459,6 +495,7 @@ void orc_env_start(const orc_spec *s, orc_exp *e, int test, double *x)
     case ORC_ENV_PENDULUM: pendulum_start(s, e, test, x); break;
     case ORC_ENV_ACROBOT: acrobot_start(e, x); break;
     case ORC_ENV_CART_POLE: cart_pole_start(s, e, x); break;
+    case ORC_ENV_CART_POLE_BALANCING: balancing_start(e, x); break;
     case ORC_ENV_COMPASS_WALKER: walker_start(s, e, test, x); break;
   }
 }
@@ -470,6 +507,7 @@ int orc_env_observe(const orc_spec *s, const double *x, double *obs)
     case ORC_ENV_PENDULUM: return pendulum_observe(s, x, obs);
     case ORC_ENV_ACROBOT: return acrobot_observe(x, obs);
     case ORC_ENV_CART_POLE: return cart_pole_observe(s, x, obs);
+    case ORC_ENV_CART_POLE_BALANCING: return balancing_observe(s, x, obs);
     case ORC_ENV_COMPASS_WALKER: return walker_observe(x, obs);
   }
   return 0;
@@ -520,6 +558,7 @@ double orc_env_step(const orc_spec *s, double *state, double action,
     case ORC_ENV_PENDULUM: *reward = pendulum_evaluate(s, state, action, next); break;
     case ORC_ENV_ACROBOT: *reward = !acrobot_failed(next); break;        /* acrobot.cpp:127-133 */
     case ORC_ENV_CART_POLE: *reward = cart_pole_evaluate(s, state, action, next); break;
+    case ORC_ENV_CART_POLE_BALANCING: *reward = balancing_evaluate(state, next); break;
     case ORC_ENV_COMPASS_WALKER: *reward = walker_evaluate(s, next); break;
     default: *reward = 0;
   }

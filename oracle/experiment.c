@@ -48,6 +48,26 @@ void orc_spec_pendulum_sarsa(orc_spec *s)
   s->math = ORC_MATH_LIBM;
 }
 
+void orc_spec_cart_pole_balancing_pid(orc_spec *s)
+{ /* values of the reference's tests/cart_pole_balancing-pid.yaml: dynamics/cart_pole (end_stop = 1, the class
+   * default, cart_pole.h:52) under model/dynamical {control_step 0.05, integration_steps 5},
+   * task/cart_pole/balancing {timeout 9.99}, agent/fixed with policy/parameterized/pid
+   * {setpoint [0,0,0,0], p [-10,-50,-6,-10]} as both the agent and the test agent; test_interval 0. */
+  memset(s, 0, sizeof(*s));
+  s->test_interval = 0;
+  s->env = ORC_ENV_CART_POLE_BALANCING;
+  s->control_step = 0.05;
+  s->integration_steps = 5;
+  s->timeout = 9.99;
+  s->action_min = -15;           /* task/cart_pole/balancing action_min/max, cart_pole.cpp:255-256 */
+  s->action_max = 15;
+  s->action_steps = 1;
+  s->agent = ORC_AGENT_PID;
+  s->pid_p[0] = -10; s->pid_p[1] = -50; s->pid_p[2] = -6; s->pid_p[3] = -10;
+  s->ac_step_limit = -1;
+  s->math = ORC_MATH_LIBM;
+}
+
 /* ------------------------------------------------------- representation -- */
 static double lin_read(orc_exp *e, int table, const orc_linear_spec *ls, const orc_proj *p)
 { /* linear.cpp:136-184, IndexProjection with empty weights */
@@ -466,6 +486,23 @@ typedef struct { double value; int index; double q[ORC_MAX_ACTIONS]; } act_t;
 
 static void policy_act(orc_exp *e, int test, double time, const double *obs, act_t *out)
 { /* q.cpp:143-155 (QPolicy::act with time) */
+  if (e->spec.agent == ORC_AGENT_PID)
+  { /* PIDPolicy::act(time, in, out), pid.cpp:136-179, with `p` gains only (i, d, il empty), one output:
+     * u = sum_ii p[P(ii, 0)] * (setpoint[ii] - in[ii]) accumulated in index order from 0, then clamped to
+     * the task's action range (pid.cpp:175); P(i, o) = o*N + i (pid.cpp:30) */
+    const int D = orc_env_obs_dims(e->spec.env);
+    double u = 0;
+    (void)time;
+    for (int ii = 0; ii < D; ++ii)
+    {
+      double err = e->spec.pid_setpoint[ii] - obs[ii];
+      u += e->spec.pid_p[ii] * err;
+    }
+    out->index = 0;
+    out->value = fmin(e->spec.action_max, fmax(u, e->spec.action_min));
+    out->q[0] = out->value;
+    return;
+  }
   if (e->spec.agent == ORC_AGENT_AC)
   {
     out->index = 0;
@@ -495,7 +532,22 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
 {
   if (orc_env_state_dims(spec->env) < 0) return NULL;             /* environments not restated yet */
   if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q && spec->agent != ORC_AGENT_AC && spec->agent != ORC_AGENT_EXPECTED_SARSA &&
-      spec->agent != ORC_AGENT_ADVANTAGE && spec->agent != ORC_AGENT_QV) return NULL;
+      spec->agent != ORC_AGENT_ADVANTAGE && spec->agent != ORC_AGENT_QV && spec->agent != ORC_AGENT_PID) return NULL;
+  if (spec->agent == ORC_AGENT_PID)
+  { /* tests/cart_pole_balancing-pid.yaml: no representation, no sampler.  Nothing consumes a random number at
+     * instantiation; the first RandGen::get() (the task's start, cart_pole.cpp:269) creates the thread-local
+     * Rand, seeded by the first global lrand48() (utils.h:90-93, 160-171). */
+    orc_exp *e = (orc_exp *)calloc(1, sizeof(*e));
+    if (!e) return NULL;
+    e->spec = *spec;
+    orc_srand48(&e->G, seed);
+    orc_srand48(&e->TL, (long)orc_lrand48(&e->G));
+    e->A = 1;
+    e->ac_decay = 1;
+    e->eps_decay = 1;
+    trace_clear(&e->trace);
+    return e;
+  }
   if (spec->agent == ORC_AGENT_QV && (spec->actor_projector.dims != orc_env_obs_dims(spec->env) || spec->actor_projector.tilings > ORC_MAX_TILINGS)) return NULL;
   if (spec->agent == ORC_AGENT_ADVANTAGE && !(spec->kappa > 0)) return NULL;
   if (spec->agent == ORC_AGENT_AC)
@@ -594,6 +646,11 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
       e->test_time = 0.;
       policy_act(e, 1, e->test_time, obs, &act);
     }
+    else if (s->agent == ORC_AGENT_PID)
+    { /* the learning agent is an agent/fixed too (`test_agent: ../agent`): fixed.cpp:47-51 */
+      e->time = 0;
+      policy_act(e, 0, e->time, obs, &act);
+    }
     else
     { /* td.cpp:50-61 */
       if (s->agent != ORC_AGENT_AC)                            /* predictor_->finalize(), sarsa.cpp:126-132;          */
@@ -638,6 +695,16 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
           policy_act(e, 1, e->test_time, obs, &act);
         }
         e->stats.test_steps++;
+      }
+      else if (s->agent == ORC_AGENT_PID)
+      { /* fixed.cpp:53-61 as the learning agent; learning steps are still counted (online_learning.cpp:219) */
+        if (terminal != 2)
+        {
+          e->time += tau;
+          policy_act(e, 0, e->time, obs, &act);
+        }
+        e->ss++;
+        e->stats.learn_steps++;
       }
       else
       {

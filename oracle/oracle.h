@@ -63,8 +63,10 @@ double orc_plog(double x);
 enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };
 
 /* ---------------------------------------------------------------- spec -- */
-enum { ORC_ENV_PENDULUM = 0, ORC_ENV_CART_POLE = 1, ORC_ENV_ACROBOT = 2, ORC_ENV_COMPASS_WALKER = 3 };
-enum { ORC_AGENT_SARSA = 0, ORC_AGENT_Q = 1, ORC_AGENT_AC = 2, ORC_AGENT_EXPECTED_SARSA = 3, ORC_AGENT_ADVANTAGE = 4, ORC_AGENT_QV = 5 };
+enum { ORC_ENV_PENDULUM = 0, ORC_ENV_CART_POLE = 1, ORC_ENV_ACROBOT = 2, ORC_ENV_COMPASS_WALKER = 3,
+       ORC_ENV_CART_POLE_BALANCING = 4 };   /* dynamics/cart_pole + task/cart_pole/balancing (cart_pole.cpp:239-320) */
+enum { ORC_AGENT_SARSA = 0, ORC_AGENT_Q = 1, ORC_AGENT_AC = 2, ORC_AGENT_EXPECTED_SARSA = 3, ORC_AGENT_ADVANTAGE = 4, ORC_AGENT_QV = 5,
+       ORC_AGENT_PID = 6 };                 /* agent/fixed + policy/parameterized/pid, proportional gains (pid.cpp:136-179) */
 enum { ORC_TRACE_NONE = 0, ORC_TRACE_REPLACING = 1, ORC_TRACE_ACCUMULATING = 2 };
 enum { ORC_AC_PROPORTIONAL = 0, ORC_AC_CACLA = 1 };
 
@@ -126,10 +128,15 @@ typedef struct {
   double kappa;                       /* advantage scaling factor (advantage.cpp:188, cfg: 0.2)  */
   /* predictor/critic/qv: Q = projector/representation (table 0), V = actor_projector/actor_representation (table 1) */
   double beta;                        /* state value learning rate (qv.cpp:40, cfg: 0.1)         */
+  /* policy/parameterized/pid (ORC_AGENT_PID): `p` gains and `setpoint`, one per observation dimension, one output */
+  double pid_p[ORC_MAX_DIMS];
+  double pid_setpoint[ORC_MAX_DIMS];
 } orc_spec;
 
 /* fill with the values of the reference's tests/pendulum-sarsa-tc.yaml */
 void orc_spec_pendulum_sarsa(orc_spec *s);
+/* fill with the values of the reference's tests/cart_pole_balancing-pid.yaml (its second golden file on this path) */
+void orc_spec_cart_pole_balancing_pid(orc_spec *s);
 
 /* --------------------------------------------------- fine-grained rows -- */
 /* a7: TileCodingProjector::_project. in[dims] -> out[tilings]; returns 0, or

@@ -31,7 +31,8 @@ def _set_tile(ts, tilings, memory, resolution, wrapping):
 
 
 def pendulum(grlx, n, agent=0, **over):
-    cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over)
+    """grlx = None: the oracle half only (bench.py's cpu_baseline leg)."""
+    cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over) if grlx is not None else None
     spec = _spec(agent=agent)
     return cfg, spec
 
@@ -41,11 +42,7 @@ def acrobot(grlx, n, agent=1, **over):
     (the reference ships no TD yaml for the acrobot)."""
     res = [0.05, 0.05, 0.2, 0.4, 1.0]
     wrap = [0, 0, 0, 0, 0]
-    cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over)
-    cfg.env = grlx.capi.ENV_ACROBOT
-    cfg.control_step, cfg.integration_steps, cfg.timeout = 0.05, 5, 20.0
-    cfg.action_min, cfg.action_max, cfg.action_steps = -1.0, 1.0, 3
-    _set_tile(cfg.projector, 16, 8388608, res, wrap)
+    cfg = grlx.acrobot_q_config(n, agent=agent, **over) if grlx is not None else None
     spec = _spec(agent=agent)
     spec.env = 2
     spec.control_step, spec.integration_steps, spec.timeout = 0.05, 5, 20.0
@@ -57,11 +54,11 @@ def acrobot(grlx, n, agent=1, **over):
 def cart_pole_ac(grlx, n, **over):
     """cfg/cart_pole/ac_tc.yaml: dynamics/cart_pole + task/cart_pole/swingup, mapping/policy/action,
     predictor/ac/action with a predictor/critic/td critic; two 8,388,608-slot tables."""
-    cfg = grlx.cart_pole_ac_config(n, **over)
+    cfg = grlx.cart_pole_ac_config(n, **over) if grlx is not None else None
     spec = _spec()
     spec.env, spec.agent = 1, ob.AGENT_AC
     spec.control_step, spec.integration_steps, spec.timeout, spec.randomization = 0.05, 5, 9.99, 0.0
-    spec.end_stop_penalty, spec.action_penalty = cfg.end_stop_penalty, cfg.action_penalty
+    spec.end_stop_penalty, spec.action_penalty = (cfg.end_stop_penalty, cfg.action_penalty) if cfg is not None else (0, 0)
     spec.action_min, spec.action_max, spec.action_steps = -15.0, 15.0, 0
     res, wrap = [2.5, 0.157075, 2.5, 1.57075], [0, 6.283, 0, 0]
     for ts in (spec.projector, spec.actor_projector):
@@ -83,12 +80,7 @@ def compass_walker(grlx, n, agent=1, **over):
     """cfg/compass_walker/qlearning_walk.yaml: model/compass_walker + task/compass_walker/walk, Q-learning."""
     res = [0.0838, 0.1047, 0.1111, 0.2222, 10, 1.2]
     wrap = [0] * 6
-    cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over)
-    cfg.env = grlx.capi.ENV_COMPASS_WALKER
-    cfg.control_step, cfg.integration_steps, cfg.timeout = 0.2, 20, 100.0
-    cfg.slope_angle, cfg.initial_state_variation, cfg.negative_reward = 0.004, 0.2, -100.0
-    cfg.action_min, cfg.action_max, cfg.action_steps = -1.2, 1.2, 3
-    _set_tile(cfg.projector, 16, 8388608, res, wrap)
+    cfg = grlx.compass_walker_q_config(n, agent=agent, **over) if grlx is not None else None
     spec = _spec(agent=agent)
     spec.env = 3
     spec.control_step, spec.integration_steps, spec.timeout = 0.2, 20, 100.0

@@ -30,6 +30,16 @@ def grlx():
     return grl_amd
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a box without an MI355X skips the gpu-marked tests instead of failing them."""
+    if not any("gpu" in it.keywords for it in items) or gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no MI355X (HIP device) on this box")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 def gpu_available() -> bool:
     try:
         from grl_amd import _build, capi

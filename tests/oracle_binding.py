@@ -15,8 +15,8 @@ LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
 MAX_DIMS, MAX_STATE = 8, 12
 MATH_LIBM, MATH_PORTABLE = 0, 1
-ENV_PENDULUM = 0
-AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE, AGENT_QV = 0, 1, 2, 3, 4, 5
+ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER, ENV_CART_POLE_BALANCING = 0, 1, 2, 3, 4
+AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE, AGENT_QV, AGENT_PID = 0, 1, 2, 3, 4, 5, 6
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
 
@@ -42,7 +42,8 @@ class Spec(C.Structure):
                 ("actor_projector", TileSpec), ("actor_representation", LinearSpec),
                 ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double),
-                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int), ("kappa", C.c_double), ("beta", C.c_double)]
+                ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int), ("kappa", C.c_double), ("beta", C.c_double),
+                ("pid_p", C.c_double * MAX_DIMS), ("pid_setpoint", C.c_double * MAX_DIMS)]
 
 
 class Row(C.Structure):
@@ -87,6 +88,7 @@ def load():
     for f in ("orc_psin", "orc_pcos", "orc_plog"):
         getattr(L, f).argtypes = [C.c_double]; getattr(L, f).restype = C.c_double
     L.orc_spec_pendulum_sarsa.argtypes = [P(Spec)]
+    L.orc_spec_cart_pole_balancing_pid.argtypes = [P(Spec)]
     L.orc_tile_project.argtypes = [P(TileSpec), P(C.c_double), P(C.c_uint32)]; L.orc_tile_project.restype = C.c_int
     L.orc_env_step.argtypes = [P(Spec), P(C.c_double), C.c_double, P(C.c_double), P(C.c_double), P(C.c_int)]
     L.orc_env_step.restype = C.c_double
@@ -109,6 +111,16 @@ def load():
 def pendulum_sarsa_spec(math=MATH_PORTABLE, **over) -> Spec:
     s = Spec()
     load().orc_spec_pendulum_sarsa(C.byref(s))
+    s.math = math
+    for k, v in over.items():
+        setattr(s, k, v)
+    return s
+
+
+def cart_pole_balancing_pid_spec(math=MATH_PORTABLE, **over) -> Spec:
+    """The reference's tests/cart_pole_balancing-pid.yaml (golden: tests/golden/cart_pole_balancing-pid-0.txt)."""
+    s = Spec()
+    load().orc_spec_cart_pole_balancing_pid(C.byref(s))
     s.math = math
     for k, v in over.items():
         setattr(s, k, v)

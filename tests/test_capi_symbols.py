@@ -59,3 +59,28 @@ def test_no_cpu_fallback(grlx):
     with pytest.raises(capi.GrlxError) as ei:
         grlx.runner.device_math(0, [1.0])
     assert ei.value.code == capi.ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("over,word", [(dict(timeout=float("nan")), "timeout"), (dict(timeout=float("inf")), "timeout"),
+                                       (dict(timeout=-1.0), "timeout"), (dict(timeout=1e9), "GRLX_MAX_EPISODE_STEPS"),
+                                       (dict(timeout=3100.0), "GRLX_MAX_EPISODE_STEPS"), (dict(action_steps=4), "not built"),
+                                       (dict(action_steps=7), "not built")])
+def test_unbounded_episodes_and_unbuilt_combinations_are_refused(grlx, over, word):
+    """The fused kernels leave an episode only on the task's terminal state: a timeout that never comes would be a
+    GPU hang, and an (environment, actions) pair without an instantiation a launch failure -- both are GRLX_ERR_INVALID
+    at create, before any device work."""
+    capi = grlx.capi
+    cfg = grlx.pendulum_sarsa_config(1, **over)
+    with pytest.raises(capi.GrlxError) as ei:
+        grlx.Runner(cfg, [1])
+    assert ei.value.code == capi.ERR_INVALID and word in str(ei.value), str(ei.value)
+
+
+def test_longest_supported_episode_is_accepted_up_to_the_device_check(grlx):
+    capi = grlx.capi
+    cfg = grlx.pendulum_sarsa_config(1, timeout=2999.0)        # 99,968 steps of 0.03 s: inside the cap
+    try:
+        r = grlx.Runner(cfg, [1])
+        r.close()
+    except capi.GrlxError as ex:
+        assert ex.code == capi.ERR_NO_DEVICE

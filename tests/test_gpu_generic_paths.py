@@ -1,0 +1,143 @@
+"""Generic-kernel parameters of the fused path that the headline configuration never varies, each against the
+oracle (rows, RNG positions, environment state, weights): `test_interval` (incl. the "row every trial" branch
+of online_learning.cpp:160,238), `randomization` (pendulum.cpp:97-103), epsilon decay (greedy.cpp:144-149),
+finite output limits on a Q table (linear.cpp:150-153, 207-215) -- and the regression test of the round-1
+device fault (passes of the deferred-update kernel that evict nothing)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN_PID = os.path.join(os.path.dirname(__file__), "golden", "cart_pole_balancing-pid-0.txt")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shapes {a.shape} vs {b.shape}"
+    bad = np.nonzero(bits(a) != bits(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}: {a.flat[bad[0]]!r} vs {b.flat[bad[0]]!r}"
+
+
+def _apply(obj, over):
+    for k, v in over.items():
+        if k.startswith("representation."):
+            setattr(obj.representation, k.split(".", 1)[1], v)
+        else:
+            setattr(obj, k, v)
+
+
+def _run_both(grlx, seeds, trials, over, agent=0, chunks=None, force_generic=0):
+    """The production (deferred-update) kernel of `grlx` against one scalar oracle run per seed."""
+    cfg = grlx.pendulum_sarsa_config(len(seeds), agent=agent, max_rows=trials + 1, force_generic=force_generic)
+    _apply(cfg, over)
+    r = grlx.Runner(cfg, seeds)
+    for c in (chunks or [trials]):
+        r.run(c)
+    r.sync()                                                   # raises on any sticky status bit (ST_BAD_POS included)
+    assert r.last_kernel() in (1, 2)                           # never the diagnostic in-place instantiation
+    rng = np.random.default_rng(11)
+    for k, seed in enumerate(seeds):
+        spec = ob.pendulum_sarsa_spec(agent=agent)
+        _apply(spec, over)
+        e = ob.Experiment(spec, seed=int(seed))
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert len(rows) == r.n_rows()
+        assert list(t) == [x.trial for x in rows], f"trial column of seed {seed}"
+        assert list(s) == [x.steps for x in rows], f"steps column of seed {seed}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        assert_bit_equal(r.row_times(k), [x.time for x in rows], f"episode times of seed {seed}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3], f"RNG positions of seed {seed}"
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of seed {seed}")
+        slots = rng.integers(0, cfg.projector.memory, 2000).astype(np.uint32)
+        assert_bit_equal(r.weights(k, slots), e.weights(slots), f"weights of seed {seed}")
+        e.close()
+    learn, test = r.step_counts()
+    r.close()
+    return learn, test
+
+
+@pytest.mark.parametrize("agent", [0, 1])
+def test_passes_without_eviction_on_a_ragged_batch(grlx, agent):
+    """Round-1 device fault (gpurun_out/abort.log of that round): the first launch of the deferred-update kernel
+    aborted at the stream sync.  On passes where the update evicts nothing the held eviction is "no position"
+    (kInvalidPos); stored unguarded that is an address 64 GiB past the replica's table.  Here NO pass ever
+    evicts (7-step episodes: the trace is cleared before it fills), the batch is ragged (7 replicas: one dead
+    16-lane group whose lanes hold no position at all), and every table access is masked into the replica's
+    table, so this must simply equal the oracle."""
+    learn, test = _run_both(grlx, [5, 6, 7, 8, 9, 10, 11], 44, dict(timeout=0.2), agent=agent, chunks=[20, 24])
+    assert learn == 7 * 40 * 7 and test == 7 * 4 * 7
+
+
+@pytest.mark.parametrize("over,trials", [
+    (dict(test_interval=-1), 24),                               # no test trials: a row for EVERY (learning) trial
+    (dict(test_interval=0), 12),                                # every trial is a test trial: nothing is ever learned
+    (dict(test_interval=3), 30),
+    (dict(randomization=1.0), 33),                              # start angle drawn from the thread-local stream
+    (dict(decay_rate=0.99, decay_min=0.1), 33),                 # epsilon decays at every episode start
+    (dict(decay_rate=0.5, decay_min=0.3, epsilon=0.4), 22),     # ... down to decay_min
+    ({"representation.output_min": -60.0, "representation.output_max": 0.5}, 33),   # finite limits: clamped reads AND clamped weights
+    ({"representation.output_min": -60.0, "representation.output_max": 0.5, "representation.limit": 0}, 33),   # limit = 0: reads only
+    (dict(test_interval=-1, randomization=1.0, decay_rate=0.9, decay_min=0.05), 24),
+])
+def test_generic_parameters_against_the_oracle(grlx, over, trials):
+    seeds = [21, 22, 23, 24, 25]
+    learn, test = _run_both(grlx, seeds, trials, over, chunks=[trials // 2, trials - trials // 2])
+    ti = over.get("test_interval", 10)
+    n_test = 0 if ti < 0 else sum(1 for tt in range(trials) if tt % (ti + 1) == ti)
+    assert test == len(seeds) * n_test * 100 and learn == len(seeds) * (trials - n_test) * 100
+
+
+def test_q_learning_with_limits_and_decay_on_five_actions(grlx):
+    """The other instantiation of the pendulum kernel (5 actions), Q-learning, all the knobs at once."""
+    over = dict(action_steps=5, test_interval=4, decay_rate=0.97, decay_min=0.2, randomization=1.0)
+    over["representation.output_min"] = -500.0
+    over["representation.output_max"] = 10.0
+    _run_both(grlx, [31, 32, 33], 25, over, agent=1, chunks=[10, 15])
+
+
+def test_cart_pole_dynamics_along_the_reference_golden_trajectory(grlx):
+    """The trajectory that prints the reference's tests/template/cart_pole_balancing-pid-0.txt (oracle, portable
+    arithmetic; tests/test_oracle_golden.py pins it byte for byte): every one of its 2000 transitions through
+    grlx_env_step must give the oracle's next state bit for bit -- with the balancing task also its observation,
+    reward and terminal flag; with the swing-up task of cfg/cart_pole/ac_tc.yaml (the task of BASELINE config 3)
+    the same next state, since both tasks sit on the same dynamics/cart_pole + DynamicalModel::step."""
+    from tests import configs
+    spec = ob.cart_pole_balancing_pid_spec(math=ob.MATH_PORTABLE, tap_starts=1)
+    e = ob.Experiment(spec, seed=1)
+    rows, taps = e.run(10, tap_cap=3000)
+    with open(GOLDEN_PID) as f:
+        assert e.format_rows(rows) == f.read()
+    assert len(taps) == 10 * 201
+    prev_state, prev_action, want = [], [], []
+    for a, b in zip(taps[:-1], taps[1:]):
+        if b.terminal == -1:
+            continue                                            # b starts a new trial: no transition a -> b
+        prev_state.append(list(a.state[:5])); prev_action.append(a.action); want.append(b)
+    assert len(want) == 2000
+    cfg = grlx.pendulum_sarsa_config(1)
+    cfg.env = grlx.capi.ENV_CART_POLE_BALANCING
+    cfg.control_step, cfg.integration_steps, cfg.timeout = 0.05, 5, 9.99
+    cfg.action_min, cfg.action_max = -15.0, 15.0
+    cfg.projector.dims = 5
+    for i in range(5):
+        cfg.projector.resolution[i], cfg.projector.wrapping[i] = 1.0, 0.0
+    st, obs, rew, term = grlx.runner.env_step(cfg, prev_state, prev_action)
+    assert_bit_equal(st, [list(t.state[:5]) for t in want], "next state (balancing task)")
+    assert_bit_equal(obs, [list(t.obs[:4]) for t in want], "observation")
+    assert_bit_equal(rew, [t.reward for t in want], "reward")
+    assert list(term) == [t.terminal for t in want] and list(term).count(1) == 10
+    cfg2, _ = configs.cart_pole_ac(grlx, 1)
+    st2, _, _, _ = grlx.runner.env_step(cfg2, prev_state, prev_action)
+    assert_bit_equal(st2, st, "next state (swing-up task, same dynamics)")
+    with pytest.raises(grlx.capi.GrlxError) as ei:              # no fused TD rollout exists for this task
+        grlx.Runner(cfg, [1])
+    assert ei.value.code == grlx.capi.ERR_INVALID

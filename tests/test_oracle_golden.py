@@ -87,3 +87,38 @@ def test_q_learning_runs(oracle):
     rows, _ = e.run(110)
     assert len(rows) == 10
     assert all(np.isfinite(r.reward) and r.reward < 0 for r in rows)
+
+
+GOLDEN_PID = os.path.join(os.path.dirname(__file__), "golden", "cart_pole_balancing-pid-0.txt")
+
+
+@pytest.mark.parametrize("math", [ob.MATH_LIBM, ob.MATH_PORTABLE])
+def test_cart_pole_balancing_pid_golden_byte_exact(oracle, math):
+    """`grld -s 1 tests/cart_pole_balancing-pid.yaml` (bin/runtests.py:21) -> tests/template/cart_pole_balancing-pid-0.txt:
+    the reference's second golden file on this path.  It pins dynamics/cart_pole with end_stop = 1 under
+    DynamicalModel::step (5 RK4 sub-steps of 0.01 s), the thread-local start draw of the task (cart_pole.cpp:264-273,
+    the first RandGen::get() of the process), the balancing reward and the 200-step timeout."""
+    e = ob.Experiment(ob.cart_pole_balancing_pid_spec(math=math), seed=1)
+    rows, _ = e.run(10)
+    assert len(rows) == 10 and all(r.time == 200 for r in rows)
+    with open(GOLDEN_PID) as f:
+        assert e.format_rows(rows) == f.read()
+
+
+def test_cart_pole_pin_resolution(oracle):
+    """What the 6-digit golden does and does not resolve: returns move by > 5e-4 (one unit of the
+    last printed digit) for a 2 % change of the pole mass -- so the dynamics' constants and the integrator are pinned
+    -- while the centrifugal term pole_mass_length * dtheta^2 * sin(theta), the one the cart_pole.cpp:65 quirk touches
+    (dtheta = state[1], the ANGLE), stays below 1e-6 of the acceleration along the whole golden trajectory: the golden
+    cannot tell theta^2 from thetad^2 there.  The quirk is therefore reproduced from the source text, not pinned."""
+    spec = ob.cart_pole_balancing_pid_spec(math=ob.MATH_LIBM, tap_starts=1)
+    e = ob.Experiment(spec, seed=1)
+    _, taps = e.run(10, tap_cap=3000)
+    st = np.array([list(t.state[:5]) for t in taps])
+    assert st.shape[0] == 10 * 201
+    theta, thetad = st[:, 1], st[:, 3]
+    # size of the term under either reading, relative to gravity's g*sin(theta) on the same states
+    quirk = 0.05 * theta ** 2 * np.abs(np.sin(theta))
+    plain = 0.05 * thetad ** 2 * np.abs(np.sin(theta))
+    grav = 9.8 * np.abs(np.sin(theta)) + 1e-300
+    assert (quirk / grav).max() < 2e-5 and (plain / grav).max() < 2e-3

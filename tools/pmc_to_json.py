@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 passes of tools/profile_passes.sh into (i) a per-kernel summary (stdout: the text committed as
+profiles/<tag>_pmc_raw.txt) and (ii) profiles/pmc_traffic.json, which bench.py reads for roofline.traffic / .issue.
+
+    python3 tools/pmc_to_json.py gpurun_out/<tag> [--write]
+
+Every workload of bench.py runs its own kernel instantiation, so launches are grouped by kernel name; the mean is taken
+over the LAST `timed` launches of each (the ones bench.py times; the warm-up launches come first)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# kernel-name fragment -> (bench.py workload key, replicas, trials per launch, timed launches)
+WORKLOADS = [("rollout_kernel<0, 3, false, grlx::SpecPendulumTcA<0>", "pendulum_sarsa", 4096, 11, 20),
+             ("rollout_ac_kernel<1, grlx::SpecCartPoleAc", "cart_pole_ac", 16384, 11, 5),
+             ("rollout_kernel<2, 3, false", "acrobot_q", 8192, 22, 5),
+             ("rollout_kernel<3, 3, false", "compass_walker_q", 8192, 11, 5)]
+
+
+def workload_of(name):
+    for frag, key, n, trials, timed in WORKLOADS:
+        if frag in name:
+            return key, n, trials, timed
+    return None
+
+
+def main():
+    out = sys.argv[1]
+    write = "--write" in sys.argv[2:]
+    stats = {}
+    for path in sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                w = workload_of(row.get("Name", ""))
+                if w:
+                    stats[w[0]] = {k: row[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs") if k in row}
+                    print("stats:", w[0], stats[w[0]])
+    # per-launch durations of the timed launches from the kernel trace of the stats pass
+    for path in sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)):
+        dur = defaultdict(list)
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                w = workload_of(row.get("Kernel_Name", ""))
+                if w:
+                    dur[w[0]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+        for frag, key, n, trials, timed in WORKLOADS:
+            if key in dur:
+                v = dur[key][-timed:]
+                print(f"trace: {key}: launches={len(dur[key])} mean_timed_ms={sum(v) / len(v):.4f} (last {len(v)})")
+                stats.setdefault(key, {})["timed_ms"] = sum(v) / len(v)
+    means = defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            vals = defaultdict(lambda: defaultdict(list))
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    w = workload_of(row.get("Kernel_Name", ""))
+                    if w:
+                        vals[w][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            for w, counters in vals.items():
+                for name, v in counters.items():
+                    timed = v[-w[3]:]
+                    means[w[0]][name] = sum(timed) / len(timed)
+                    print(f"{os.path.basename(d)} {w[0]} {name}: launches={len(v)} mean_timed={means[w[0]][name]:.6g} last={v[-1]:.6g}")
+    doc = {"format": "per workload key of bench.py: HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE in KB x 1024, separate rocprofv3 --pmc "
+                     "passes, mean of the timed launches; 64-B requests of 16-B loads: the gfx950 x2 correction for wide streaming reads is "
+                     "not applied, MI355X_MICROARCH.md calls other widths uncalibrated) and issue = (SQ_ACTIVE_INST_VALU + SQ_ACTIVE_INST_SCA) "
+                     "/ SQ_WAVE_CYCLES, all in quad-cycles; written by tools/pmc_to_json.py", "workloads": {}}
+    for frag, key, n, trials, timed in WORKLOADS:
+        m = means.get(key, {})
+        if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
+            continue
+        e = {"kernel": frag, "replicas": n, "trials_per_launch": trials, "hbm_bytes_per_launch": (m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
+             "fetch_bytes": m["FETCH_SIZE"] * 1024.0, "write_bytes": m["WRITE_SIZE"] * 1024.0, "source": os.path.basename(out.rstrip("/"))}
+        if all(k in m for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES")):
+            e["issue"] = (m["SQ_ACTIVE_INST_VALU"] + m["SQ_ACTIVE_INST_SCA"]) / m["SQ_WAVE_CYCLES"]
+        if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m:
+            e["wait_any"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+        if key in stats and "timed_ms" in stats[key]:
+            e["kernel_ms_trace"] = stats[key]["timed_ms"]
+        doc["workloads"][key] = e
+    print(json.dumps(doc, indent=1))
+    if write:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
+            json.dump(doc, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Run on the GPU box from the repo root: kernel-trace stats + PMC passes of the default bench
-# (separate passes; --pmc never combined with sys/hip/hsa tracing).  Output: gpurun_out/<tag>/
+# Run on the GPU box from the repo root: kernel-trace stats + PMC passes of the default bench (headline + the
+# secondary workloads; separate passes; --pmc never combined with sys/hip/hsa tracing).  Output: gpurun_out/<tag>/
+# summary.txt = per-kernel counter means + the JSON for profiles/pmc_traffic.json (tools/pmc_to_json.py)
 set -e
 TAG=${1:-prof}
 ROOT=$(pwd)
@@ -15,5 +16,5 @@ for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ
   echo "pass $i done: $set"
 done
 cd $ROOT
-python3 tools/summarise_pmc.py $OUT > $OUT/summary.txt 2>&1 || true
+python3 tools/pmc_to_json.py $OUT > $OUT/summary.txt 2>&1 || true
 cat $OUT/summary.txt
