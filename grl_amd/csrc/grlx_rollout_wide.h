@@ -1,0 +1,622 @@
+// grlx_rollout_wide.h -- the rollout kernel of the discrete-action TD agents for batches that outnumber the SIMDs:
+// one wave carries R = 4*B replicas (B sub-batches of four) instead of four.
+// Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
+//
+// Why.  rollout_kernel gives a replica 16 lanes (lane = tiling); the per-replica scalar chain -- the RK4 integration,
+// reward, observation: 40-90 % of a pass -- is then computed 16 times over.  That is free while there are no more
+// waves than SIMDs (4096 replicas = 1024 waves), but 8192 or 16384 replicas just run two or four rounds of it.
+// Here the ENVIRONMENT phase of a pass steps all R replicas of the wave at once (lane L integrates replica L mod R: the
+// redundancy drops from 16x to 64/R), and the TABLE phase -- hashing, lookups, sums, sampler, TD update: lane = tiling,
+// exactly the code of rollout_kernel -- runs B times, once per sub-batch.  Per replica the arithmetic and its order are
+// unchanged (bit-identical results); a wave-pass costs E + B*Tb instead of B*(E + Tb).
+//
+// Between its turns a sub-batch's lane state (register trace, pending update, position of p) is PARKED in LDS
+// (180 B per lane, lane-contiguous 16-byte quads: conflict-free ds_read/write_b128), its per-replica scalars (RNG
+// streams, counters, action) in a small structure-of-arrays; observation / reward / terminal / action travel between
+// the two lane roles through LDS as well.  B = 2: 23 KB of parked state per wave, four waves per CU fit.
+#pragma once
+
+namespace grlx {
+
+struct WideLane {                 // table-role state of one lane for one sub-batch
+  TraceRegs tr;
+  bool      pd, pd_sh, p_sh;
+  double    pd_dW, pd_dT, pd_wp;
+  uint32_t  pd_pos, p_pos;
+  uint32_t  status, inserted;
+};
+constexpr int kWideQuads = 11;    // 16-byte quads per parked lane
+
+__device__ __forceinline__ uint4 pack2d(double a, double b)
+{
+  const uint64_t ua = (uint64_t)__double_as_longlong(a), ub = (uint64_t)__double_as_longlong(b);
+  return make_uint4((uint32_t)ua, (uint32_t)(ua >> 32), (uint32_t)ub, (uint32_t)(ub >> 32));
+}
+__device__ __forceinline__ void unpack2d(const uint4 &q, double &a, double &b)
+{
+  a = __longlong_as_double((long long)((uint64_t)q.x | ((uint64_t)q.y << 32)));
+  b = __longlong_as_double((long long)((uint64_t)q.z | ((uint64_t)q.w << 32)));
+}
+
+// sh_ctx: [quad][lane] of this sub-batch; sh_ins: [lane]
+__device__ __forceinline__ void wide_park(const WideLane &c, uint4 *sh_ctx, uint32_t *sh_ins, int lane)
+{
+  static_assert(kMaxTrace == 10, "the parked layout holds ten trace entries");
+  sh_ctx[0 * 64 + lane] = make_uint4(c.tr.pos[0], c.tr.pos[1], c.tr.pos[2], c.tr.pos[3]);
+  sh_ctx[1 * 64 + lane] = make_uint4(c.tr.pos[4], c.tr.pos[5], c.tr.pos[6], c.tr.pos[7]);
+  sh_ctx[2 * 64 + lane] = make_uint4(c.tr.pos[8], c.tr.pos[9], c.tr.cnt2,
+                                     c.tr.wt | (c.tr.dup ? 1u << 16 : 0u) | ((uint32_t)c.tr.len << 20));
+#pragma unroll
+  for (int k = 0; k < 5; ++k) sh_ctx[(3 + k) * 64 + lane] = pack2d(c.tr.val[2 * k], c.tr.val[2 * k + 1]);
+  {
+    const uint64_t ut = (uint64_t)__double_as_longlong(c.tr.total);
+    sh_ctx[8 * 64 + lane] = make_uint4((uint32_t)ut, (uint32_t)(ut >> 32), c.pd_pos, c.p_pos);
+  }
+  sh_ctx[9 * 64 + lane] = pack2d(c.pd_dW, c.pd_dT);
+  {
+    const uint64_t uw = (uint64_t)__double_as_longlong(c.pd_wp);
+    sh_ctx[10 * 64 + lane] = make_uint4((uint32_t)uw, (uint32_t)(uw >> 32),
+                                        (c.pd ? 1u : 0u) | (c.pd_sh ? 2u : 0u) | (c.p_sh ? 4u : 0u), c.status);
+  }
+  sh_ins[lane] = c.inserted;
+}
+
+__device__ __forceinline__ void wide_unpark(WideLane &c, const uint4 *sh_ctx, const uint32_t *sh_ins, int lane)
+{
+  uint4 q = sh_ctx[0 * 64 + lane];
+  c.tr.pos[0] = q.x; c.tr.pos[1] = q.y; c.tr.pos[2] = q.z; c.tr.pos[3] = q.w;
+  q = sh_ctx[1 * 64 + lane];
+  c.tr.pos[4] = q.x; c.tr.pos[5] = q.y; c.tr.pos[6] = q.z; c.tr.pos[7] = q.w;
+  q = sh_ctx[2 * 64 + lane];
+  c.tr.pos[8] = q.x; c.tr.pos[9] = q.y; c.tr.cnt2 = q.z;
+  c.tr.wt = q.w & 0xFFFFu;
+  c.tr.dup = ((q.w >> 16) & 1u) != 0u;
+  c.tr.len = (int)(q.w >> 20);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) unpack2d(sh_ctx[(3 + k) * 64 + lane], c.tr.val[2 * k], c.tr.val[2 * k + 1]);
+  q = sh_ctx[8 * 64 + lane];
+  c.tr.total = __longlong_as_double((long long)((uint64_t)q.x | ((uint64_t)q.y << 32)));
+  c.pd_pos = q.z;
+  c.p_pos = q.w;
+  unpack2d(sh_ctx[9 * 64 + lane], c.pd_dW, c.pd_dT);
+  q = sh_ctx[10 * 64 + lane];
+  c.pd_wp = __longlong_as_double((long long)((uint64_t)q.x | ((uint64_t)q.y << 32)));
+  c.pd = (q.z & 1u) != 0u;
+  c.pd_sh = (q.z & 2u) != 0u;
+  c.p_sh = (q.z & 4u) != 0u;
+  c.status = q.w;
+  c.inserted = sh_ins[lane];
+}
+
+// per-replica scalars of the table role, parked as a structure of arrays [field][replica in wave]
+enum { WR_G = 0, WR_TL, WR_S1, WR_EPS, WR_TT, WR_SS, WR_TSTEPS, WR_TOTAL, WR_TIME, WR_ACTION, WR_FIELDS64 };
+enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_FIELDS32 };
+enum : uint32_t { WF_RUNNING = 1u, WF_FIRST = 2u, WF_TEST = 4u };
+
+struct WideRep {
+  uint64_t G, TL, S1;
+  double   eps_decay;
+  int64_t  tt, ss;
+  uint64_t test_steps;
+  double   total_reward, time, action;
+  int      action_index;
+  bool     running, first;
+  int      test;
+  uint32_t rows;
+};
+
+template <int R>
+__device__ __forceinline__ void wide_rep_store(const WideRep &s, uint64_t *sh64, uint32_t *sh32, int q)
+{
+  sh64[WR_G * R + q] = s.G;
+  sh64[WR_TL * R + q] = s.TL;
+  sh64[WR_S1 * R + q] = s.S1;
+  sh64[WR_EPS * R + q] = (uint64_t)__double_as_longlong(s.eps_decay);
+  sh64[WR_TT * R + q] = (uint64_t)s.tt;
+  sh64[WR_SS * R + q] = (uint64_t)s.ss;
+  sh64[WR_TSTEPS * R + q] = s.test_steps;
+  sh64[WR_TOTAL * R + q] = (uint64_t)__double_as_longlong(s.total_reward);
+  sh64[WR_TIME * R + q] = (uint64_t)__double_as_longlong(s.time);
+  sh64[WR_ACTION * R + q] = (uint64_t)__double_as_longlong(s.action);
+  sh32[WR_AIDX * R + q] = (uint32_t)s.action_index;
+  sh32[WR_FLAGS * R + q] = (s.running ? WF_RUNNING : 0u) | (s.first ? WF_FIRST : 0u) | (s.test ? WF_TEST : 0u);
+  sh32[WR_ROWS * R + q] = s.rows;
+}
+
+template <int R>
+__device__ __forceinline__ void wide_rep_load(WideRep &s, const uint64_t *sh64, const uint32_t *sh32, int q)
+{
+  s.G = sh64[WR_G * R + q];
+  s.TL = sh64[WR_TL * R + q];
+  s.S1 = sh64[WR_S1 * R + q];
+  s.eps_decay = __longlong_as_double((long long)sh64[WR_EPS * R + q]);
+  s.tt = (int64_t)sh64[WR_TT * R + q];
+  s.ss = (int64_t)sh64[WR_SS * R + q];
+  s.test_steps = sh64[WR_TSTEPS * R + q];
+  s.total_reward = __longlong_as_double((long long)sh64[WR_TOTAL * R + q]);
+  s.time = __longlong_as_double((long long)sh64[WR_TIME * R + q]);
+  s.action = __longlong_as_double((long long)sh64[WR_ACTION * R + q]);
+  s.action_index = (int)sh32[WR_AIDX * R + q];
+  const uint32_t f = sh32[WR_FLAGS * R + q];
+  s.running = (f & WF_RUNNING) != 0u;
+  s.first = (f & WF_FIRST) != 0u;
+  s.test = (f & WF_TEST) ? 1 : 0;
+  s.rows = sh32[WR_ROWS * R + q];
+}
+
+// B sub-batches of four replicas per wave.  Production ordering only (deferred TD update, no taps, no stamps): the
+// diagnostic instantiations stay with rollout_kernel.
+template <int ENV, int NA, int B, typename SPEC>
+__global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_trials)
+{
+  static_assert(B >= 2 && B <= 4, "sub-batches per wave");
+  constexpr int R = 4 * B;
+  constexpr int NROWS = NA + 1;
+  const DevParams &N = SPEC::numeric(P);
+  constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
+  __shared__ double   sh_w[NROWS * 16 * 4];
+  __shared__ uint32_t sh_ppos[4 * 16];
+  __shared__ double   sh_fb[16 * 4];
+  __shared__ uint32_t sh_fbflag[16 * 4];
+  __shared__ uint32_t sh_mb[4 * NA * 16];
+  __shared__ uint32_t sh_ms[4 * NA * 16];
+  __shared__ uint32_t sh_mail[4];
+  __shared__ double   sh_res[4 * 16];
+  __shared__ uint4    sh_ctx[B * kWideQuads * 64];      // parked lane state
+  __shared__ uint32_t sh_ins[B * 64];
+  __shared__ uint64_t sh_r64[WR_FIELDS64 * R];          // parked per-replica scalars
+  __shared__ uint32_t sh_r32[WR_FIELDS32 * R];
+  // exchange between the two lane roles, [field][replica in wave]
+  __shared__ double   sh_x[S * R];                      // start state (table role -> environment role)
+  __shared__ double   sh_obs[D * R];
+  __shared__ double   sh_reward[R];
+  __shared__ double   sh_act[R];                        // action to apply in the next environment phase
+  __shared__ int      sh_term[R];
+  __shared__ uint32_t sh_step[R];                       // 1: the replica takes an environment step in the next pass
+  __shared__ uint32_t sh_est[R];                        // status bits raised by the environment role
+
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  const unsigned long long gmask = 0xFFFFull << (16 * g);
+  const int wave0 = blockIdx.x * R;                     // first replica of this wave
+
+  // ---- environment role: lane L integrates replica wave0 + (L mod R)
+  const int eq = lane % R;
+  const bool elive = wave0 + eq < P.n_replicas;
+  double x[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) x[i] = P.states[elive ? wave0 + eq : 0].x[i];
+  uint32_t estatus = 0;
+  if (lane < R) { sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0; }
+
+  // ---- table role: lane (g, j) of sub-batch b serves tiling j of replica wave0 + 4b + g
+  UpdateParams up;
+  up.out_min = N.lin.out_min;
+  up.out_max = N.lin.out_max;
+  up.limit = N.lin.limit != 0;
+  up.ee = N.gl;
+  up.cut = (N.trace_kind == GRLX_TRACE_REPLACING) ? 0.01 : 0.0001;
+  up.use_trace = N.trace_kind == GRLX_TRACE_REPLACING;
+  up.dW = up.dT = 0;
+
+  double acts[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acts[a] = N.actions[a];
+  uint32_t key_act[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+    key_act[a] = in_reg(murmur_key(tile_coord<T>(N.tile, D, tile_quant(N.tile, D, N.actions[a]), j)));
+  const uint32_t key_j = in_reg(murmur_key(j));
+
+  for (int b = 0; b < B; ++b)
+  { // initial parked state of every sub-batch
+    const int q = 4 * b + g;
+    const bool live = wave0 + q < P.n_replicas;
+    const ReplicaState &RS = P.states[live ? wave0 + q : 0];
+    WideLane c;
+    trace_init(c.tr);
+    c.pd = c.pd_sh = c.p_sh = false;
+    c.pd_dW = c.pd_dT = c.pd_wp = 0;
+    c.pd_pos = c.p_pos = kInvalidPos;
+    c.status = RS.status;
+    c.inserted = 0;
+    wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+    WideRep s;
+    s.G = RS.G; s.TL = RS.TL; s.S1 = RS.S1;
+    s.eps_decay = RS.eps_decay;
+    s.tt = RS.tt; s.ss = RS.ss;
+    s.test_steps = RS.test_steps;
+    s.total_reward = 0; s.time = 0; s.action = 0;
+    s.action_index = 0;
+    s.running = false; s.first = true; s.test = 0;
+    s.rows = RS.rows;
+    wide_rep_store<R>(s, sh_r64, sh_r32, q);
+  }
+  wave_sync();
+
+  for (int trial = 0; trial < n_trials; ++trial)
+  {
+    // ---- start of the trial, table role (the start state may draw from the replica's RNG streams)
+    for (int b = 0; b < B; ++b)
+    {
+      const int q = 4 * b + g;
+      const bool live = wave0 + q < P.n_replicas;
+      WideRep s;
+      wide_rep_load<R>(s, sh_r64, sh_r32, q);
+      const int ti = N.test_interval;
+      s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;               // online_learning.cpp:160
+      double xs[S], obs[D];
+#pragma unroll
+      for (int i = 0; i < S; ++i) xs[i] = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) obs[i] = 0;
+      if (live)
+      {
+        Env<ENV>::start(N, s.test, s.TL, s.G, xs);                         // modeled.cpp:132-158
+        Env<ENV>::observe(N, xs, obs);
+      }
+      s.total_reward = 0;
+      s.time = 0;
+      s.action = 0;
+      s.action_index = 0;
+      s.running = live;
+      s.first = true;
+      wide_rep_store<R>(s, sh_r64, sh_r32, q);
+#pragma unroll
+      for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i) sh_obs[i * R + q] = obs[i];
+      if (j == 0) { sh_step[q] = 0u; sh_term[q] = 0; sh_reward[q] = 0; }
+      // TDAgent::start clears the trace (td.cpp:54): it was flushed at the end of the previous learning trial
+    }
+    wave_sync();
+    if (elive)
+    {
+#pragma unroll
+      for (int i = 0; i < S; ++i) x[i] = sh_x[i * R + eq];
+    }
+
+    for (;;)
+    {
+      // ================= environment phase: every replica of the wave that is in mid-episode takes its step
+      {
+        const bool step = elive && sh_step[eq] != 0u;
+        if (__any(step))
+        {
+          double obs[D], reward = 0;
+          int terminal = 0;
+#pragma unroll
+          for (int i = 0; i < D; ++i) obs[i] = 0;
+          if (step)
+          {
+            const double action = sh_act[eq];
+            env_step<ENV>(N, x, action, obs, reward, terminal, estatus);     // online_learning.cpp:196
+          }
+          wave_sync();                                                         // every lane has read its inputs
+          if (step)
+          { // the 64/R lanes of a replica hold identical values: all of them store (same address, same bits)
+#pragma unroll
+            for (int i = 0; i < D; ++i) sh_obs[i * R + eq] = obs[i];
+            sh_reward[eq] = reward;
+            sh_term[eq] = terminal;
+          }
+        }
+        wave_sync();
+      }
+
+      // ================= table phase, one sub-batch after the other
+      bool more = false;
+      for (int b = 0; b < B; ++b)
+      {
+        const int q = 4 * b + g;
+        const bool live = wave0 + q < P.n_replicas;
+        const int r = live ? wave0 + q : 0;
+        const ReplicaState &RS = P.states[r];
+        const Table tab = table_of(P, 0, r);
+        WideLane c;
+        wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+        WideRep s;
+        wide_rep_load<R>(s, sh_r64, sh_r32, q);
+        if (!__any(s.running || c.pd)) continue;                             // this sub-batch has finished its episodes
+
+        uint32_t slot[NA];
+        Lookup lk[NA];
+        BucketRegs br[NA];
+        double wp = 0;
+        bool has_next = false, update = false;
+        double obs[D], reward = 0;
+        int terminal = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) obs[i] = sh_obs[i * R + q];
+        if (s.running)
+        {
+          if (!s.first)
+          {
+            reward = sh_reward[q];
+            terminal = sh_term[q];
+            s.total_reward += reward;                                          // online_learning.cpp:202
+            s.time += 1;                                                       // tau = 1
+          }
+          has_next = s.first || terminal != 2;
+          update = !s.first && !s.test;
+          if (has_next)
+          { // policy: projections of Q(s', .) (q.cpp:94-107)
+            uint32_t hpre = 449u ^ (uint32_t)(D + 2);
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+              hpre = murmur_mix(hpre, tile_coord<T>(N.tile, i, tile_quant(N.tile, i, obs[i]), j));
+            const uint32_t hpm = hpre * 0x5bd1e995u;
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+            {
+              uint32_t h = hpm ^ key_act[a];
+              h = murmur_absorb(h, key_j);
+              const uint32_t hm = murmur_final(h), mem = (uint32_t)N.tile.memory;
+              slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          if (update) wp = value_load(tab, c.p_pos);
+          if (has_next) table_issue<NA>(tab, slot, lk, br);
+        }
+
+        // the PREVIOUS step's predictor update, in the shadow of the loads just issued (see rollout_kernel)
+        Evicted ev;
+        ev.n = 0u; ev.pos = kInvalidPos; ev.val = 0;
+        if (c.pd)
+        {
+          sh_ppos[g * 16 + j] = c.pd_pos;
+          sh_fbflag[j * 4 + g] = 0u;
+        }
+        wave_sync();
+        if (c.pd)
+        {
+          up.dW = c.pd_dW;
+          up.dT = c.pd_dT;
+          td_update_lane<true>(c.tr, tab, up, c.pd_pos, c.pd_sh, c.pd_wp, g, j, sh_ppos, sh_fb, sh_fbflag, c.status, ev);
+          c.pd = false;
+        }
+
+        if (s.running)
+        {
+          double qv[NA];
+          uint32_t pos[NA];
+          double w[NA];
+          bool sh[NA];
+#pragma unroll
+          for (int a = 0; a < NA; ++a) { qv[a] = 0; pos[a] = kInvalidPos; w[a] = 0; sh[a] = false; }
+          if (has_next)
+          {
+            bool shared_event = false;
+            table_get_finish<NA>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+                                 c.status, c.inserted,
+                                 [&](uint32_t mp) {
+                                   if (ev.pos != kInvalidPos && ev.pos == mp) value_store(tab, mp, ev.val);
+                                   trace_share_event(c.tr, tab, mp);
+                                   if (c.p_pos == mp) c.p_sh = true;
+                                   shared_event = true;
+                                 });
+            if (rarely(__any(shared_event)) && update) wp = value_load(tab, c.p_pos);
+          }
+          {
+            bool risky = ev.n > 1u || (update && c.p_sh);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) risky = risky || (has_next && sh[a]);
+            if (rarely(__any(risky)))
+            {
+#pragma unroll
+              for (int a = 0; a < NA; ++a)
+                if (has_next) w[a] = value_load(tab, pos[a]);
+              if (update) wp = value_load(tab, c.p_pos);
+            }
+            const bool held = ev.pos != kInvalidPos;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) w[a] = (held && pos[a] == ev.pos) ? ev.val : w[a];
+            wp = (held && c.p_pos == ev.pos) ? ev.val : wp;
+          }
+          if (has_next)
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+            {
+              w[a] = trace_forward(c.tr, pos[a], w[a]);
+              SHW(a, j, g) = w[a];
+            }
+          }
+          if (update)
+          {
+            wp = trace_forward(c.tr, c.p_pos, wp);
+            SHW(NA, j, g) = wp;
+          }
+          wave_sync();
+          { // LinearRepresentation::read (linear.cpp:136-184): lane r of the replica sums row r in the reference's order
+            const int row = (j < NROWS) ? j : 0;
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += SHW(row, k, g);
+            sum /= 16;
+            sh_res[g * 16 + j] = sum;
+          }
+          wave_sync();
+          if (has_next)
+          {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) qv[a] = clampd(sh_res[g * 16 + a], up.out_min, up.out_max);
+          }
+          double qsa = 0;
+          if (update) qsa = clampd(sh_res[g * 16 + NA], up.out_min, up.out_max);
+
+          // sampler (greedy.cpp:63-86, 144-218)
+          int a_next = 0;
+          int mai = 0, man = 1;
+          double best = 0;
+          if (has_next)
+          {
+            findmax<NA>(qv, mai, man, best);
+            if (s.test)
+              a_next = (man > 1) ? tie_break<NA>(qv, best, man, s.G) : mai;
+            else
+            {
+              if (s.time == 0.) s.eps_decay = fmax(s.eps_decay * N.decay_rate, N.decay_min);
+              s.S1 = lcg_next(s.S1);
+              const double rnd = lcg_double(s.S1);
+              if (rnd < s.eps_decay * N.epsilon)
+              {
+                s.G = lcg_next(s.G);
+                a_next = (int)(lcg_long(s.G) % (uint32_t)NA);
+              }
+              else
+                a_next = (man > 1) ? tie_break<NA>(qv, best, man, s.G) : mai;
+            }
+          }
+
+          // predictor update (sarsa.cpp:98-124 / advantage.cpp:71-110), queued for the next pass
+          if (update)
+          {
+            double target = reward;
+            if (has_next)
+            {
+              if (SPEC::agent(P) == GRLX_AGENT_SARSA)
+                target += N.gamma * pick<double, NA>(qv, a_next);
+              else if (SPEC::agent(P) == GRLX_AGENT_EXPECTED_SARSA)
+              {
+                const double de = s.eps_decay * N.epsilon;
+                double v = 0;
+#pragma unroll
+                for (int kk = 0; kk < NA; ++kk)
+                {
+                  double d = (qv[kk] == best) ? 1. / man : 0.;
+                  if (d == 1) d = 1 - de;
+                  d += de / NA;
+                  v += qv[kk] * d;
+                }
+                target += N.gamma * v;
+              }
+              else
+              {
+                double v = -__builtin_inf();
+#pragma unroll
+                for (int kk = 0; kk < NA; ++kk) v = fmax(v, qv[kk]);
+                target += N.gamma * v;
+              }
+            }
+            const double delta = target - qsa;
+            c.pd = true;
+            c.pd_dW = N.alpha * (target - qsa);
+            c.pd_dT = N.alpha * delta;
+            c.pd_pos = c.p_pos;
+            c.status |= (c.p_pos == kInvalidPos) ? ST_BAD_POS : 0u;
+            c.pd_sh = c.p_sh;
+            c.pd_wp = wp;
+          }
+
+          // bookkeeping
+          if (!s.first)
+          {
+            if (s.test) s.test_steps++;
+            else s.ss++;                                                       // online_learning.cpp:218
+          }
+          if (has_next)
+          {
+            s.action_index = a_next;
+            s.action = pick<double, NA>(acts, a_next);                         // discretizer_->at(index)
+            c.p_pos = pick<uint32_t, NA>(pos, a_next);
+            c.p_sh = pick<bool, NA>(sh, a_next);
+          }
+          if (!s.first && terminal) s.running = false;
+          s.first = false;
+        }
+        if (ev.pos != kInvalidPos) value_store(tab, ev.pos, ev.val);
+
+        // hand the action to the environment role and park
+        if (j == 0 && live)
+        {
+          sh_act[q] = s.action;
+          sh_step[q] = s.running ? 1u : 0u;
+        }
+        more = more || s.running || c.pd;
+        wide_rep_store<R>(s, sh_r64, sh_r32, q);
+        wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+      }
+      wave_sync();
+      if (!__any(more)) break;
+    }
+
+    // ---- end of the trial: write the cached weights back (test trials and the host read the table); row
+    for (int b = 0; b < B; ++b)
+    {
+      const int q = 4 * b + g;
+      const bool live = wave0 + q < P.n_replicas;
+      const int r = live ? wave0 + q : 0;
+      const Table tab = table_of(P, 0, r);
+      WideLane c;
+      wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+      WideRep s;
+      wide_rep_load<R>(s, sh_r64, sh_r32, q);
+      if (!s.test) trace_flush(c.tr, tab, true);
+      const int ti = N.test_interval;
+      if (live && (ti >= 0 ? s.test : 1))
+      {
+        if (s.rows < (uint32_t)P.max_rows)
+        {
+          if (j == 0)
+          {
+            const size_t at = (size_t)s.rows * (size_t)P.n_replicas + (size_t)r;
+            P.row_reward[at] = s.total_reward;
+            P.row_time[at] = s.time;
+            P.row_steps[at] = s.ss;
+            P.row_trial[at] = (ti >= 0) ? (s.tt + 1 - (s.tt + 1) / (ti + 1)) : s.tt;
+          }
+          s.rows++;
+        }
+        else
+          c.status |= ST_ROWS_FULL;
+      }
+      s.tt++;
+      wide_rep_store<R>(s, sh_r64, sh_r32, q);
+      wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+    }
+    wave_sync();
+  }
+
+  // ---- write the replicas back
+  if (elive && lane < R)
+  {
+    ReplicaState &RS = P.states[wave0 + eq];
+#pragma unroll
+    for (int i = 0; i < S; ++i) RS.x[i] = x[i];
+    sh_est[eq] = estatus;
+  }
+  wave_sync();
+  for (int b = 0; b < B; ++b)
+  {
+    const int q = 4 * b + g;
+    const bool live = wave0 + q < P.n_replicas;
+    WideLane c;
+    wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+    WideRep s;
+    wide_rep_load<R>(s, sh_r64, sh_r32, q);
+    uint32_t ins = c.inserted;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) ins += __shfl_xor(ins, off, 16);
+    uint32_t st = c.status | sh_est[q];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+    if (live && j == 0)
+    {
+      ReplicaState &RS = P.states[wave0 + q];
+      RS.G = s.G;
+      RS.TL = s.TL;
+      RS.S1 = s.S1;
+      RS.eps_decay = s.eps_decay;
+      RS.tt = s.tt;
+      RS.ss = s.ss;
+      RS.test_steps = s.test_steps;
+      RS.n_slots[0] += ins;
+      RS.rows = s.rows;
+      RS.status = st;
+    }
+  }
+}
+
+} // namespace grlx
