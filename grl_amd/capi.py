@@ -44,7 +44,7 @@ class Config(C.Structure):
                 ("tap_capacity", C.c_int32), ("end_stop_penalty", C.c_int32), ("action_penalty", C.c_int32),
                 ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
-                ("kappa", C.c_double), ("beta", C.c_double)]
+                ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Tap(C.Structure):
@@ -77,6 +77,7 @@ _SIGS = {
     "grlx_rows": (C.c_int, [C.c_void_p]),
     "grlx_read_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64), _P(C.c_double)]),
     "grlx_last_kernel": (C.c_int, [C.c_void_p]),
+    "grlx_replicas_per_wave": (C.c_int, [C.c_void_p]),
     "grlx_read_row_times": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_curve_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "grlx_step_counts": (C.c_int, [C.c_void_p, _P(C.c_uint64), _P(C.c_uint64)]),

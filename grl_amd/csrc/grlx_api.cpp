@@ -418,6 +418,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   *out = nullptr;
   if (cfg->n_replicas < 1) return fail(GRLX_ERR_INVALID, "n_replicas must be >= 1");
   if (cfg->max_rows < 1) return fail(GRLX_ERR_INVALID, "max_rows must be >= 1");
+  if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8)
+    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8");
   DevParams P;
   int rc = make_params(*cfg, &P);
   if (rc != GRLX_OK) return rc;
@@ -438,6 +440,21 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_replica = cfg->tap_replica;
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
   P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
+  { // replicas per wave: wide waves once the batch outnumbers the SIMDs four to one (taps and stamps: always 4)
+    const bool has_wide = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA) &&
+                          cfg->trace != GRLX_TRACE_ACCUMULATING;
+    int rpw = cfg->replicas_per_wave;
+    if (rpw == 0)
+    {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      int simds = 1024;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) simds = 4 * prop.multiProcessorCount;
+      rpw = ((N + kReplicasPerWave - 1) / kReplicasPerWave > simds) ? 8 : 4;
+    }
+    if (!has_wide || P.tap_capacity > 0) rpw = 4;
+    P.replicas_per_wave = rpw;
+  }
 
   const size_t n_tables = (cfg->agent == GRLX_AGENT_AC || cfg->agent == GRLX_AGENT_QV) ? 2 : 1;
   ctx->n_tables = (int)n_tables;
@@ -658,6 +675,7 @@ int grlx_read_rows(grlx_ctx *ctx, int replica, int first, int count, int64_t *tr
 }
 
 int grlx_last_kernel(grlx_ctx *ctx) { return ctx ? ctx->last_kernel : GRLX_KERNEL_NONE; }
+int grlx_replicas_per_wave(grlx_ctx *ctx) { return ctx ? ctx->P.replicas_per_wave : 0; }
 
 int grlx_read_row_times(grlx_ctx *ctx, int replica, int first, int count, double *episode_time)
 {

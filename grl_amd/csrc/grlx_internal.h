@@ -7,7 +7,7 @@
 namespace grlx {
 
 constexpr int kLanesPerReplica = 16;     // one lane per tiling
-constexpr int kReplicasPerWave = 4;
+constexpr int kReplicasPerWave = 4;      // per sub-batch; a wide wave carries 4*B (grlx_rollout_wide.h)
 constexpr int kMaxTrace = 10;            // replacing trace: (gamma*lambda)^n < 0.01 must hold for n <= 10
 constexpr int kMaxActions = GRLX_MAX_ACTIONS;
 constexpr uint32_t kInvalidPos = 0xFFFFFFFFu;
@@ -103,6 +103,7 @@ struct DevParams {
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
   double   kappa;               // predictor/critic/advantage: advantage scaling factor
   double   beta;                // predictor/critic/qv: state-value learning rate
+  int32_t  replicas_per_wave;   // 4 (one sub-batch) or 8 (two): chosen at create from the replica count and the SIMD count
 };
 
 // ---------------------------------------------------------------------------

@@ -41,6 +41,7 @@ namespace grlx {
 
 #include "grlx_update.h"
 #include "grlx_rollout.h"
+#include "grlx_rollout_wide.h"
 #include "grlx_rollout_ac.h"
 #include "grlx_rollout_qv.h"
 #include "grlx_rollout_acc.h"
@@ -113,6 +114,33 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
     GRLX_LAUNCH_ADV(GRLX_ENV_PENDULUM, 3)
     GRLX_LAUNCH_ADV(GRLX_ENV_ACROBOT, 3)
 #undef GRLX_LAUNCH_ADV
+    return hipErrorInvalidValue;
+  }
+  if (!inplace && P.replicas_per_wave == 8)
+  { // more replicas than 4 x SIMDs: two sub-batches per wave share one environment phase (grlx_rollout_wide.h)
+    const int wwaves = (P.n_replicas + 7) / 8;
+#define GRLX_LAUNCH_WIDE(ENVID, NACT)                                                                                 \
+    if (P.env == ENVID && P.A == NACT)                                                                              \
+    {                                                                                                               \
+      hipLaunchKernelGGL((rollout_wide_kernel<ENVID, NACT, 2, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                     \
+    }
+#define GRLX_LAUNCH_WIDE_SPEC(AGENT)                                                                                  \
+    if (!P.no_specialisation && SpecPendulumTcA<AGENT>::matches(P))                                                 \
+    {                                                                                                               \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                              \
+      hipLaunchKernelGGL((rollout_wide_kernel<GRLX_ENV_PENDULUM, 3, 2, SpecPendulumTcA<AGENT>>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                     \
+    }
+    GRLX_LAUNCH_WIDE_SPEC(GRLX_AGENT_SARSA)
+    GRLX_LAUNCH_WIDE_SPEC(GRLX_AGENT_Q)
+    GRLX_LAUNCH_WIDE(GRLX_ENV_PENDULUM, 3)
+    GRLX_LAUNCH_WIDE(GRLX_ENV_PENDULUM, 5)
+    GRLX_LAUNCH_WIDE(GRLX_ENV_ACROBOT, 3)
+    GRLX_LAUNCH_WIDE(GRLX_ENV_CART_POLE, 3)
+    GRLX_LAUNCH_WIDE(GRLX_ENV_COMPASS_WALKER, 3)
+#undef GRLX_LAUNCH_WIDE
+#undef GRLX_LAUNCH_WIDE_SPEC
     return hipErrorInvalidValue;
   }
   if (!inplace && !P.no_specialisation)

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
           if (has_next)
           {
             bool shared_event = false;
-            table_get_finish<NA>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+            table_get_finish<NA, false>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
                                  c.status, c.inserted,
                                  [&](uint32_t mp) {
                                    if (ev.pos != kInvalidPos && ev.pos == mp) value_store(tab, mp, ev.val);

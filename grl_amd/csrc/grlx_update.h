@@ -341,7 +341,9 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
 // resolves new cross-tiling sharing events.  sh[i]: the slot is shared between tilings.
 // on_share(mp): called in every lane of the group for each slot position that just became shared.
 // table_get_finish: the part after the loads of table_issue (lk, br).
-template <int NP, typename OnShare>
+// LDSJ: the LCG jump table is staged in LDS (sh_jump); false: read from device memory (the wide kernels, whose LDS
+// holds parked state instead; sh_jump is ignored)
+template <int NP, bool LDSJ = true, typename OnShare>
 __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearParams &lp, const ReplicaState &rs, int table, const uint32_t (&slot)[NP],
                                                  Lookup (&lk)[NP], const BucketRegs (&br)[NP],
                                                  uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
@@ -374,7 +376,10 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
       { // a loaded policy image replaces the drawn initial value (read here, on the rare path, so
         // that the hot path carries no pointer for it)
         const double *img = rs.lazy_base[table];
-        w0[a] = img ? img[slot[a]] : lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
+        if constexpr (LDSJ)
+          w0[a] = img ? img[slot[a]] : lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
+        else
+          w0[a] = img ? img[slot[a]] : lazy_weight(rs.TL0, lp, slot[a]);
       }
     }
     wave_sync();

@@ -128,6 +128,10 @@ class Runner:
         """capi GRLX_KERNEL_*: 1 generic, 2 specialised (compile-time instantiation), 3 diagnostic in-place."""
         return self.lib.grlx_last_kernel(self._ctx)
 
+    def replicas_per_wave(self) -> int:
+        """4: one replica per 16 lanes; 8: two sub-batches per wave sharing the environment phase (wide kernels)."""
+        return self.lib.grlx_replicas_per_wave(self._ctx)
+
     def row_times(self, replica: int, first: int = 0, count: int = None):
         """Episode time of each row's trial (column 4, online_learning.cpp:243): steps under discrete_time."""
         if count is None:

@@ -121,6 +121,11 @@ typedef struct {
   /* predictor/critic/qv (qv.cpp:35-64): state-value learning rate; V's projector / representation
    * are given in actor_projector / actor_representation (the second table of the context) */
   double   beta;
+  /* GPU-side layout (no reference counterpart): replicas carried by one wavefront.  0 = automatic: 4 (16 lanes per
+   * replica, lane = tiling) while the batch has no more than 4 replicas per SIMD of the device, else 8 (two sub-batches
+   * of four share one environment phase; grlx_rollout_wide.h).  4 / 8 force the choice (tests); results are identical. */
+  int32_t  replicas_per_wave;
+  int32_t  reserved0;
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;
@@ -189,6 +194,8 @@ enum { GRLX_KERNEL_NONE = 0,          /* nothing launched yet                   
                                          SARSA / Q / Expected SARSA, cart-pole actor-critic)                   */
        GRLX_KERNEL_IN_PLACE = 3       /* diagnostic instantiation: taps / stamps, TD update applied in place   */ };
 int  grlx_last_kernel(grlx_ctx *ctx);
+/* Replicas per wavefront of the context's rollout kernels (4 or 8): the layout chosen at create. */
+int  grlx_replicas_per_wave(grlx_ctx *ctx);
 
 /* counters: total env steps executed by all replicas since create */
 int  grlx_step_counts(grlx_ctx *ctx, uint64_t *learn_steps, uint64_t *test_steps);

@@ -141,3 +141,77 @@ def test_cart_pole_dynamics_along_the_reference_golden_trajectory(grlx):
     with pytest.raises(grlx.capi.GrlxError) as ei:              # no fused TD rollout exists for this task
         grlx.Runner(cfg, [1])
     assert ei.value.code == grlx.capi.ERR_INVALID
+
+
+# ------------------------------------------------ wide waves (8 replicas per wave) ---
+def _wide_vs_oracle(grlx, make, n, trials, sample, chunks, **over):
+    """replicas_per_wave = 8 (two sub-batches of four share one environment phase, grlx_rollout_wide.h) against the
+    scalar oracle AND against the 4-per-wave kernel: rows, RNG positions, environment state, weights, step counts."""
+    got = {}
+    for rpw in (8, 4):
+        cfg, spec = make(grlx, n, **over)
+        cfg.replicas_per_wave = rpw
+        cfg.max_rows = trials + 1
+        seeds = np.arange(101, 101 + n)
+        r = grlx.Runner(cfg, seeds)
+        assert r.replicas_per_wave() == rpw
+        for c in chunks:
+            r.run(c)
+        r.sync()
+        assert r.last_kernel() in (1, 2)
+        rng = np.random.default_rng(5)
+        slots = rng.integers(0, cfg.projector.memory, 1500).astype(np.uint32)
+        got[rpw] = dict(rows=[r.rows(k) for k in sample], times=[r.row_times(k) for k in sample], rng=[list(r.rng(k))[:3] for k in sample],
+                        state=[r.env_state(k) for k in sample], w=[r.weights(k, slots) for k in sample], counts=r.step_counts(),
+                        load=[r.table_load(k) for k in sample])
+        r.close()
+    assert got[8]["counts"] == got[4]["counts"]
+    assert got[8]["load"] == got[4]["load"]
+    for i, k in enumerate(sample):
+        e = ob.Experiment(spec, seed=int(101 + k))
+        rows, _ = e.run(trials)
+        for rpw in (8, 4):
+            t, s, rew = got[rpw]["rows"][i]
+            assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows], f"rpw {rpw} replica {k}"
+            assert_bit_equal(rew, [x.reward for x in rows], f"rpw {rpw}: returns of replica {k}")
+            assert_bit_equal(got[rpw]["times"][i], [x.time for x in rows], f"rpw {rpw}: episode times of replica {k}")
+            assert got[rpw]["rng"][i] == list(e.rng())[:3], f"rpw {rpw}: RNG positions of replica {k}"
+            assert_bit_equal(got[rpw]["state"][i], e.state(), f"rpw {rpw}: env state of replica {k}")
+            assert_bit_equal(got[rpw]["w"][i], e.weights(slots), f"rpw {rpw}: weights of replica {k}")
+        e.close()
+
+
+@pytest.mark.parametrize("name,n,trials,agent", [("pendulum", 21, 33, 0), ("pendulum", 13, 22, 1), ("pendulum", 9, 22, 3),
+                                                 ("acrobot", 19, 44, 1), ("acrobot", 10, 33, 0), ("compass_walker", 11, 22, 1)])
+def test_wide_waves_bit_exact(grlx, name, n, trials, agent):
+    """Ragged batches (n mod 8 != 0: a half-empty sub-batch, a dead 16-lane group), every replica checked; episodes of
+    the acrobot and the walker end at different steps inside one wave (absorbing states), so sub-batches finish apart."""
+    from tests import configs
+    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot, "compass_walker": configs.compass_walker}[name]
+    _wide_vs_oracle(grlx, lambda g, k, **o: make(g, k, agent=agent, **o), n, trials, list(range(n)), [trials // 3, trials - trials // 3])
+
+
+def test_wide_waves_generic_parameters_and_tiny_memory(grlx):
+    """The generic wide instantiation with the knobs of the generic-parameter tests, and a 2048-slot hash memory where
+    nearly every slot is shared between tilings (write-through entries, cross-lane aliases, reloads after the update)."""
+    from tests import configs
+
+    def make(g, k, **o):
+        cfg, spec = configs.pendulum(g, k, agent=1, **o)
+        for obj in (cfg, spec):
+            obj.projector.memory = 2048
+            obj.test_interval, obj.randomization, obj.decay_rate, obj.decay_min = 3, 1.0, 0.95, 0.2
+            obj.representation.output_min, obj.representation.output_max = -300.0, 5.0
+        return cfg, spec
+    _wide_vs_oracle(grlx, make, 12, 24, list(range(12)), [10, 14])
+
+
+def test_wide_waves_are_chosen_for_batches_beyond_four_replicas_per_simd(grlx):
+    """Automatic layout: 4 replicas per wave while the waves fit the SIMDs (4096 replicas on 1024 SIMDs), 8 beyond;
+    actor-critic, QV, advantage and accumulating-trace contexts and tapped contexts stay at 4."""
+    r = grlx.Runner(grlx.pendulum_sarsa_config(4096, table_log2_capacity=10), np.arange(4096)); assert r.replicas_per_wave() == 4; r.close()
+    r = grlx.Runner(grlx.pendulum_sarsa_config(4100, table_log2_capacity=10), np.arange(4100)); assert r.replicas_per_wave() == 8; r.close()
+    r = grlx.Runner(grlx.pendulum_sarsa_config(4100, table_log2_capacity=10, trace=2), np.arange(4100)); assert r.replicas_per_wave() == 4; r.close()
+    r = grlx.Runner(grlx.pendulum_sarsa_config(8, replicas_per_wave=8, tap_replica=0, tap_capacity=16), np.arange(8)); assert r.replicas_per_wave() == 4; r.close()
+    with pytest.raises(grlx.capi.GrlxError):
+        grlx.Runner(grlx.pendulum_sarsa_config(8, replicas_per_wave=16), np.arange(8))
