@@ -441,8 +441,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
   P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
   { // replicas per wave: wide waves once the batch outnumbers the SIMDs four to one (taps and stamps: always 4)
-    const bool has_wide = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA) &&
-                          cfg->trace != GRLX_TRACE_ACCUMULATING;
+    const bool has_wide = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA ||
+                           cfg->agent == GRLX_AGENT_AC) && cfg->trace != GRLX_TRACE_ACCUMULATING;
     int rpw = cfg->replicas_per_wave;
     if (rpw == 0)
     {

@@ -43,6 +43,7 @@ namespace grlx {
 #include "grlx_rollout.h"
 #include "grlx_rollout_wide.h"
 #include "grlx_rollout_ac.h"
+#include "grlx_rollout_ac_wide.h"
 #include "grlx_rollout_qv.h"
 #include "grlx_rollout_acc.h"
 
@@ -55,6 +56,22 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
   const bool taps = P.tap_replica >= 0 && P.tap_capacity > 0;          // recorded by the in-place instantiation
   if (variant) *variant = taps ? GRLX_KERNEL_IN_PLACE : GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (!taps && P.replicas_per_wave == 8)
+  { // two sub-batches per wave share one environment phase (grlx_rollout_ac_wide.h)
+    const int wwaves = (P.n_replicas + 7) / 8;
+    if (P.env == GRLX_ENV_CART_POLE && !P.no_specialisation && SpecCartPoleAc::matches(P))
+    {
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;
+      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_CART_POLE, 2, SpecCartPoleAc>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+    }
+    else if (P.env == GRLX_ENV_CART_POLE)
+      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_CART_POLE, 2, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+    else if (P.env == GRLX_ENV_PENDULUM)
+      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_PENDULUM, 2, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+    else
+      return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   switch (P.env)
   {
     case GRLX_ENV_CART_POLE:

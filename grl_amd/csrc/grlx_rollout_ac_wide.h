@@ -1,0 +1,466 @@
+// grlx_rollout_ac_wide.h -- actor-critic rollout with 8 replicas per wave: rollout_ac_kernel's table phase (grlx_rollout_ac.h)
+// under the wave layout and the per-replica trial sequencing of rollout_wide_kernel (grlx_rollout_wide.h).
+// Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
+#pragma once
+
+namespace grlx {
+
+// WideRep slots reused: S1 holds the bits of ActionPolicy::n_ (ac_noise), eps_decay holds ActionPolicy::decay_ (ac_decay).
+template <int ENV, int B, typename SPEC>
+__global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_trials)
+{
+  static_assert(B >= 2 && B <= 4, "sub-batches per wave");
+  constexpr int R = 4 * B;
+  const DevParams &N = SPEC::numeric(P);
+  constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
+  __shared__ double   sh_w[4 * 16 * 4];        // rows: actor(s'), critic(s'), actor(s), critic(s)
+  __shared__ uint32_t sh_ppos[4 * 16];
+  __shared__ uint32_t sh_apos[4 * 16];
+  __shared__ double   sh_fb[16 * 4];
+  __shared__ uint32_t sh_fbflag[16 * 4];
+  __shared__ uint32_t sh_mb[4 * 16];
+  __shared__ uint32_t sh_ms[4 * 16];
+  __shared__ uint32_t sh_mail[4];
+  __shared__ double   sh_res[4 * 16];
+  __shared__ uint4    sh_ctx[B * kWideQuads * 64];
+  __shared__ uint32_t sh_ins[B * 3 * 64];
+  __shared__ uint64_t sh_r64[WR_FIELDS64 * R];
+  __shared__ uint32_t sh_r32[WR_FIELDS32 * R];
+  __shared__ double   sh_x[S * R];
+  __shared__ double   sh_obs[D * R];
+  __shared__ double   sh_reward[R];
+  __shared__ double   sh_act[R];
+  __shared__ int      sh_term[R];
+  __shared__ uint32_t sh_step[R];
+  __shared__ uint32_t sh_est[R];
+
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  const unsigned long long gmask = 0xFFFFull << (16 * g);
+  const int wave0 = blockIdx.x * R;
+
+  // ---- environment role
+  const int eq = lane % R;
+  const bool elive = wave0 + eq < P.n_replicas;
+  double x[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) x[i] = P.states[elive ? wave0 + eq : 0].x[i];
+  uint32_t estatus = 0;
+  if (lane < R) { sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0; }
+
+  // ---- table role
+  UpdateParams up;
+  up.out_min = N.lin.out_min;
+  up.out_max = N.lin.out_max;
+  up.limit = N.lin.limit != 0;
+  up.ee = N.gl;
+  up.cut = 0.01;
+  up.use_trace = N.trace_kind == GRLX_TRACE_REPLACING;
+  up.dW = up.dT = 0;
+  const double a_min = N.lin_actor.out_min, a_max = N.lin_actor.out_max;
+  const bool a_limit = N.lin_actor.limit != 0;
+
+  for (int b = 0; b < B; ++b)
+  { // initial parked state: the critic's trace is restored (positions from HBM, weights from the current table)
+    const int q = 4 * b + g;
+    const bool live = wave0 + q < P.n_replicas;
+    const int r = live ? wave0 + q : 0;
+    const ReplicaState &RS = P.states[r];
+    const Table tabC = table_of(P, 0, r);
+    WideLane c;
+    trace_init(c.tr);
+    if (live && up.use_trace)
+    {
+      const uint32_t *ts = P.trace_state + ((size_t)r * 16 + (size_t)j) * kMaxTrace * 2;
+      c.tr.len = RS.tr_len;
+      c.tr.total = RS.tr_total;
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+      {
+        c.tr.pos[e] = ts[e * 2];
+        const uint32_t cw = ts[e * 2 + 1];
+        const uint32_t cn = cw & 0xFFFFu;
+        c.tr.cnt2 |= ((cn > 0u ? cn - 1u : 0u) & 3u) << (2 * e);
+        if (cw >> 16) c.tr.wt |= 1u << e;
+        c.tr.dup = c.tr.dup || cn > 1u;
+        if (c.tr.pos[e] != kInvalidPos) c.tr.val[e] = value_load(tabC, c.tr.pos[e]);
+      }
+    }
+    c.pd = c.pd_sh = c.p_sh = false;
+    c.pd_dW = c.pd_dT = c.pd_wp = 0;
+    c.pd_pos = c.p_pos = kInvalidPos;
+    c.status = RS.status;
+    c.inserted = 0;
+    c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
+    wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+    WideRep s;
+    s.G = RS.G; s.TL = RS.TL;
+    s.S1 = (uint64_t)__double_as_longlong(RS.ac_noise);
+    s.eps_decay = RS.ac_decay;
+    s.tt = RS.tt; s.ss = RS.ss;
+    s.test_steps = RS.test_steps;
+    s.total_reward = 0; s.time = 0; s.action = 0;
+    s.action_index = 0;
+    s.running = false; s.first = true; s.test = 0;
+    s.ending = false;
+    s.rows = RS.rows;
+    s.trials_left = live ? n_trials : 0;
+    wide_rep_store<R>(s, sh_r64, sh_r32, q);
+  }
+  wave_sync();
+
+  for (;;)
+  {
+    // ================= environment phase (see rollout_wide_kernel)
+    {
+      const uint32_t todo = elive ? sh_step[eq] : 0u;
+      if (rarely(__any(todo == 2u)))
+      {
+        if (todo == 2u)
+        {
+#pragma unroll
+          for (int i = 0; i < S; ++i) x[i] = sh_x[i * R + eq];
+        }
+      }
+      const bool step = todo == 1u;
+      if (__any(step))
+      {
+        double obs[D], reward = 0;
+        int terminal = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) obs[i] = 0;
+        if (step)
+        {
+          const double action = sh_act[eq];
+          env_step<ENV>(N, x, action, obs, reward, terminal, estatus);
+#pragma unroll
+          for (int i = 0; i < D; ++i) sh_obs[i * R + eq] = obs[i];
+          sh_reward[eq] = reward;
+          sh_term[eq] = terminal;
+        }
+      }
+      wave_sync();
+    }
+
+    // ================= table phase, one sub-batch after the other
+    bool more = false;
+    for (int b = 0; b < B; ++b)
+    {
+      const int q = 4 * b + g;
+      const bool live = wave0 + q < P.n_replicas;
+      const int r = live ? wave0 + q : 0;
+      const ReplicaState &RS = P.states[r];
+      const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
+      WideLane c;
+      wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      WideRep s;
+      wide_rep_load<R>(s, sh_r64, sh_r32, q);
+      if (!__any(s.running || c.pd || s.trials_left > 0)) continue;
+      double ac_noise = __longlong_as_double((long long)s.S1), ac_decay = s.eps_decay;
+
+      uint32_t slotA[1] = {0}, slotC[1] = {0};
+      Lookup lkA[1], lkC[1];
+      BucketRegs brA[1], brC[1];
+      double wap = 0, wpc = 0;
+      bool has_next = false, update = false, need_critic = false;
+      double obs[D], reward = 0;
+      int terminal = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) obs[i] = sh_obs[i * R + q];
+      if (s.running)
+      {
+        if (!s.first)
+        {
+          reward = sh_reward[q];
+          terminal = sh_term[q];
+          s.total_reward += reward;
+          s.time += 1;
+        }
+        has_next = s.first || terminal != 2;
+        update = !s.first && !s.test;
+        need_critic = has_next && !s.test;
+        if (has_next)
+        {
+          slotA[0] = tile_slot_obs<T>(N.tile_actor, obs, D, j);
+          slotC[0] = tile_slot_obs<T>(N.tile, obs, D, j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (update)
+        {
+          wap = value_load(tabA, c.ap_pos);
+          wpc = value_load(tabC, c.p_pos);
+        }
+        if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
+        if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
+      }
+
+      // the PREVIOUS step's critic update, in the shadow of the loads just issued
+      Evicted ev;
+      ev.n = 0u; ev.pos = kInvalidPos; ev.val = 0;
+      if (c.pd)
+      {
+        sh_ppos[g * 16 + j] = c.pd_pos;
+        sh_fbflag[j * 4 + g] = 0u;
+      }
+      wave_sync();
+      if (c.pd)
+      {
+        up.dW = c.pd_dW;
+        up.dT = c.pd_dT;
+        td_update_lane<true>(c.tr, tabC, up, c.pd_pos, c.pd_sh, c.pd_wp, g, j, sh_ppos, sh_fb, sh_fbflag, c.status, ev);
+        c.pd = false;
+      }
+
+      if (s.running)
+      {
+        uint32_t posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
+        double wA[1] = {0}, wC[1] = {0};
+        bool shA[1] = {false}, shC[1] = {false};
+        if (has_next)
+        {
+          table_get_finish<1, false>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+                                     c.status, c.inserted2, [&](uint32_t mp) { if (c.ap_pos == mp) c.ap_sh = true; });
+        }
+        if (need_critic)
+        {
+          bool shared_event = false;
+          table_get_finish<1, false>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+                                     c.status, c.inserted,
+                                     [&](uint32_t mp) {
+                                       if (ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);
+                                       trace_share_event(c.tr, tabC, mp);
+                                       if (c.p_pos == mp) c.p_sh = true;
+                                       shared_event = true;
+                                     });
+          if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, c.p_pos);
+        }
+        {
+          const bool risky = ev.n > 1u || (update && c.p_sh) || (need_critic && shC[0]);
+          if (rarely(__any(risky)))
+          {
+            if (need_critic) wC[0] = value_load(tabC, posC[0]);
+            if (update) wpc = value_load(tabC, c.p_pos);
+          }
+          const bool held = ev.pos != kInvalidPos;
+          wC[0] = (held && posC[0] == ev.pos) ? ev.val : wC[0];
+          wpc = (held && c.p_pos == ev.pos) ? ev.val : wpc;
+        }
+        if (need_critic) wC[0] = trace_forward(c.tr, posC[0], wC[0]);
+        if (update) wpc = trace_forward(c.tr, c.p_pos, wpc);
+        SHA(0, j, g) = wA[0];
+        SHA(1, j, g) = wC[0];
+        SHA(2, j, g) = wap;
+        SHA(3, j, g) = wpc;
+        sh_apos[g * 16 + j] = c.ap_pos;
+        wave_sync();
+        double sums[4];
+        {
+          const int row = j & 3;
+          double sum = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sum += SHA(row, k, g);
+          sh_res[g * 16 + j] = sum / 16;
+        }
+        wave_sync();
+#pragma unroll
+        for (int row = 0; row < 4; ++row) sums[row] = sh_res[g * 16 + row];
+        const double u_next = clampd(sums[0], a_min, a_max);
+        const double v_next = clampd(sums[1], up.out_min, up.out_max);
+        const double u_prev = clampd(sums[2], a_min, a_max);
+        const double v_prev = clampd(sums[3], up.out_min, up.out_max);
+
+        // policy (ActionPolicy::act, action.cpp:127-158)
+        double a_next = 0;
+        if (has_next)
+        {
+          double out = u_next;
+          if (!s.test)
+          {
+            if (s.time == 0) ac_noise = 0;
+            if (s.time == 0.) ac_decay = fmax(ac_decay * N.ac_decay_rate, N.ac_decay_min);
+            if (N.sigma != 0)
+            { // Rand::getNormal(0, decay*sigma): two thread-local draws (utils.h:120-125)
+              s.TL = lcg_next(s.TL);
+              const double U1 = lcg_double(s.TL);
+              s.TL = lcg_next(s.TL);
+              const double U2 = lcg_double(s.TL);
+              const double sg = ac_decay * N.sigma;
+              const double nrm = __builtin_sqrt(-2 * plog(U1)) * pcos(2 * GRLX_PI * U2) * sg + 0.;
+              ac_noise = (1 - N.theta) * ac_noise + nrm;
+              out += ac_noise;
+            }
+          }
+          a_next = fmin(fmax(out, N.action_min), N.action_max);
+        }
+
+        // predictor (ActionACPredictor::update, ac.cpp:72-110)
+        if (update)
+        {
+          double target = reward;
+          if (has_next) target += N.gamma * v_next;
+          const double delta = target - v_prev;
+          c.pd = true;
+          c.pd_dW = N.alpha * (target - v_prev);
+          c.pd_dT = N.alpha * delta;
+          c.pd_pos = c.p_pos;
+          c.status |= (c.p_pos == kInvalidPos) ? ST_BAD_POS : 0u;
+          c.pd_sh = c.p_sh;
+          c.pd_wp = wpc;
+          if (N.ac_update_method == 0 || delta > 0)
+          {
+            double du = s.action - u_prev;
+            if (N.ac_update_method == 0) du = delta * du;
+            if (N.ac_step_limit >= 0) du = fmin(fmax(du, -N.ac_step_limit), N.ac_step_limit);
+            const double target_u = u_prev + du;
+            const double dA = N.actor_alpha * (target_u - u_prev);
+            uint32_t cpa = 1;
+            const uint32_t amask = (uint32_t)((__ballot(c.ap_sh) >> (16 * g)) & 0xFFFFull);
+            for (uint32_t mm = amask; mm != 0u; mm &= mm - 1u)
+            {
+              const int k = __builtin_ctz(mm);
+              if (k != j && sh_apos[g * 16 + k] == c.ap_pos) cpa++;
+            }
+            double nv = wap;
+            for (uint32_t cc = 0; cc < cpa; ++cc) nv = a_limit ? clampd(nv + dA, a_min, a_max) : nv + dA;
+            value_store(tabA, c.ap_pos, nv);
+          }
+        }
+
+        if (!s.first)
+        {
+          if (s.test) s.test_steps++;
+          else s.ss++;
+        }
+        if (has_next)
+        {
+          s.action = a_next;
+          c.ap_pos = posA[0]; c.ap_sh = shA[0];
+          if (need_critic) { c.p_pos = posC[0]; c.p_sh = shC[0]; }
+        }
+        if (!s.first && terminal) { s.running = false; s.ending = true; }
+        s.first = false;
+      }
+      if (ev.pos != kInvalidPos) value_store(tabC, ev.pos, ev.val);
+
+      // ---- between trials
+      uint32_t step_next = s.running ? 1u : 0u;
+      const bool between = !s.running && !c.pd && s.trials_left > 0;
+      if (__any(between))
+      {
+        if (between && s.ending)
+        { // end of a learning trial: make the table current; the entries stay -- the reference never clears the critic's trace
+          if (!s.test) trace_flush(c.tr, tabC, false);
+          const int ti = N.test_interval;
+          if (ti >= 0 ? s.test : 1)
+          {
+            if (s.rows < (uint32_t)P.max_rows)
+            {
+              if (j == 0)
+              {
+                const size_t at = (size_t)s.rows * (size_t)P.n_replicas + (size_t)r;
+                P.row_reward[at] = s.total_reward;
+                P.row_time[at] = s.time;
+                P.row_steps[at] = s.ss;
+                P.row_trial[at] = (ti >= 0) ? (s.tt + 1 - (s.tt + 1) / (ti + 1)) : s.tt;
+              }
+              s.rows++;
+            }
+            else
+              c.status |= ST_ROWS_FULL;
+          }
+          s.tt++;
+          s.trials_left--;
+          s.ending = false;
+        }
+        if (between && s.trials_left > 0)
+        {
+          const int ti = N.test_interval;
+          s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;
+          double xs[S], ob0[D];
+          Env<ENV>::start(N, s.test, s.TL, s.G, xs);
+          Env<ENV>::observe(N, xs, ob0);
+#pragma unroll
+          for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
+#pragma unroll
+          for (int i = 0; i < D; ++i) sh_obs[i * R + q] = ob0[i];
+          s.total_reward = 0;
+          s.time = 0;
+          s.action = 0;
+          s.running = true;
+          s.first = true;
+          step_next = 2u;
+        }
+      }
+
+      if (j == 0 && live)
+      {
+        sh_act[q] = s.action;
+        sh_step[q] = step_next;
+      }
+      more = more || s.running || c.pd || s.trials_left > 0;
+      s.S1 = (uint64_t)__double_as_longlong(ac_noise);
+      s.eps_decay = ac_decay;
+      wide_rep_store<R>(s, sh_r64, sh_r32, q);
+      wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+    }
+    wave_sync();
+    if (!__any(more)) break;
+  }
+
+  // ---- write the replicas back; persist the critic's trace (weights are in the table already)
+  if (elive && lane < R)
+  {
+    ReplicaState &RS = P.states[wave0 + eq];
+#pragma unroll
+    for (int i = 0; i < S; ++i) RS.x[i] = x[i];
+    sh_est[eq] = estatus;
+  }
+  wave_sync();
+  for (int b = 0; b < B; ++b)
+  {
+    const int q = 4 * b + g;
+    const bool live = wave0 + q < P.n_replicas;
+    const int r = live ? wave0 + q : 0;
+    const Table tabC = table_of(P, 0, r);
+    WideLane c;
+    wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+    WideRep s;
+    wide_rep_load<R>(s, sh_r64, sh_r32, q);
+    trace_flush(c.tr, tabC, false);
+    if (live && up.use_trace)
+    {
+      uint32_t *ts = P.trace_state + ((size_t)r * 16 + (size_t)j) * kMaxTrace * 2;
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+      {
+        ts[e * 2] = c.tr.pos[e];
+        ts[e * 2 + 1] = (trace_cnt(c.tr, e) & 0xFFFFu) | (((c.tr.wt >> e) & 1u) << 16);
+      }
+    }
+    uint32_t ic = c.inserted, ia = c.inserted2;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { ic += __shfl_xor(ic, off, 16); ia += __shfl_xor(ia, off, 16); }
+    uint32_t st = c.status | sh_est[q];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+    if (live && j == 0)
+    {
+      ReplicaState &RS = P.states[r];
+      RS.G = s.G;
+      RS.TL = s.TL;
+      RS.ac_decay = s.eps_decay;
+      RS.ac_noise = __longlong_as_double((long long)s.S1);
+      RS.tt = s.tt;
+      RS.ss = s.ss;
+      RS.test_steps = s.test_steps;
+      RS.n_slots[0] += ic;
+      RS.n_slots[1] += ia;
+      RS.rows = s.rows;
+      RS.tr_len = c.tr.len;
+      RS.tr_total = c.tr.total;
+      RS.status = st;
+    }
+  }
+}
+
+} // namespace grlx

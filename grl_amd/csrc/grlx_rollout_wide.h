@@ -10,6 +10,10 @@
 // exactly the code of rollout_kernel -- runs B times, once per sub-batch.  Per replica the arithmetic and its order are
 // unchanged (bit-identical results); a wave-pass costs E + B*Tb instead of B*(E + Tb).
 //
+// Replicas of a wave do not wait for each other at episode ends: each one runs its own sequence of trials (start,
+// steps, drain of the pending update, row) and begins its next trial in the pass after its episode has drained, so a
+// wave idles only at the very end of a launch -- episodes of the acrobot and the walker end at different steps.
+//
 // Between its turns a sub-batch's lane state (register trace, pending update, position of p) is PARKED in LDS
 // (180 B per lane, lane-contiguous 16-byte quads: conflict-free ds_read/write_b128), its per-replica scalars (RNG
 // streams, counters, action) in a small structure-of-arrays; observation / reward / terminal / action travel between
@@ -24,6 +28,9 @@ struct WideLane {                 // table-role state of one lane for one sub-ba
   double    pd_dW, pd_dT, pd_wp;
   uint32_t  pd_pos, p_pos;
   uint32_t  status, inserted;
+  // actor-critic only (AC = true): position of the actor's projection of s, its shared flag, slots created in the actor's table
+  uint32_t  ap_pos, inserted2;
+  bool      ap_sh;
 };
 constexpr int kWideQuads = 11;    // 16-byte quads per parked lane
 
@@ -38,7 +45,8 @@ __device__ __forceinline__ void unpack2d(const uint4 &q, double &a, double &b)
   b = __longlong_as_double((long long)((uint64_t)q.z | ((uint64_t)q.w << 32)));
 }
 
-// sh_ctx: [quad][lane] of this sub-batch; sh_ins: [lane]
+// sh_ctx: [quad][lane] of this sub-batch; sh_ins: [lane] (AC: [3][lane])
+template <bool AC = false>
 __device__ __forceinline__ void wide_park(const WideLane &c, uint4 *sh_ctx, uint32_t *sh_ins, int lane)
 {
   static_assert(kMaxTrace == 10, "the parked layout holds ten trace entries");
@@ -56,11 +64,17 @@ __device__ __forceinline__ void wide_park(const WideLane &c, uint4 *sh_ctx, uint
   {
     const uint64_t uw = (uint64_t)__double_as_longlong(c.pd_wp);
     sh_ctx[10 * 64 + lane] = make_uint4((uint32_t)uw, (uint32_t)(uw >> 32),
-                                        (c.pd ? 1u : 0u) | (c.pd_sh ? 2u : 0u) | (c.p_sh ? 4u : 0u), c.status);
+                                        (c.pd ? 1u : 0u) | (c.pd_sh ? 2u : 0u) | (c.p_sh ? 4u : 0u) | ((AC && c.ap_sh) ? 8u : 0u), c.status);
   }
   sh_ins[lane] = c.inserted;
+  if (AC)
+  {
+    sh_ins[64 + lane] = c.inserted2;
+    sh_ins[128 + lane] = c.ap_pos;
+  }
 }
 
+template <bool AC = false>
 __device__ __forceinline__ void wide_unpark(WideLane &c, const uint4 *sh_ctx, const uint32_t *sh_ins, int lane)
 {
   uint4 q = sh_ctx[0 * 64 + lane];
@@ -86,12 +100,15 @@ __device__ __forceinline__ void wide_unpark(WideLane &c, const uint4 *sh_ctx, co
   c.p_sh = (q.z & 4u) != 0u;
   c.status = q.w;
   c.inserted = sh_ins[lane];
+  c.ap_sh = AC && (q.z & 8u) != 0u;
+  c.inserted2 = AC ? sh_ins[64 + lane] : 0u;
+  c.ap_pos = AC ? sh_ins[128 + lane] : kInvalidPos;
 }
 
 // per-replica scalars of the table role, parked as a structure of arrays [field][replica in wave]
 enum { WR_G = 0, WR_TL, WR_S1, WR_EPS, WR_TT, WR_SS, WR_TSTEPS, WR_TOTAL, WR_TIME, WR_ACTION, WR_FIELDS64 };
-enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_FIELDS32 };
-enum : uint32_t { WF_RUNNING = 1u, WF_FIRST = 2u, WF_TEST = 4u };
+enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_LEFT, WR_FIELDS32 };
+enum : uint32_t { WF_RUNNING = 1u, WF_FIRST = 2u, WF_TEST = 4u, WF_ENDING = 8u };
 
 struct WideRep {
   uint64_t G, TL, S1;
@@ -101,8 +118,10 @@ struct WideRep {
   double   total_reward, time, action;
   int      action_index;
   bool     running, first;
+  bool     ending;              // the episode has seen its terminal state; its row is written once the pending update is applied
   int      test;
   uint32_t rows;
+  int      trials_left;         // trials of this launch the replica has not finished yet
 };
 
 template <int R>
@@ -119,8 +138,9 @@ __device__ __forceinline__ void wide_rep_store(const WideRep &s, uint64_t *sh64,
   sh64[WR_TIME * R + q] = (uint64_t)__double_as_longlong(s.time);
   sh64[WR_ACTION * R + q] = (uint64_t)__double_as_longlong(s.action);
   sh32[WR_AIDX * R + q] = (uint32_t)s.action_index;
-  sh32[WR_FLAGS * R + q] = (s.running ? WF_RUNNING : 0u) | (s.first ? WF_FIRST : 0u) | (s.test ? WF_TEST : 0u);
+  sh32[WR_FLAGS * R + q] = (s.running ? WF_RUNNING : 0u) | (s.first ? WF_FIRST : 0u) | (s.test ? WF_TEST : 0u) | (s.ending ? WF_ENDING : 0u);
   sh32[WR_ROWS * R + q] = s.rows;
+  sh32[WR_LEFT * R + q] = (uint32_t)s.trials_left;
 }
 
 template <int R>
@@ -141,7 +161,9 @@ __device__ __forceinline__ void wide_rep_load(WideRep &s, const uint64_t *sh64, 
   s.running = (f & WF_RUNNING) != 0u;
   s.first = (f & WF_FIRST) != 0u;
   s.test = (f & WF_TEST) ? 1 : 0;
+  s.ending = (f & WF_ENDING) != 0u;
   s.rows = sh32[WR_ROWS * R + q];
+  s.trials_left = (int)sh32[WR_LEFT * R + q];
 }
 
 // B sub-batches of four replicas per wave.  Production ordering only (deferred TD update, no taps, no stamps): the
@@ -220,6 +242,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     c.pd_pos = c.p_pos = kInvalidPos;
     c.status = RS.status;
     c.inserted = 0;
+    c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
     wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
     WideRep s;
     s.G = RS.G; s.TL = RS.TL; s.S1 = RS.S1;
@@ -229,58 +252,29 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     s.total_reward = 0; s.time = 0; s.action = 0;
     s.action_index = 0;
     s.running = false; s.first = true; s.test = 0;
+    s.ending = false;
     s.rows = RS.rows;
+    s.trials_left = live ? n_trials : 0;
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
 
-  for (int trial = 0; trial < n_trials; ++trial)
   {
-    // ---- start of the trial, table role (the start state may draw from the replica's RNG streams)
-    for (int b = 0; b < B; ++b)
-    {
-      const int q = 4 * b + g;
-      const bool live = wave0 + q < P.n_replicas;
-      WideRep s;
-      wide_rep_load<R>(s, sh_r64, sh_r32, q);
-      const int ti = N.test_interval;
-      s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;               // online_learning.cpp:160
-      double xs[S], obs[D];
-#pragma unroll
-      for (int i = 0; i < S; ++i) xs[i] = 0;
-#pragma unroll
-      for (int i = 0; i < D; ++i) obs[i] = 0;
-      if (live)
-      {
-        Env<ENV>::start(N, s.test, s.TL, s.G, xs);                         // modeled.cpp:132-158
-        Env<ENV>::observe(N, xs, obs);
-      }
-      s.total_reward = 0;
-      s.time = 0;
-      s.action = 0;
-      s.action_index = 0;
-      s.running = live;
-      s.first = true;
-      wide_rep_store<R>(s, sh_r64, sh_r32, q);
-#pragma unroll
-      for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
-#pragma unroll
-      for (int i = 0; i < D; ++i) sh_obs[i * R + q] = obs[i];
-      if (j == 0) { sh_step[q] = 0u; sh_term[q] = 0; sh_reward[q] = 0; }
-      // TDAgent::start clears the trace (td.cpp:54): it was flushed at the end of the previous learning trial
-    }
-    wave_sync();
-    if (elive)
-    {
-#pragma unroll
-      for (int i = 0; i < S; ++i) x[i] = sh_x[i * R + eq];
-    }
-
     for (;;)
     {
-      // ================= environment phase: every replica of the wave that is in mid-episode takes its step
+      // ================= environment phase: every replica of the wave that is in mid-episode takes its step;
+      // a replica whose trial has just started takes its start state over from the table role instead (sh_step = 2)
       {
-        const bool step = elive && sh_step[eq] != 0u;
+        const uint32_t todo = elive ? sh_step[eq] : 0u;
+        if (rarely(__any(todo == 2u)))
+        {
+          if (todo == 2u)
+          {
+#pragma unroll
+            for (int i = 0; i < S; ++i) x[i] = sh_x[i * R + eq];
+          }
+        }
+        const bool step = todo == 1u;
         if (__any(step))
         {
           double obs[D], reward = 0;
@@ -291,10 +285,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
           {
             const double action = sh_act[eq];
             env_step<ENV>(N, x, action, obs, reward, terminal, estatus);     // online_learning.cpp:196
-          }
-          wave_sync();                                                         // every lane has read its inputs
-          if (step)
-          { // the 64/R lanes of a replica hold identical values: all of them store (same address, same bits)
+            // the 64/R lanes of a replica hold identical values: all of them store (same address, same bits)
 #pragma unroll
             for (int i = 0; i < D; ++i) sh_obs[i * R + eq] = obs[i];
             sh_reward[eq] = reward;
@@ -317,7 +308,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
         wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
         WideRep s;
         wide_rep_load<R>(s, sh_r64, sh_r32, q);
-        if (!__any(s.running || c.pd)) continue;                             // this sub-batch has finished its episodes
+        if (!__any(s.running || c.pd || s.trials_left > 0)) continue;        // this sub-batch has finished its trials
 
         uint32_t slot[NA];
         Lookup lk[NA];
@@ -523,18 +514,69 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             c.p_pos = pick<uint32_t, NA>(pos, a_next);
             c.p_sh = pick<bool, NA>(sh, a_next);
           }
-          if (!s.first && terminal) s.running = false;
+          if (!s.first && terminal) { s.running = false; s.ending = true; }
           s.first = false;
         }
         if (ev.pos != kInvalidPos) value_store(tab, ev.pos, ev.val);
+
+        // ---- between trials: the episode has ended and its last update has been applied (or none was pending)
+        uint32_t step_next = s.running ? 1u : 0u;
+        const bool between = !s.running && !c.pd && s.trials_left > 0;
+        if (__any(between))
+        {
+          if (between && s.ending)
+          { // end of the trial: write the cached weights back (test trials and the host read the table); the row
+            if (!s.test) trace_flush(c.tr, tab, true);       // the next TDAgent::start clears the trace (td.cpp:54)
+            const int ti = N.test_interval;
+            if (ti >= 0 ? s.test : 1)
+            { // online_learning.cpp:238-262
+              if (s.rows < (uint32_t)P.max_rows)
+              {
+                if (j == 0)
+                {
+                  const size_t at = (size_t)s.rows * (size_t)P.n_replicas + (size_t)r;
+                  P.row_reward[at] = s.total_reward;
+                  P.row_time[at] = s.time;
+                  P.row_steps[at] = s.ss;
+                  P.row_trial[at] = (ti >= 0) ? (s.tt + 1 - (s.tt + 1) / (ti + 1)) : s.tt;
+                }
+                s.rows++;
+              }
+              else
+                c.status |= ST_ROWS_FULL;
+            }
+            s.tt++;
+            s.trials_left--;
+            s.ending = false;
+          }
+          if (between && s.trials_left > 0)
+          { // start of the next trial (the start state may draw from the replica's RNG streams)
+            const int ti = N.test_interval;
+            s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;             // online_learning.cpp:160
+            double xs[S], ob0[D];
+            Env<ENV>::start(N, s.test, s.TL, s.G, xs);                       // modeled.cpp:132-158
+            Env<ENV>::observe(N, xs, ob0);
+#pragma unroll
+            for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
+#pragma unroll
+            for (int i = 0; i < D; ++i) sh_obs[i * R + q] = ob0[i];
+            s.total_reward = 0;
+            s.time = 0;
+            s.action = 0;
+            s.action_index = 0;
+            s.running = true;
+            s.first = true;
+            step_next = 2u;                                                  // environment role: take sh_x over
+          }
+        }
 
         // hand the action to the environment role and park
         if (j == 0 && live)
         {
           sh_act[q] = s.action;
-          sh_step[q] = s.running ? 1u : 0u;
+          sh_step[q] = step_next;
         }
-        more = more || s.running || c.pd;
+        more = more || s.running || c.pd || s.trials_left > 0;
         wide_rep_store<R>(s, sh_r64, sh_r32, q);
         wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
       }
@@ -542,41 +584,6 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
       if (!__any(more)) break;
     }
 
-    // ---- end of the trial: write the cached weights back (test trials and the host read the table); row
-    for (int b = 0; b < B; ++b)
-    {
-      const int q = 4 * b + g;
-      const bool live = wave0 + q < P.n_replicas;
-      const int r = live ? wave0 + q : 0;
-      const Table tab = table_of(P, 0, r);
-      WideLane c;
-      wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
-      WideRep s;
-      wide_rep_load<R>(s, sh_r64, sh_r32, q);
-      if (!s.test) trace_flush(c.tr, tab, true);
-      const int ti = N.test_interval;
-      if (live && (ti >= 0 ? s.test : 1))
-      {
-        if (s.rows < (uint32_t)P.max_rows)
-        {
-          if (j == 0)
-          {
-            const size_t at = (size_t)s.rows * (size_t)P.n_replicas + (size_t)r;
-            P.row_reward[at] = s.total_reward;
-            P.row_time[at] = s.time;
-            P.row_steps[at] = s.ss;
-            P.row_trial[at] = (ti >= 0) ? (s.tt + 1 - (s.tt + 1) / (ti + 1)) : s.tt;
-          }
-          s.rows++;
-        }
-        else
-          c.status |= ST_ROWS_FULL;
-      }
-      s.tt++;
-      wide_rep_store<R>(s, sh_r64, sh_r32, q);
-      wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
-    }
-    wave_sync();
   }
 
   // ---- write the replicas back

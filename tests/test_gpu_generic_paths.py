@@ -215,3 +215,35 @@ def test_wide_waves_are_chosen_for_batches_beyond_four_replicas_per_simd(grlx):
     r = grlx.Runner(grlx.pendulum_sarsa_config(8, replicas_per_wave=8, tap_replica=0, tap_capacity=16), np.arange(8)); assert r.replicas_per_wave() == 4; r.close()
     with pytest.raises(grlx.capi.GrlxError):
         grlx.Runner(grlx.pendulum_sarsa_config(8, replicas_per_wave=16), np.arange(8))
+
+
+@pytest.mark.parametrize("over", [dict(), dict(end_stop_penalty=1, ac_update_method=1, ac_step_limit=0.5)])
+def test_wide_waves_actor_critic_bit_exact(grlx, over):
+    """rollout_ac_wide_kernel: both actor update methods, the end-stop penalty (episodes of one wave end apart), the
+    critic's trace kept across episodes AND launches (three launches), a ragged batch, every replica checked."""
+    from tests import configs
+    n, trials = 13, 24
+    got = {}
+    for rpw in (8, 4):
+        cfg, spec = configs.cart_pole_ac(grlx, n, **over)
+        cfg.replicas_per_wave = rpw
+        cfg.max_rows = trials + 1
+        r = grlx.Runner(cfg, np.arange(201, 201 + n))
+        assert r.replicas_per_wave() == rpw
+        r.run(7); r.run(9); r.run(8); r.sync()
+        rng = np.random.default_rng(9)
+        slots = rng.integers(0, 8388608, 1500).astype(np.uint32)
+        got[rpw] = [(r.rows(k), list(r.rng(k))[:2], r.env_state(k), r.weights(k, slots, 0), r.weights(k, slots, 1)) for k in range(n)]
+        r.close()
+    for k in range(n):
+        e = ob.Experiment(spec, seed=201 + k)
+        rows, _ = e.run(trials)
+        for rpw in (8, 4):
+            (t, s, rew), rg, st, w0, w1 = got[rpw][k]
+            assert list(s) == [x.steps for x in rows], f"rpw {rpw} replica {k}"
+            assert_bit_equal(rew, [x.reward for x in rows], f"rpw {rpw}: returns of replica {k}")
+            assert rg == list(e.rng())[:2]
+            assert_bit_equal(st, e.state(), f"rpw {rpw}: env state of replica {k}")
+            assert_bit_equal(w0, e.weights(slots, 0), f"rpw {rpw}: critic weights of replica {k}")
+            assert_bit_equal(w1, e.weights(slots, 1), f"rpw {rpw}: actor weights of replica {k}")
+        e.close()
