@@ -47,6 +47,13 @@ class Config(C.Structure):
                 ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class FqiConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_replicas", C.c_int32), ("env", C.c_int32), ("integration_steps", C.c_int32),
+                ("control_step", C.c_double), ("timeout", C.c_double), ("action_min", C.c_double), ("action_max", C.c_double),
+                ("action_steps", C.c_int32), ("batch_size", C.c_int32), ("gamma", C.c_double), ("iterations", C.c_int32),
+                ("epochs", C.c_int32), ("hidden", C.c_int32), ("max_batches", C.c_int32)]
+
+
 class Tap(C.Structure):
     _fields_ = [("test", C.c_int32), ("action_index", C.c_int32), ("terminal", C.c_int32), ("trace_len", C.c_int32),
                 ("obs", C.c_double * MAX_DIMS), ("action", C.c_double), ("reward", C.c_double), ("delta", C.c_double),
@@ -96,6 +103,15 @@ _SIGS = {
     "grlx_update": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), _P(C.c_uint32), C.c_int, _P(C.c_double)]),
     "grlx_math": (C.c_int, [C.c_int, _P(C.c_double), _P(C.c_double), C.c_int, _P(C.c_double)]),
     "grlx_rand48_at": (C.c_int, [C.c_int64, _P(C.c_uint64), C.c_int, _P(C.c_double)]),
+    "grlx_fqi_config_pendulum": (None, [_P(FqiConfig)]),
+    "grlx_fqi_create": (C.c_int, [_P(FqiConfig), _P(C.c_int64), _P(C.c_void_p)]),
+    "grlx_fqi_destroy": (C.c_int, [C.c_void_p]),
+    "grlx_fqi_run_batch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grlx_fqi_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grlx_fqi_read_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64), _P(C.c_double)]),
+    "grlx_fqi_get_params": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double), C.c_int]),
+    "grlx_fqi_get_transitions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "grlx_fqi_info": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64), _P(C.c_double), _P(C.c_int32), _P(C.c_double), _P(C.c_uint64)]),
 }
 
 

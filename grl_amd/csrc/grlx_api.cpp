@@ -30,6 +30,11 @@ int fail(int code, const char *fmt, ...)
   return code;
 }
 
+} // namespace
+namespace grlx {
+void set_last_error(const char *msg) { g_err = msg; }     // other translation units of the library (grlx_fqi.hip)
+}
+namespace {
 #define HIP_TRY(expr)                                                                   \
   do {                                                                                  \
     hipError_t e__ = (expr);                                                            \

@@ -1,0 +1,629 @@
+// grlx_fqi.hip -- the batch path (BASELINE.json configs[4]): experiment/batch_learning + predictor/fqi +
+// representation/iterative + representation/parameterized/ann over projector/pre/normalizing, R independent-seed
+// replicas per GPU.  Reference: batch_learning.cpp:88-205, fqi.cpp:187-285, iterative.cpp:63-107, ann.cpp:133-263,
+// normalizing.cpp:78-87, greedy.cpp:47-86.  The operation-by-operation specification (incl. the documented
+// deviations D1-D4 from the unpinnable parts of the reference) is oracle/fqi.c; this file restates it for the GPU.
+//
+// Shape of the work.  A rebuild is `iterations` x (targets + `epochs` x (gradient over all samples + RPROP step)): a
+// long chain of tiny dense passes (3 -> H -> 1 per sample, 2 x 101 parameters) whose only coupling is the gradient
+// sum.  One lane = one sample; the network (101 doubles) sits in LDS; the per-sample gradient stays in registers
+// only as long as it takes to park its factors in LDS, and is summed by the fixed two-level tree of the specification
+// (chunks of 64 samples in sample order -> chunk sums strided over 64 lanes + wave shuffle), independent of the grid.  No contraction here is large enough for MFMA
+// (K = 3 and K = 20, N = 1; a 16x16x4 f64 tile would be 80 % padding) and the chain is bound by launch latency and
+// the reduction, not by FLOPs: see DESIGN.md section 4.3 for the measurement.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "grlx_internal.h"
+#include "grlx_math.h"
+#include "grlx_rng.h"
+#include "grlx_tile.h"
+#include "grlx_table.h"
+#include "grlx_envs.h"
+
+namespace grlx {
+void set_last_error(const char *msg);      // grlx_api.cpp
+
+constexpr int kFqiNIn = 3;                 // task/pendulum/swingup: observation (2) ++ action (1)
+constexpr int kFqiD = 2;
+constexpr int kFqiS = 3;
+
+struct FqiRep {                            // per-replica state between launches
+  uint64_t G, TL;                          // global / thread-local streams (fqi.c: orc_fqi_create)
+  int64_t  n;                              // transitions stored
+  int64_t  batches_done;
+  unsigned long long maxdelta_bits;        // max |target - previous target| of the running iteration (non-negative double)
+  double   maxdelta_last;
+  int32_t  done;                           // the rebuild's iteration loop has ended (maxdelta <= 0.001)
+  int32_t  iterations;                     // iterations executed by the last rebuild
+  uint32_t status;
+  uint32_t rows;
+  double   last_error;
+};
+
+struct FqiParams {
+  DevParams env;                           // h, integration_steps, timeout, randomization of the pendulum
+  int32_t  R, H, P, A, batch_size, cap, chunks_cap;
+  double   actions[kMaxActions];
+  double   in_min[kFqiNIn], in_scale[kFqiNIn], obs_min[kFqiD], obs_range[kFqiD];
+  double   action_min, action_range;
+  double   gamma_tau;
+  FqiRep  *rep;
+  double  *in, *next_obs, *reward, *targets;        // [R][cap][...]
+  int32_t *absorbing;
+  double  *net;                                     // [R][4][P]: params, eta, Delta (unused), prev_Delta
+  double  *partial;                                 // [R][chunks_cap][P + 1]
+  double  *row_reward;                              // [R][max_rows]
+  int64_t *row_batch, *row_transitions;
+  int32_t  max_rows;
+};
+
+// ANNRepresentation::read (ann.cpp:133-160): net input ((w0 a0 + w1 a1) + w2 a2) + bias, logistic hidden layer, linear output
+template <int H>
+__device__ __forceinline__ double ann_forward(const double *w, const double (&in)[kFqiNIn], double *a_out)
+{
+  const double *W2 = w + (kFqiNIn + 1) * H;
+  double out = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+  {
+    double net = 0;
+#pragma unroll
+    for (int i = 0; i < kFqiNIn; ++i) net += w[h * (kFqiNIn + 1) + i] * in[i];
+    net += w[h * (kFqiNIn + 1) + kFqiNIn];
+    const double a = 1. / (1. + pexp(-net));
+    if (a_out) a_out[h] = a;
+    out += W2[h] * a;
+  }
+  out += W2[H];
+  return out;
+}
+
+__device__ __forceinline__ void fqi_normalise(const FqiParams &F, const double *obs, double action, double (&in)[kFqiNIn])
+{ // NormalizingProjector::project (normalizing.cpp:78-87), signed = 0
+#pragma unroll
+  for (int i = 0; i < kFqiD; ++i) in[i] = (obs[i] - F.in_min[i]) * F.in_scale[i] - 0;
+  in[kFqiD] = (action - F.in_min[kFqiD]) * F.in_scale[kFqiD] - 0;
+}
+
+// weights: w[i] = 0.01 * (2 u_i - 1) from the initialisation stream (fqi.c D1); eta = 0.1 (RPROP, ann.cpp:108-109)
+__global__ void fqi_init_kernel(FqiParams F, const uint64_t *r0)
+{
+  const int r = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= F.P) return;
+  double *net = F.net + (size_t)r * 4 * F.P;
+  const uint64_t x = lcg_next(lcg_jump(r0[r], (uint64_t)k));
+  net[k] = (2 * lcg_double(x) - 1) * 0.01;
+  net[F.P + k] = 1. * 0.1;
+  net[2 * F.P + k] = 0;
+  net[3 * F.P + k] = 0;
+}
+
+// BatchLearningExperiment::run, the sampling loop (batch_learning.cpp:107-138): one lane per transition; the
+// replica's thread-local stream is consumed 4 draws per transition in sample order (LCG jump-ahead)
+__global__ __launch_bounds__(256) void fqi_generate_kernel(FqiParams F)
+{
+  const int r = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= F.batch_size) return;
+  const FqiRep &rep = F.rep[r];
+  uint64_t x = lcg_jump(rep.TL, 4ull * (uint64_t)s);
+  double obs[kFqiD];
+#pragma unroll
+  for (int i = 0; i < kFqiD; ++i) { x = lcg_next(x); obs[i] = 0 + lcg_double(x) * (1 - 0); }
+  x = lcg_next(x);
+  double action = 0 + lcg_double(x) * (1 - 0);
+  // (the fourth draw is next_action: consumed, never read by FQI)
+#pragma unroll
+  for (int i = 0; i < kFqiD; ++i) obs[i] = F.obs_min[i] + obs[i] * F.obs_range[i];
+  action = F.action_min + action * F.action_range;
+  double st[kFqiS] = {obs[0] - GRLX_PI, obs[1], 0.};                          // PendulumSwingupTask::invert (pendulum.cpp:147-155)
+  double nobs[kFqiD], reward;
+  int terminal;
+  uint32_t status = 0;
+  env_step<GRLX_ENV_PENDULUM, false>(F.env, st, action, nobs, reward, terminal, status);
+  const size_t at = (size_t)r * (size_t)F.cap + (size_t)rep.n + (size_t)s;
+  double in[kFqiNIn];
+  fqi_normalise(F, obs, action, in);
+#pragma unroll
+  for (int i = 0; i < kFqiNIn; ++i) F.in[at * kFqiNIn + i] = in[i];
+#pragma unroll
+  for (int i = 0; i < kFqiD; ++i) F.next_obs[at * kFqiD + i] = nobs[i];
+  F.reward[at] = reward;
+  F.absorbing[at] = terminal == 2 ? 1 : 0;
+  F.targets[at] = 0.;
+  if (status) atomicOr(&F.rep[r].status, status);
+}
+
+// after the generate kernel: the batch is part of the store, the stream has moved on, a rebuild begins
+__global__ void fqi_batch_begin_kernel(FqiParams F)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= F.R) return;
+  FqiRep &rep = F.rep[r];
+  rep.TL = lcg_jump(rep.TL, 4ull * (uint64_t)F.batch_size);
+  rep.n += F.batch_size;
+  rep.done = 0;
+  rep.iterations = 0;
+  rep.maxdelta_bits = 0x7FF0000000000000ull;                                  // +inf (fqi.cpp:208)
+}
+
+// head of iteration ii of FQIPredictor::rebuild (fqi.cpp:213): `ii < iterations_ && maxdelta > 0.001`
+__global__ void fqi_iter_begin_kernel(FqiParams F, int ii)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= F.R) return;
+  FqiRep &rep = F.rep[r];
+  if (rep.done) return;
+  const double md = __longlong_as_double((long long)rep.maxdelta_bits);
+  rep.maxdelta_last = md;
+  if (!(md > 0.001)) { rep.done = 1; return; }
+  rep.iterations = ii + 1;
+  rep.maxdelta_bits = 0ull;
+}
+
+// targets of one iteration (fqi.cpp:227-262): r + gamma^tau max_a Q(s', a); L-infinity change against the previous targets
+template <int H>
+__global__ __launch_bounds__(256) void fqi_targets_kernel(FqiParams F, int first_iteration)
+{
+  __shared__ double sh_net[(kFqiNIn + 1) * H + H + 1];
+  __shared__ double sh_max[4];
+  const int r = blockIdx.y;
+  const FqiRep &rep = F.rep[r];
+  if (rep.done) return;
+  const double *net = F.net + (size_t)r * 4 * F.P;
+  for (int k = threadIdx.x; k < F.P; k += blockDim.x) sh_net[k] = net[k];
+  __syncthreads();
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double diff = 0;
+  if (s < rep.n)
+  {
+    const size_t at = (size_t)r * (size_t)F.cap + (size_t)s;
+    double target = F.reward[at];
+    if (!F.absorbing[at])
+    {
+      double nobs[kFqiD];
+#pragma unroll
+      for (int i = 0; i < kFqiD; ++i) nobs[i] = F.next_obs[at * kFqiD + i];
+      double v = -__builtin_inf();
+      for (int k = 0; k < F.A; ++k)
+      {
+        double in[kFqiNIn];
+        fqi_normalise(F, nobs, F.actions[k], in);
+        v = fmax(v, ann_forward<H>(sh_net, in, nullptr));
+      }
+      target += F.gamma_tau * v;
+    }
+    const double prev = first_iteration ? 0. : F.targets[at];
+    diff = __builtin_fabs(prev - target);
+    F.targets[at] = target;
+  }
+  // max is order-independent: any reduction gives the reference's value
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) diff = fmax(diff, __shfl_down(diff, off, 64));
+  if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = diff;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const double m = fmax(fmax(sh_max[0], sh_max[1]), fmax(sh_max[2], sh_max[3]));
+    atomicMax(&F.rep[r].maxdelta_bits, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+__device__ __forceinline__ double shfl_down_f64(double v, int off)
+{
+  return __shfl_down(v, off, 64);
+}
+
+// one epoch, part 1 (ann.cpp:224-263 over every sample): block = one wave = a chunk of 64 samples, lane = sample for the
+// forward / backward pass; the lanes then leave their factors (inputs, hidden deltas, activations, output delta: 44
+// doubles, plus a constant 1) in LDS and turn into one lane per PARAMETER, which forms the per-sample products and adds
+// them in sample order -- level 1 of the specification's reduction.  partial[r][chunk][0..P] (P = squared error).
+constexpr int kFqiCols = 2 * 20 + kFqiNIn + 2;       // in[3], d1[H], a[H], d2, 1.0  (H = 20)
+template <int H>
+__global__ __launch_bounds__(64) void fqi_grad_kernel(FqiParams F)
+{
+  static_assert(H == 20, "column layout of the factor tile");
+  constexpr int P = (kFqiNIn + 1) * H + H + 1;
+  constexpr int C_IN = 0, C_D1 = kFqiNIn, C_A = kFqiNIn + H, C_D2 = kFqiNIn + 2 * H, C_ONE = C_D2 + 1, COLS = C_ONE + 1;
+  static_assert(COLS == kFqiCols, "factor tile width");
+  __shared__ double sh_net[P];
+  __shared__ double sh_f[64 * COLS];
+  const int r = blockIdx.y;
+  const FqiRep &rep = F.rep[r];
+  if (rep.done) return;
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  if (c0 >= rep.n) return;
+  const int lane = threadIdx.x;
+  const double *net = F.net + (size_t)r * 4 * F.P;
+  for (int k = lane; k < P; k += 64) sh_net[k] = net[k];
+  __syncthreads();
+  const int64_t s = c0 + lane;
+  double *row = sh_f + lane * COLS;
+  if (s < rep.n)
+  {
+    const size_t at = (size_t)r * (size_t)F.cap + (size_t)s;
+    double in[kFqiNIn], a[H];
+#pragma unroll
+    for (int i = 0; i < kFqiNIn; ++i) in[i] = F.in[at * kFqiNIn + i];
+    const double out = ann_forward<H>(sh_net, in, a);
+    const double d2 = out - F.targets[at];
+    const double *W2 = sh_net + (kFqiNIn + 1) * H;
+#pragma unroll
+    for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+    {
+      row[C_D1 + h] = (W2[h] * d2) * (a[h] * (1. - a[h]));       // ann.cpp:249 with deviation D2
+      row[C_A + h] = a[h];
+    }
+    row[C_D2] = d2;
+    row[C_ONE] = 1.;
+  }
+  __syncthreads();
+  const int n_here = (int)((rep.n - c0 < 64) ? rep.n - c0 : 64);
+  double *out = F.partial + ((size_t)r * (size_t)F.chunks_cap + (size_t)blockIdx.x) * (size_t)(P + 1);
+  for (int p = lane; p <= P; p += 64)
+  { // the two factors of parameter p's per-sample gradient term (x * 1.0 is exact)
+    int cx, cy;
+    if (p < (kFqiNIn + 1) * H)
+    {
+      const int h = p / (kFqiNIn + 1), i = p % (kFqiNIn + 1);
+      cx = (i < kFqiNIn) ? C_IN + i : C_ONE;                      // Delta1(i, h) += a0[i] * d1[h]; bias row: d1[h]
+      cy = C_D1 + h;
+    }
+    else if (p < P - 1) { cx = C_A + (p - (kFqiNIn + 1) * H); cy = C_D2; }   // Delta2(h) += a1[h] * d2
+    else if (p == P - 1) { cx = C_ONE; cy = C_D2; }                          // bias: d2
+    else { cx = C_D2; cy = C_D2; }                                           // squared error (ann.cpp:240)
+    double v = 0.;
+    for (int q = 0; q < n_here; ++q) v += sh_f[q * COLS + cx] * sh_f[q * COLS + cy];
+    out[p] = v;
+  }
+}
+
+// one epoch, part 2: level 3 of the tree (chunk sums strided over 64 lanes, wave reduction) and the RPROP step of
+// ANNRepresentation::finalize (ann.cpp:186-192, 199); one wave per parameter
+__global__ __launch_bounds__(64) void fqi_step_kernel(FqiParams F)
+{
+  const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  FqiRep &rep = F.rep[r];
+  if (rep.done) return;
+  const int64_t chunks = (rep.n + 63) / 64;
+  const double *part = F.partial + (size_t)r * (size_t)F.chunks_cap * (size_t)(F.P + 1);
+  double v = 0.;
+  for (int64_t c = lane; c < chunks; c += 64) v += part[(size_t)c * (size_t)(F.P + 1) + (size_t)k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += shfl_down_f64(v, off);
+  if (lane != 0) return;
+  if (k == F.P) { rep.last_error = v / (double)rep.n; return; }
+  double *net = F.net + (size_t)r * 4 * F.P;
+  const double Delta = 0. + v;                                               // Delta was zero before this epoch (ann.cpp:199)
+  double eta = net[F.P + k];
+  const double prev = net[3 * F.P + k];
+  eta = (Delta * prev > 0) ? eta * 1.2 : eta * 0.5;
+  net[k] -= (Delta > 0) ? eta : -eta;
+  net[F.P + k] = eta;
+  net[3 * F.P + k] = Delta;
+}
+
+// the test trial after a batch (batch_learning.cpp:141-186): agent/fixed + policy/discrete/q + sampler/greedy; one lane per replica
+template <int H>
+__global__ __launch_bounds__(64) void fqi_test_kernel(FqiParams F)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= F.R) return;
+  FqiRep &rep = F.rep[r];
+  const double *net = F.net + (size_t)r * 4 * F.P;
+  uint64_t TL = rep.TL, G = rep.G;
+  double x[kFqiS], obs[kFqiD], reward = 0, total = 0;
+  int terminal = 0;
+  uint32_t status = 0;
+  Env<GRLX_ENV_PENDULUM>::start(F.env, 1, TL, G, x);
+  Env<GRLX_ENV_PENDULUM>::observe(F.env, x, obs);
+  for (int guard = 0; guard < GRLX_MAX_EPISODE_STEPS + 2; ++guard)
+  {
+    double q[kMaxActions];
+    for (int k = 0; k < F.A; ++k)
+    {
+      double in[kFqiNIn];
+      fqi_normalise(F, obs, F.actions[k], in);
+      q[k] = ann_forward<H>(net, in, nullptr);
+    }
+    int mai = 0, man = 1;                                                    // GreedySampler::sample (greedy.cpp:47-86)
+    for (int k = 1; k < F.A; ++k)
+    {
+      if (q[k] > q[mai]) { mai = k; man = 1; }
+      else if (q[k] == q[mai]) man++;
+    }
+    if (man > 1)
+    {
+      G = lcg_next(G);
+      int jj = (int)(lcg_long(G) % (uint32_t)man);
+      for (int k = 0; k < F.A; ++k)
+        if (q[k] == q[mai])
+        {
+          if (jj == 0) { mai = k; break; }
+          --jj;
+        }
+    }
+    if (terminal) break;
+    env_step<GRLX_ENV_PENDULUM, false>(F.env, x, F.actions[mai], obs, reward, terminal, status);
+    total += reward;
+    if (terminal == 2) break;
+  }
+  if (rep.rows < (uint32_t)F.max_rows)
+  {
+    const size_t at = (size_t)r * (size_t)F.max_rows + rep.rows;
+    F.row_reward[at] = total;
+    F.row_batch[at] = rep.batches_done;
+    F.row_transitions[at] = rep.batches_done * (int64_t)F.batch_size;
+    rep.rows++;
+  }
+  else
+    status |= ST_ROWS_FULL;
+  rep.batches_done++;
+  rep.TL = TL;
+  rep.G = G;
+  rep.status |= status;
+}
+
+} // namespace grlx
+
+using namespace grlx;
+
+struct grlx_fqi_ctx {
+  grlx_fqi_config cfg;
+  FqiParams F;
+  std::vector<void *> bufs;
+  uint64_t *r0 = nullptr;
+  int batches_run = 0;
+};
+
+namespace {
+int ffail(int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  set_last_error(buf);
+  return code;
+}
+#define FQI_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess) return ffail(GRLX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+constexpr uint64_t kA = 0x5DEECE66DULL, kC = 0xBULL, kM = (1ULL << 48) - 1;
+inline uint64_t h_seed(long s) { return ((((uint64_t)s) & 0xFFFFFFFFULL) << 16) | 0x330EULL; }
+inline uint64_t h_next(uint64_t x) { return (kA * x + kC) & kM; }
+
+template <typename T> int dev_alloc(grlx_fqi_ctx *ctx, T **p, size_t n)
+{
+  void *q = nullptr;
+  if (hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : 8) != hipSuccess) return ffail(GRLX_ERR_OOM, "out of device memory (%zu bytes)", n * sizeof(T));
+  if (hipMemset(q, 0, n * sizeof(T)) != hipSuccess) return ffail(GRLX_ERR_HIP, "hipMemset failed");
+  ctx->bufs.push_back(q);
+  *p = (T *)q;
+  return GRLX_OK;
+}
+} // namespace
+
+extern "C" {
+
+void grlx_fqi_config_pendulum(grlx_fqi_config *c)
+{ // the reference's tests/pendulum-fqi-ann.yaml
+  memset(c, 0, sizeof(*c));
+  c->struct_size = sizeof(grlx_fqi_config);
+  c->n_replicas = 1;
+  c->env = GRLX_ENV_PENDULUM;
+  c->control_step = 0.03;
+  c->integration_steps = 5;
+  c->timeout = 2.99;
+  c->action_min = -3;
+  c->action_max = 3;
+  c->action_steps = 3;
+  c->gamma = 0.97;
+  c->batch_size = 1000;
+  c->max_batches = 2;
+  c->iterations = 10;
+  c->epochs = 500;
+  c->hidden = 20;
+}
+
+int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_ctx **out)
+{
+  if (!cfg || !seeds || !out) return ffail(GRLX_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(grlx_fqi_config)) return ffail(GRLX_ERR_INVALID, "grlx_fqi_config.struct_size mismatch");
+  if (cfg->env != GRLX_ENV_PENDULUM) return ffail(GRLX_ERR_INVALID, "experiment/batch_learning: the task must support invert(); built for task/pendulum/swingup");
+  if (cfg->hidden != 20) return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:hiddens = [%d] is not built (instantiated: [20])", cfg->hidden);
+  if (cfg->n_replicas < 1 || cfg->batch_size < 1 || cfg->max_batches < 1 || cfg->iterations < 1 || cfg->epochs < 0)
+    return ffail(GRLX_ERR_INVALID, "n_replicas, batch_size, max_batches, iterations must be >= 1");
+  if (cfg->action_steps < 1 || cfg->action_steps > GRLX_MAX_ACTIONS) return ffail(GRLX_ERR_INVALID, "discretizer/uniform:steps");
+  if (!(cfg->action_min < cfg->action_max) || !(cfg->control_step > 0) || cfg->integration_steps < 1 || !std::isfinite(cfg->timeout) || cfg->timeout < 0)
+    return ffail(GRLX_ERR_INVALID, "model / task parameters");
+  if (std::ceil(cfg->timeout / cfg->control_step) + 1 > (double)GRLX_MAX_EPISODE_STEPS) return ffail(GRLX_ERR_INVALID, "task:timeout exceeds GRLX_MAX_EPISODE_STEPS");
+  if ((double)cfg->batch_size * cfg->max_batches > 2e8) return ffail(GRLX_ERR_INVALID, "transition store too large");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void)hipGetLastError(); return ffail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback"); }
+
+  grlx_fqi_ctx *ctx = new grlx_fqi_ctx();
+  ctx->cfg = *cfg;
+  FqiParams &F = ctx->F;
+  memset(&F, 0, sizeof(F));
+  F.env.env = GRLX_ENV_PENDULUM;
+  F.env.integration_steps = cfg->integration_steps;
+  F.env.h = cfg->control_step / (double)(size_t)cfg->integration_steps;
+  F.env.timeout = cfg->timeout;
+  F.env.randomization = 0;
+  F.R = cfg->n_replicas;
+  F.H = cfg->hidden;
+  F.P = (kFqiNIn + 1) * F.H + F.H + 1;
+  F.A = cfg->action_steps;
+  F.batch_size = cfg->batch_size;
+  F.cap = cfg->batch_size * cfg->max_batches;
+  F.chunks_cap = (F.cap + 63) / 64;
+  F.max_rows = cfg->max_batches;
+  {
+    const double range = cfg->action_max - cfg->action_min;
+    double delta = range / ((double)cfg->action_steps - 1);
+    if (std::isnan(delta)) delta = 0.;
+    for (int k = 0; k < cfg->action_steps; ++k) F.actions[k] = cfg->action_min + delta * k;
+  }
+  const double omin[2] = {0., -12 * M_PI}, omax[2] = {2 * M_PI, 12 * M_PI};      // pendulum.cpp:84-85
+  for (int i = 0; i < kFqiD; ++i)
+  {
+    F.obs_min[i] = omin[i];
+    F.obs_range[i] = omax[i] - omin[i];
+    F.in_min[i] = omin[i];
+    F.in_scale[i] = 1. / (omax[i] - omin[i]) * (1 + 0);
+  }
+  F.action_min = cfg->action_min;
+  F.action_range = cfg->action_max - cfg->action_min;
+  F.in_min[kFqiD] = cfg->action_min;
+  F.in_scale[kFqiD] = 1. / (cfg->action_max - cfg->action_min) * (1 + 0);
+  F.gamma_tau = pow(cfg->gamma, cfg->control_step);                               // pow(gamma_, tau), tau = control_step
+
+  const size_t R = (size_t)F.R, cap = (size_t)F.cap;
+  int rc = GRLX_OK;
+  if ((rc = dev_alloc(ctx, &F.rep, R)) != GRLX_OK || (rc = dev_alloc(ctx, &F.in, R * cap * kFqiNIn)) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.next_obs, R * cap * kFqiD)) != GRLX_OK || (rc = dev_alloc(ctx, &F.reward, R * cap)) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.targets, R * cap)) != GRLX_OK || (rc = dev_alloc(ctx, &F.absorbing, R * cap)) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.net, R * 4 * (size_t)F.P)) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.partial, R * (size_t)F.chunks_cap * (size_t)(F.P + 1))) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.row_reward, R * (size_t)F.max_rows)) != GRLX_OK || (rc = dev_alloc(ctx, &F.row_batch, R * (size_t)F.max_rows)) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.row_transitions, R * (size_t)F.max_rows)) != GRLX_OK || (rc = dev_alloc(ctx, &ctx->r0, R)) != GRLX_OK)
+  {
+    grlx_fqi_destroy(ctx);
+    return rc;
+  }
+  // instantiate order of the yaml (oracle/fqi.c: orc_fqi_create): sampler/greedy Rand = global lrand48 #1, the
+  // thread-local RandGen = global lrand48 #2; the weight-initialisation stream of deviation D1 = srand48_r(seed)
+  std::vector<FqiRep> hr(R);
+  std::vector<uint64_t> hr0(R);
+  for (size_t r = 0; r < R; ++r)
+  {
+    memset(&hr[r], 0, sizeof(FqiRep));
+    uint64_t G = h_seed((long)seeds[r]);
+    G = h_next(G);                                   // sampler's private Rand (never drawn from: ties use the global stream)
+    G = h_next(G);
+    hr[r].TL = h_seed((long)(G >> 17));
+    hr[r].G = G;
+    hr0[r] = h_seed((long)seeds[r]);
+  }
+  if (hipMemcpy(F.rep, hr.data(), sizeof(FqiRep) * R, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ctx->r0, hr0.data(), sizeof(uint64_t) * R, hipMemcpyHostToDevice) != hipSuccess)
+  {
+    grlx_fqi_destroy(ctx);
+    return ffail(GRLX_ERR_HIP, "hipMemcpy failed");
+  }
+  hipLaunchKernelGGL(fqi_init_kernel, dim3((F.P + 127) / 128, F.R), dim3(128), 0, nullptr, F, ctx->r0);
+  if (hipDeviceSynchronize() != hipSuccess)
+  {
+    grlx_fqi_destroy(ctx);
+    return ffail(GRLX_ERR_HIP, "fqi_init_kernel failed");
+  }
+  *out = ctx;
+  return GRLX_OK;
+}
+
+int grlx_fqi_destroy(grlx_fqi_ctx *ctx)
+{
+  if (!ctx) return GRLX_OK;
+  for (void *p : ctx->bufs) (void)hipFree(p);
+  delete ctx;
+  return GRLX_OK;
+}
+
+int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
+{
+  if (!ctx) return ffail(GRLX_ERR_INVALID, "null ctx");
+  if (ctx->batches_run >= ctx->cfg.max_batches) return ffail(GRLX_ERR_ROWS_FULL, "more batches than max_batches");
+  hipStream_t stream = (hipStream_t)stream_;
+  const FqiParams &F = ctx->F;
+  const int n_after = (ctx->batches_run + 1) * F.batch_size;
+  const int chunks = (n_after + 255) / 256, gchunks = (n_after + 63) / 64;
+  hipLaunchKernelGGL(fqi_generate_kernel, dim3((F.batch_size + 255) / 256, F.R), dim3(256), 0, stream, F);
+  hipLaunchKernelGGL(fqi_batch_begin_kernel, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
+  for (int ii = 0; ii < ctx->cfg.iterations; ++ii)
+  {
+    hipLaunchKernelGGL(fqi_iter_begin_kernel, dim3((F.R + 63) / 64), dim3(64), 0, stream, F, ii);
+    hipLaunchKernelGGL(fqi_targets_kernel<20>, dim3(chunks, F.R), dim3(256), 0, stream, F, ii == 0 ? 1 : 0);
+    for (int e = 0; e < ctx->cfg.epochs; ++e)
+    {
+      hipLaunchKernelGGL(fqi_grad_kernel<20>, dim3(gchunks, F.R), dim3(64), 0, stream, F);
+      hipLaunchKernelGGL(fqi_step_kernel, dim3(F.P + 1, F.R), dim3(64), 0, stream, F);
+    }
+  }
+  hipLaunchKernelGGL(fqi_test_kernel<20>, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
+  FQI_TRY(hipGetLastError());
+  ctx->batches_run++;
+  return GRLX_OK;
+}
+
+int grlx_fqi_sync(grlx_fqi_ctx *ctx, void *stream)
+{
+  if (!ctx) return ffail(GRLX_ERR_INVALID, "null ctx");
+  FQI_TRY(hipStreamSynchronize((hipStream_t)stream));
+  std::vector<FqiRep> hr((size_t)ctx->F.R);
+  FQI_TRY(hipMemcpy(hr.data(), ctx->F.rep, sizeof(FqiRep) * hr.size(), hipMemcpyDeviceToHost));
+  uint32_t st = 0;
+  for (const FqiRep &r : hr) st |= r.status;
+  if (st & ST_DOMAIN) return ffail(GRLX_ERR_DOMAIN, "sin/cos argument outside |x| < 2^20");
+  if (st & ST_ROWS_FULL) return ffail(GRLX_ERR_ROWS_FULL, "more batches than max_batches");
+  return GRLX_OK;
+}
+
+int grlx_fqi_read_rows(grlx_fqi_ctx *ctx, int replica, int first, int count, int64_t *batch, int64_t *transitions, double *reward)
+{
+  if (!ctx || replica < 0 || replica >= ctx->F.R || first < 0 || count < 0 || first + count > ctx->F.max_rows) return ffail(GRLX_ERR_INVALID, "bad argument");
+  if (count == 0) return GRLX_OK;
+  FQI_TRY(hipDeviceSynchronize());
+  const size_t at = (size_t)replica * (size_t)ctx->F.max_rows + (size_t)first;
+  if (batch) FQI_TRY(hipMemcpy(batch, ctx->F.row_batch + at, sizeof(int64_t) * (size_t)count, hipMemcpyDeviceToHost));
+  if (transitions) FQI_TRY(hipMemcpy(transitions, ctx->F.row_transitions + at, sizeof(int64_t) * (size_t)count, hipMemcpyDeviceToHost));
+  if (reward) FQI_TRY(hipMemcpy(reward, ctx->F.row_reward + at, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_fqi_get_params(grlx_fqi_ctx *ctx, int replica, double *out, int n)
+{
+  if (!ctx || !out || replica < 0 || replica >= ctx->F.R || n != ctx->F.P) return ffail(GRLX_ERR_INVALID, "bad argument (the network has %d parameters)", ctx ? ctx->F.P : 0);
+  FQI_TRY(hipDeviceSynchronize());
+  FQI_TRY(hipMemcpy(out, ctx->F.net + (size_t)replica * 4 * (size_t)ctx->F.P, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_fqi_get_transitions(grlx_fqi_ctx *ctx, int replica, int first, int count, double *in, double *next_obs, double *reward, double *targets)
+{
+  if (!ctx || replica < 0 || replica >= ctx->F.R || first < 0 || count < 0 || first + count > ctx->F.cap) return ffail(GRLX_ERR_INVALID, "bad argument");
+  if (count == 0) return GRLX_OK;
+  FQI_TRY(hipDeviceSynchronize());
+  const size_t at = (size_t)replica * (size_t)ctx->F.cap + (size_t)first;
+  if (in) FQI_TRY(hipMemcpy(in, ctx->F.in + at * kFqiNIn, sizeof(double) * (size_t)count * kFqiNIn, hipMemcpyDeviceToHost));
+  if (next_obs) FQI_TRY(hipMemcpy(next_obs, ctx->F.next_obs + at * kFqiD, sizeof(double) * (size_t)count * kFqiD, hipMemcpyDeviceToHost));
+  if (reward) FQI_TRY(hipMemcpy(reward, ctx->F.reward + at, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  if (targets) FQI_TRY(hipMemcpy(targets, ctx->F.targets + at, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_fqi_info(grlx_fqi_ctx *ctx, int replica, int64_t *n_transitions, double *maxdelta, int32_t *iterations, double *error, uint64_t rng[2])
+{
+  if (!ctx || replica < 0 || replica >= ctx->F.R) return ffail(GRLX_ERR_INVALID, "bad argument");
+  FQI_TRY(hipDeviceSynchronize());
+  FqiRep r;
+  FQI_TRY(hipMemcpy(&r, ctx->F.rep + replica, sizeof(r), hipMemcpyDeviceToHost));
+  if (n_transitions) *n_transitions = r.n;
+  if (maxdelta) *maxdelta = r.done ? r.maxdelta_last : __builtin_bit_cast(double, r.maxdelta_bits);
+  if (iterations) *iterations = r.iterations;
+  if (error) *error = r.last_error;
+  if (rng) { rng[0] = r.G; rng[1] = r.TL; }
+  return GRLX_OK;
+}
+
+} // extern "C"

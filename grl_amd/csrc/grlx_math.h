@@ -388,6 +388,38 @@ __device__ __forceinline__ double plog(double x)
   return __builtin_fma(dk, 0x1.62e4200000000p-1, 2.0 * s + lo);
 }
 
+// pexp(x) (the logistic activation of representation/parameterized/ann, ann.h:108-111): k = rint(x*LOG2E);
+// r = fma(-k, LN2_LO, fma(-k, LN2_HI, x)); q = Horner (fma) over 1/13! .. 1/2!; e = 1 + fma(r*r, q, r);
+// result (e * 2^(k/2)) * 2^(k - k/2).  The specification is oracle/portable_math.c: orc_pexp.
+__device__ __forceinline__ double ppow2(int k)
+{
+  return __longlong_as_double((long long)((unsigned long long)(k + 1023) << 52));
+}
+__device__ __forceinline__ double pexp(double x)
+{
+  if (x != x) return __builtin_nan("");
+  if (x > 709.782712893384) return __builtin_inf();
+  if (x < -745.2) return 0.0;
+  const double kd = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(-kd, 0x1.62e4200000000p-1, x);
+  r = __builtin_fma(-kd, 0x1.fdf473de6af28p-22, r);
+  double q = 1.0 / 6227020800.0;
+  q = __builtin_fma(r, q, 1.0 / 479001600.0);
+  q = __builtin_fma(r, q, 1.0 / 39916800.0);
+  q = __builtin_fma(r, q, 1.0 / 3628800.0);
+  q = __builtin_fma(r, q, 1.0 / 362880.0);
+  q = __builtin_fma(r, q, 1.0 / 40320.0);
+  q = __builtin_fma(r, q, 1.0 / 5040.0);
+  q = __builtin_fma(r, q, 1.0 / 720.0);
+  q = __builtin_fma(r, q, 1.0 / 120.0);
+  q = __builtin_fma(r, q, 1.0 / 24.0);
+  q = __builtin_fma(r, q, 1.0 / 6.0);
+  q = __builtin_fma(r, q, 0.5);
+  const double e = 1.0 + __builtin_fma(r * r, q, r);
+  const int k = (int)kd, k1 = k / 2, k2 = k - k1;
+  return (e * ppow2(k1)) * ppow2(k2);
+}
+
 // fmod(x, y) for finite x, y > 0: exact by definition (IEEE remainder toward
 // zero); long division by exactly representable multiples of y.  Each
 // subtraction is exact (Sterbenz), so the result equals libm's fmod bit for bit.

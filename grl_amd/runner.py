@@ -212,6 +212,71 @@ class Runner:
         capi.check(self.lib.grlx_update(self._ctx, table, _ptr(replica, C.c_int32), _ptr(idx, C.c_uint32), replica.size, _ptr(delta, C.c_double)))
 
 
+def pendulum_fqi_config(n_replicas=1, **overrides) -> capi.FqiConfig:
+    """Config of the reference's tests/pendulum-fqi-ann.yaml (experiment/batch_learning + predictor/fqi + ANN)."""
+    lib = capi.load()
+    cfg = capi.FqiConfig()
+    lib.grlx_fqi_config_pendulum(C.byref(cfg))
+    cfg.n_replicas = n_replicas
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class FqiRunner:
+    """N independent-seed replicas of the batch-learning experiment (fitted Q-iteration over a 3-H-1 network) on the
+    current GPU: include/grlx.h, grlx_fqi_*."""
+
+    def __init__(self, cfg: capi.FqiConfig, seeds):
+        self.lib = capi.load()
+        self.cfg = cfg
+        seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+        if seeds.shape != (cfg.n_replicas,):
+            raise ValueError("need one seed per replica")
+        self._ctx = C.c_void_p()
+        capi.check(self.lib.grlx_fqi_create(C.byref(cfg), _ptr(seeds, C.c_int64), C.byref(self._ctx)))
+        self.n_params = 4 * cfg.hidden + cfg.hidden + 1
+
+    def close(self):
+        if self._ctx:
+            self.lib.grlx_fqi_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_batch(self, stream: int = 0):
+        capi.check(self.lib.grlx_fqi_run_batch(self._ctx, C.c_void_p(stream)))
+
+    def sync(self, stream: int = 0):
+        capi.check(self.lib.grlx_fqi_sync(self._ctx, C.c_void_p(stream)))
+
+    def rows(self, replica: int, count: int):
+        b = np.zeros(count, np.int64); t = np.zeros(count, np.int64); rew = np.zeros(count, np.float64)
+        capi.check(self.lib.grlx_fqi_read_rows(self._ctx, replica, 0, count, _ptr(b, C.c_int64), _ptr(t, C.c_int64), _ptr(rew, C.c_double)))
+        return b, t, rew
+
+    def params(self, replica: int):
+        out = np.zeros(self.n_params, np.float64)
+        capi.check(self.lib.grlx_fqi_get_params(self._ctx, replica, _ptr(out, C.c_double), out.size))
+        return out
+
+    def transitions(self, replica: int, first: int, count: int):
+        inp = np.zeros((count, 3), np.float64); nobs = np.zeros((count, 2), np.float64)
+        rew = np.zeros(count, np.float64); tgt = np.zeros(count, np.float64)
+        capi.check(self.lib.grlx_fqi_get_transitions(self._ctx, replica, first, count, _ptr(inp, C.c_double), _ptr(nobs, C.c_double),
+                                                     _ptr(rew, C.c_double), _ptr(tgt, C.c_double)))
+        return inp, nobs, rew, tgt
+
+    def info(self, replica: int):
+        n = C.c_int64(); md = C.c_double(); it = C.c_int32(); err = C.c_double(); rng = (C.c_uint64 * 2)()
+        capi.check(self.lib.grlx_fqi_info(self._ctx, replica, C.byref(n), C.byref(md), C.byref(it), C.byref(err), rng))
+        return dict(n=n.value, maxdelta=md.value, iterations=it.value, error=err.value, rng=[rng[0], rng[1]])
+
+
 # ---- stateless batched operators --------------------------------------------
 def project(spec: capi.TileSpec, x):
     """Projector::project (TileCodingProjector::_project) for a batch of inputs."""

@@ -262,6 +262,51 @@ int  grlx_math(int op, const double *x, const double *y, int n, double *out);
  * out[n] = drand48 of the stream seeded by srand48(seed) after `skip[i]` draws. */
 int  grlx_rand48_at(int64_t seed, const uint64_t *skip, int n, double *out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The batch path (BASELINE.json configs[4]): experiment/batch_learning + predictor/fqi + representation/iterative +
+ * representation/parameterized/ann over projector/pre/normalizing, as the reference's tests/pendulum-fqi-ann.yaml
+ * composes them; n_replicas independent-seed copies per GPU.
+ * PARITY UNPINNED: the reference's ANN initialisation (Eigen's Random over libc rand(), ann.cpp:97) and its
+ * hidden-layer delta (mismatched Eigen dimensions, ann.cpp:249) cannot be reproduced; the four documented
+ * deviations are listed at the top of oracle/fqi.c and in DESIGN.md.  Everything else follows the cited lines. */
+typedef struct {
+  uint32_t struct_size;               /* = sizeof(grlx_fqi_config)                                                */
+  int32_t  n_replicas;
+  int32_t  env;                       /* GRLX_ENV_PENDULUM (the task must support invert(), pendulum.cpp:147-155) */
+  int32_t  integration_steps;         /* model/dynamical                                                          */
+  double   control_step;
+  double   timeout;                   /* task/pendulum/swingup                                                    */
+  double   action_min, action_max;    /* discretizer/uniform over the task's action range                         */
+  int32_t  action_steps;
+  int32_t  batch_size;                /* experiment/batch_learning:batch_size (transitions drawn per batch)       */
+  double   gamma;                     /* predictor/fqi                                                            */
+  int32_t  iterations;
+  int32_t  epochs;                    /* representation/iterative:epochs                                          */
+  int32_t  hidden;                    /* representation/parameterized/ann:hiddens = [hidden]; eta = 0 (RPROP)     */
+  int32_t  max_batches;               /* batches reserved (transition store and rows): experiment:batches         */
+} grlx_fqi_config;
+typedef struct grlx_fqi_ctx grlx_fqi_ctx;
+/* Fill *cfg with the values of the reference's tests/pendulum-fqi-ann.yaml. */
+void grlx_fqi_config_pendulum(grlx_fqi_config *cfg);
+/* Replaces Configurator::instantiate of that experiment for n_replicas clones after srand48(seeds[r]). */
+int  grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_ctx **out);
+int  grlx_fqi_destroy(grlx_fqi_ctx *ctx);
+/* Replaces one pass of the batch loop of BatchLearningExperiment::run (batch_learning.cpp:105-188) for every replica:
+ * batch_size random transitions (one model step each), FQIPredictor::rebuild over the whole store (fqi.cpp:205-285),
+ * one greedy test trial -> one row.  Asynchronous on `stream`. */
+int  grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream);
+int  grlx_fqi_sync(grlx_fqi_ctx *ctx, void *stream);
+/* rows of `<output>-<run>.txt` (batch_learning.cpp:179): batch, batch*batch_size, return of the test trial */
+int  grlx_fqi_read_rows(grlx_fqi_ctx *ctx, int replica, int first, int count, int64_t *batch, int64_t *transitions, double *reward);
+/* ANNRepresentation::params_: layer 1 (inputs+1) x hidden column-major, then layer 2 (hidden+1) x 1; n must match */
+int  grlx_fqi_get_params(grlx_fqi_ctx *ctx, int replica, double *out, int n);
+/* the transition store (FQIPredictor::transitions_) as the kernels hold it: normalised (obs, action) inputs [count][3],
+ * next observations [count][2], rewards, and the targets of the last iteration; any pointer may be NULL */
+int  grlx_fqi_get_transitions(grlx_fqi_ctx *ctx, int replica, int first, int count, double *in, double *next_obs, double *reward, double *targets);
+/* state of a replica after the last batch: transitions stored, L-infinity target change and iteration count of the last
+ * rebuild (fqi.cpp:213), mean squared error of its last epoch (ann.cpp:201), RNG streams {global, thread-local} */
+int  grlx_fqi_info(grlx_fqi_ctx *ctx, int replica, int64_t *n_transitions, double *maxdelta, int32_t *iterations, double *error, uint64_t rng[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,7 @@ void     orc_rand48_jump(orc_rand48 *g, uint64_t n);
 double orc_psin(double x);
 double orc_pcos(double x);
 double orc_plog(double x);
+double orc_pexp(double x);     /* logistic activation of the ANN representation (ann.h:108-111) */
 
 enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };
 
@@ -212,6 +213,30 @@ int orc_format_row(const orc_row *r, char *buf, size_t cap);
  * by `tl_seed` (= the lrand48() draw) *before* any other TL draw. */
 double orc_lazy_weight(uint32_t tl_seed, uint64_t draws_before, uint32_t slot,
                        double init_min, double init_max);
+
+/* ------------------------------------------------------- batch path (FQI) -- */
+/* experiment/batch_learning + predictor/fqi + representation/iterative + representation/parameterized/ann over
+ * projector/pre/normalizing (tests/pendulum-fqi-ann.yaml; BASELINE configs[4]).  fqi.c: PARITY UNPINNED, deviations D1-D4. */
+typedef struct {
+  orc_spec base;          /* env (pendulum), control_step, integration_steps, timeout, action_min/max/steps, gamma, math */
+  int      batch_size;    /* experiment/batch_learning:batch_size: transitions drawn per batch                          */
+  int      iterations;    /* predictor/fqi:iterations                                                                   */
+  int      epochs;        /* representation/iterative:epochs                                                            */
+  int      hidden;        /* representation/parameterized/ann:hiddens = [hidden]; eta = 0 (RPROP)                       */
+  int      sum_order;     /* 0: gradient summed in sample order (the reference); 1: the GPU's fixed tree (fqi.c D3)     */
+  double   gamma_tau;     /* pow(gamma, control_step), evaluated once by the caller with libm                           */
+} orc_fqi_spec;
+typedef struct orc_fqi orc_fqi;
+void     orc_fqi_spec_pendulum(orc_fqi_spec *s);                 /* the reference's tests/pendulum-fqi-ann.yaml */
+orc_fqi *orc_fqi_create(const orc_fqi_spec *spec, long seed);
+void     orc_fqi_destroy(orc_fqi *f);
+/* one batch: draw batch_size transitions, FQIPredictor::rebuild, one greedy test trial -> *row (batch, transitions, return) */
+int      orc_fqi_run_batch(orc_fqi *f, orc_row *row);
+const double *orc_fqi_params(const orc_fqi *f, int *n);          /* layer 1 (n_in+1) x H column-major, then layer 2 (H+1) x 1 */
+size_t   orc_fqi_transitions(const orc_fqi *f, const double **in, const double **next_obs, const double **reward, const double **targets);
+void     orc_fqi_info(const orc_fqi *f, double *maxdelta, int *iterations, double *error);
+double   orc_fqi_q(const orc_fqi *f, const double *obs, double action);
+void     orc_fqi_rng(const orc_fqi *f, uint64_t out[3]);         /* G, TL, weight-init stream */
 
 #ifdef __cplusplus
 }

@@ -178,3 +178,42 @@ double orc_plog(double x)
   double lo = fma(dk, PM_LN2_LO, fma(s * z, R, 2.0 * sl));
   return fma(dk, PM_LN2_HI, 2.0 * s + lo);
 }
+
+/* pexp(x) -- the logistic activation of representation/parameterized/ann needs exp (ann.h:108-111).
+ * Specification: k = rint(x*LOG2E); r = fma(-k, LN2_LO, fma(-k, LN2_HI, x))  [k*LN2_HI is exact: LN2_HI has 21
+ * trailing zero bits]; q = Horner with fma over the Taylor coefficients 1/13! .. 1/2! (each the correctly rounded
+ * quotient 1.0/n!, n! exact in binary64); e = 1 + fma(r*r, q, r); result = (e * 2^k1) * 2^k2 with k1 = k/2 (C integer
+ * division), k2 = k - k1 (both powers of two are normal numbers; only the last multiplication can round).
+ * NaN -> NaN; x > 709.782712893384 -> +inf; x < -745.2 -> +0. */
+static double pm_pow2(int k)
+{
+  uint64_t b = (uint64_t)(k + 1023) << 52;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+
+double orc_pexp(double x)
+{
+  if (x != x) return NAN;
+  if (x > 709.782712893384) return INFINITY;
+  if (x < -745.2) return 0.0;
+  const double kd = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-kd, PM_LN2_HI, x);
+  r = fma(-kd, PM_LN2_LO, r);
+  double q = 1.0 / 6227020800.0;
+  q = fma(r, q, 1.0 / 479001600.0);
+  q = fma(r, q, 1.0 / 39916800.0);
+  q = fma(r, q, 1.0 / 3628800.0);
+  q = fma(r, q, 1.0 / 362880.0);
+  q = fma(r, q, 1.0 / 40320.0);
+  q = fma(r, q, 1.0 / 5040.0);
+  q = fma(r, q, 1.0 / 720.0);
+  q = fma(r, q, 1.0 / 120.0);
+  q = fma(r, q, 1.0 / 24.0);
+  q = fma(r, q, 1.0 / 6.0);
+  q = fma(r, q, 0.5);
+  const double e = 1.0 + fma(r * r, q, r);
+  const int k = (int)kd, k1 = k / 2, k2 = k - k1;
+  return (e * pm_pow2(k1)) * pm_pow2(k2);
+}

@@ -46,6 +46,11 @@ class Spec(C.Structure):
                 ("pid_p", C.c_double * MAX_DIMS), ("pid_setpoint", C.c_double * MAX_DIMS)]
 
 
+class FqiSpec(C.Structure):
+    _fields_ = [("base", Spec), ("batch_size", C.c_int), ("iterations", C.c_int), ("epochs", C.c_int), ("hidden", C.c_int),
+                ("sum_order", C.c_int), ("gamma_tau", C.c_double)]
+
+
 class Row(C.Structure):
     _fields_ = [("trial", C.c_int64), ("steps", C.c_int64), ("reward", C.c_double), ("time", C.c_double)]
 
@@ -104,6 +109,16 @@ def load():
     L.orc_format_row.argtypes = [P(Row), C.c_char_p, C.c_size_t]; L.orc_format_row.restype = C.c_int
     L.orc_lazy_weight.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double]
     L.orc_lazy_weight.restype = C.c_double
+    L.orc_pexp.argtypes = [C.c_double]; L.orc_pexp.restype = C.c_double
+    L.orc_fqi_spec_pendulum.argtypes = [P(FqiSpec)]
+    L.orc_fqi_create.argtypes = [P(FqiSpec), C.c_long]; L.orc_fqi_create.restype = C.c_void_p
+    L.orc_fqi_destroy.argtypes = [C.c_void_p]
+    L.orc_fqi_run_batch.argtypes = [C.c_void_p, P(Row)]; L.orc_fqi_run_batch.restype = C.c_int
+    L.orc_fqi_params.argtypes = [C.c_void_p, P(C.c_int)]; L.orc_fqi_params.restype = P(C.c_double)
+    L.orc_fqi_transitions.argtypes = [C.c_void_p] + [P(P(C.c_double))] * 4; L.orc_fqi_transitions.restype = C.c_size_t
+    L.orc_fqi_info.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int), P(C.c_double)]
+    L.orc_fqi_q.argtypes = [C.c_void_p, P(C.c_double), C.c_double]; L.orc_fqi_q.restype = C.c_double
+    L.orc_fqi_rng.argtypes = [C.c_void_p, P(C.c_uint64)]
     _lib = L
     return L
 
@@ -187,6 +202,79 @@ class Experiment:
         out = (C.c_uint64 * 4)()
         self.L.orc_rng_states(self.h, out)
         return np.array(out[:], dtype=np.uint64)
+
+
+SUM_SEQUENTIAL, SUM_TREE = 0, 1
+
+
+def pendulum_fqi_spec(math=MATH_PORTABLE, sum_order=SUM_TREE, **over) -> FqiSpec:
+    """The reference's tests/pendulum-fqi-ann.yaml; gamma_tau = pow(gamma, control_step) is recomputed from the final values."""
+    s = FqiSpec()
+    load().orc_fqi_spec_pendulum(C.byref(s))
+    s.base.math = math
+    s.sum_order = sum_order
+    for k, v in over.items():
+        if hasattr(s, k):
+            setattr(s, k, v)
+        else:
+            setattr(s.base, k, v)
+    s.gamma_tau = float(s.base.gamma) ** float(s.base.control_step)
+    return s
+
+
+class FqiExperiment:
+    """One scalar batch-learning experiment of the oracle (oracle/fqi.c)."""
+
+    def __init__(self, spec: FqiSpec, seed: int):
+        self.L = load()
+        self.spec = spec
+        self.h = self.L.orc_fqi_create(C.byref(spec), seed)
+        if not self.h:
+            raise RuntimeError("orc_fqi_create failed (unsupported spec)")
+
+    def close(self):
+        if self.h:
+            self.L.orc_fqi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def run_batch(self) -> Row:
+        row = Row()
+        if self.L.orc_fqi_run_batch(self.h, C.byref(row)) != 0:
+            raise MemoryError("orc_fqi_run_batch")
+        return row
+
+    def params(self):
+        n = C.c_int()
+        p = self.L.orc_fqi_params(self.h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def transitions(self):
+        ptrs = [C.POINTER(C.c_double)() for _ in range(4)]
+        n = self.L.orc_fqi_transitions(self.h, *[C.byref(p) for p in ptrs])
+        shapes = [(n, 3), (n, 2), (n,), (n,)]
+        return [np.ctypeslib.as_array(p, shape=sh).copy() for p, sh in zip(ptrs, shapes)]
+
+    def info(self):
+        md = C.c_double(); it = C.c_int(); err = C.c_double()
+        self.L.orc_fqi_info(self.h, C.byref(md), C.byref(it), C.byref(err))
+        return dict(maxdelta=md.value, iterations=it.value, error=err.value)
+
+    def q(self, obs, action):
+        o = (C.c_double * 2)(*obs)
+        return self.L.orc_fqi_q(self.h, o, float(action))
+
+    def rng(self):
+        out = (C.c_uint64 * 3)()
+        self.L.orc_fqi_rng(self.h, out)
+        return [out[0], out[1], out[2]]
+
+    def format_row(self, row) -> str:
+        buf = C.create_string_buffer(128)
+        self.L.orc_format_row(C.byref(row), buf, 128)
+        return buf.value.decode()
 
 
 def tile_project(ts: TileSpec, x):

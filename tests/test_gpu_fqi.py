@@ -1,0 +1,99 @@
+"""The batch path on the GPU (grlx_fqi_*, BASELINE.json configs[4]) against the oracle with the same specification
+(oracle/fqi.c, portable arithmetic, the GPU's gradient summation tree): bit for bit -- the transition store, the
+targets, all 101 network parameters after every batch, the rows, the RNG streams.  PARITY UNPINNED with respect to the
+reference (see oracle/fqi.c D1-D4); tolerance against the oracle written here: 0 ulp."""
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shapes {a.shape} vs {b.shape}"
+    bad = np.nonzero(bits(a).ravel() != bits(b).ravel())[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}: {a.ravel()[bad[0]]!r} vs {b.ravel()[bad[0]]!r}"
+
+
+def _both(grlx, seeds, batches, **over):
+    cfg = grlx.pendulum_fqi_config(len(seeds), max_batches=batches, **over)
+    r = grlx.FqiRunner(cfg, seeds)
+    oracles = [ob.FqiExperiment(ob.pendulum_fqi_spec(**over), seed=int(s)) for s in seeds]
+    for b in range(batches):
+        r.run_batch()
+        r.sync()
+        for k, e in enumerate(oracles):
+            row = e.run_batch()
+            n = (b + 1) * cfg.batch_size
+            inp, nobs, rew, tgt = r.transitions(k, 0, n)
+            oin, onobs, orew, otgt = e.transitions()
+            assert_bit_equal(inp, oin, f"batch {b} replica {k}: normalised inputs")
+            assert_bit_equal(nobs, onobs, f"batch {b} replica {k}: next observations")
+            assert_bit_equal(rew, orew, f"batch {b} replica {k}: rewards")
+            assert_bit_equal(tgt, otgt, f"batch {b} replica {k}: targets of the last iteration")
+            assert_bit_equal(r.params(k), e.params(), f"batch {b} replica {k}: network parameters")
+            info, oinfo = r.info(k), e.info()
+            assert info["n"] == n and info["iterations"] == oinfo["iterations"]
+            assert_bit_equal([info["maxdelta"], info["error"]], [oinfo["maxdelta"], oinfo["error"]], f"batch {b} replica {k}: maxdelta, mse")
+            assert info["rng"] == e.rng()[:2]
+            bb, tt, rr = r.rows(k, b + 1)
+            assert bb[b] == row.trial and tt[b] == row.steps
+            assert_bit_equal(rr[b:b + 1], [row.reward], f"batch {b} replica {k}: return of the test trial")
+    for e in oracles:
+        e.close()
+    r.close()
+
+
+def test_fqi_small_batches_bit_exact(grlx):
+    """Ragged sizes: 700 transitions per batch (2.7 chunks of 256), three replicas, two batches (the second rebuild runs
+    over 1400 stored transitions = 5.5 chunks)."""
+    _both(grlx, [1, 2, 3], 2, batch_size=700, iterations=3, epochs=40)
+
+
+def test_fqi_many_chunks_bit_exact(grlx):
+    """More chunks than the 64 lanes of the third reduction level (20000 transitions = 79 chunks)."""
+    _both(grlx, [7], 1, batch_size=20000, iterations=2, epochs=12)
+
+
+def test_fqi_iteration_loop_stops_per_replica(grlx):
+    """gamma = 0: the targets are the rewards and the second iteration changes nothing (fqi.cpp:213); the stop is taken
+    on the device, per replica, without a host round trip."""
+    _both(grlx, [4, 5], 1, batch_size=300, iterations=6, epochs=5, gamma=0.0)
+
+
+def test_fqi_reference_yaml_first_row(grlx):
+    """tests/pendulum-fqi-ann.yaml as the reference ships it (1000 transitions, 10 iterations x 500 epochs), seed 1: the first
+    row is the template's first row (-3508.07, the constant-torque return); both rows equal the oracle's bit for bit."""
+    import os
+    cfg = grlx.pendulum_fqi_config(1)
+    r = grlx.FqiRunner(cfg, [1])
+    e = ob.FqiExperiment(ob.pendulum_fqi_spec(), seed=1)
+    r.run_batch(); r.run_batch(); r.sync()
+    rows = [e.run_batch(), e.run_batch()]
+    b, t, rew = r.rows(0, 2)
+    assert list(b) == [0, 1] and list(t) == [0, 1000]
+    assert_bit_equal(rew, [x.reward for x in rows], "returns of the two test trials")
+    assert_bit_equal(r.params(0), e.params(), "network parameters after two batches")
+    template = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-fqi-ann-0.txt")).readline()
+    assert "%15d%15d%15s\n" % (b[0], t[0], "%g" % rew[0]) == template
+    e.close(); r.close()
+
+
+def test_fqi_validation(grlx):
+    capi = grlx.capi
+    for over in (dict(hidden=7), dict(env=1), dict(batch_size=0), dict(timeout=float("nan")), dict(action_steps=0)):
+        with pytest.raises(capi.GrlxError) as ei:
+            grlx.FqiRunner(grlx.pendulum_fqi_config(1, **over), [1])
+        assert ei.value.code == capi.ERR_INVALID
+    r = grlx.FqiRunner(grlx.pendulum_fqi_config(1, batch_size=100, iterations=1, epochs=1, max_batches=1), [1])
+    r.run_batch()
+    with pytest.raises(capi.GrlxError) as ei:
+        r.run_batch()
+    assert ei.value.code == capi.ERR_ROWS_FULL
+    r.close()
