@@ -68,6 +68,67 @@ SECONDARY = [
 ]
 
 
+# The batch path (BASELINE.json configs[4], per-GPU share): tests/pendulum-fqi-ann.yaml scaled to 100,000 transitions per
+# batch, 16 independent-seed replicas per GPU.  A step = one batch (100,000 new transitions, FQIPredictor::rebuild over the
+# whole store: 10 iterations x 500 epochs, one greedy test trial); the first batch is the warm-up, the second (200,000
+# stored transitions) is timed.  Unit of work: a sample-epoch (forward + backward pass of one stored transition);
+# algorithmic FLOPs per sample-epoch for the 3-20-1 network, exp counted as one: 2*(3+1)*20 + 2*(20+1) (forward MACs)
+# + 4*20 (logistic) + 3*20 (hidden deltas) + (3+1)*20 + 20 (gradient products) + 2 = 444.
+FQI = dict(key="pendulum_fqi_ann", replicas=16, batch_size=100000, iterations=10, epochs=500, flops_per_sample_epoch=444,
+           workload="pendulum fitted Q-iteration, 3-20-1 logistic network trained by RPROP (tests/pendulum-fqi-ann.yaml scaled: 100000 transitions per batch, "
+                    "10 iterations x 500 epochs), 16 independent-seed replicas; step = the second batch (rebuild over 200000 stored transitions)",
+           kernel="fqi_grad_kernel<20> (+ fqi_step_kernel, fqi_targets_kernel<20>)")
+F64_PEAK_TFLOPS = 78.6                    # MI355X f64 vector = matrix rate: half the 157.3 TF f32 vector peak of MI355X_MICROARCH.md
+
+
+def run_fqi(torch, no_cpu_baseline, replicas=None, batch_size=None, epochs=None):
+    import numpy as np
+    import grl_amd
+    w = FQI
+    R = replicas or w["replicas"]
+    n = batch_size or w["batch_size"]
+    ep = epochs or w["epochs"]
+    cfg = grl_amd.pendulum_fqi_config(R, batch_size=n, iterations=w["iterations"], epochs=ep, max_batches=2)
+    r = grl_amd.FqiRunner(cfg, np.arange(1, R + 1))
+    stream = torch.cuda.current_stream()
+    r.run_batch(stream.cuda_stream)
+    r.sync(stream.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    r.run_batch(stream.cuda_stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    r.sync(stream.cuda_stream)
+    its = [r.info(k)["iterations"] for k in range(R)]
+    returns = [float(r.rows(k, 2)[2][1]) for k in range(R)]
+    r.close()
+    sample_epochs = sum(its) * ep * 2 * n
+    flops = sample_epochs * w["flops_per_sample_epoch"]
+    ms = e0.elapsed_time(e1)
+    out = {"workload": w["workload"].replace("100000 transitions", f"{n} transitions").replace("200000 stored", f"{2 * n} stored").replace("16 independent", f"{R} independent").replace("500 epochs", f"{ep} epochs"),
+           "value": sample_epochs / elapsed, "unit": "sample-epochs/s", "steps": 1, "warmup": 1, "ms_per_step": 1e3 * elapsed,
+           "replicas": R, "transitions_stored": 2 * n, "iterations_run": its, "epochs": ep, "dtype": "f64", "data": "synthetic",
+           "mean_test_return": sum(returns) / len(returns), "parity": "unpinned by the reference (oracle/fqi.c D1-D4); HIP == oracle bit for bit",
+           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS, "traffic": None, "kernel": w["kernel"], "kernel_ms_total": ms,
+                        "algorithmic_flops_per_step": flops,
+                        "note": "f64 VALU (no MFMA: K = 3 and K = 20 contractions, DESIGN.md 4.3); the chain of 10000 tiny launches per rebuild is latency-bound"}}
+    if not no_cpu_baseline:
+        from tests import oracle_binding as ob
+        e = ob.FqiExperiment(ob.pendulum_fqi_spec(math=ob.MATH_LIBM, sum_order=ob.SUM_SEQUENTIAL, batch_size=4000, iterations=4, epochs=100), seed=1)
+        t0 = time.perf_counter()
+        e.run_batch()
+        dt = time.perf_counter() - t0
+        se = e.info()["iterations"] * 100 * 4000
+        e.close()
+        out["cpu_baseline"] = {"value": se / dt, "unit": "sample-epochs/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/fqi.c (libm, the reference's sample-order gradient sum), 1 replica, 4000 transitions x {se // 4000} epochs in {dt:.1f} s"}
+    return out
+
+
 def secondary_config(key, n):
     import grl_amd
     if key == "cart_pole_ac":
@@ -214,6 +275,9 @@ def main():
     from grl_amd import parallel
 
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if args.only == FQI["key"]:
+        print(json.dumps(run_fqi(torch, args.no_cpu_baseline, args.secondary_replicas or None)))
+        return
     if args.only:
         w = [x for x in SECONDARY if x["key"] == args.only]
         if not w:
@@ -306,6 +370,7 @@ def main():
         if world == 1 and not args.no_secondary:
             # the other single-GPU configurations BASELINE.json names, each timed the same way on this GPU
             out["secondary"] = [run_secondary(w, torch, args.no_cpu_baseline, args.secondary_replicas or None) for w in SECONDARY]
+            out["secondary"].append(run_fqi(torch, args.no_cpu_baseline))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

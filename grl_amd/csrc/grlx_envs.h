@@ -68,32 +68,38 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
   static constexpr int S = 5, D = 4;
   using Consts = SinConsts;                     // held in registers across the integration loop
   template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
+  // Equations of motion of dynamics/acrobot (acrobot.cpp:48-79).  Unit link masses, lengths and inertias fold the
+  // reference's parameter products into five constants; each is formed by the same left-to-right products the
+  // reference evaluates at run time, and every remaining operation keeps the reference's order (bit parity).
   __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
-  { // acrobot.cpp:48-79, expression for expression
-    const double l1 = 1, m1 = 1, m2 = 1, lc1 = 0.5, lc2 = 0.5, I1 = 1, I2 = 1, g = 9.8;
-    const double theta1 = x[0], theta2 = x[1], thetad1 = x[2], thetad2 = x[3];
-    const double tau = u;
-    double sin2, cos2;
-    psincos(theta2, k, sin2, cos2);
+  {
+    constexpr double kElbowGrav = 1.0 * 0.5 * 9.8;                // m2*lc2*g
+    constexpr double kCoriolis = -1.0 * 1.0 * 0.5;                // -m2*l1*lc2
+    constexpr double kCoupling = 2 * 1.0 * 1.0 * 0.5;             // 2*m2*l1*lc2  (= 1: exact, the product below keeps it)
+    constexpr double kShoulderGrav = (1.0 * 0.5 + 1.0 * 1.0) * 9.8;    // (m1*lc1+m2*l1)*g
+    constexpr double kElbowInertia = 1.0 * 0.5 * 0.5 + 1.0;       // m2*lc2*lc2+I2, the denominator's constant part
+    const double q1 = x[0], q2 = x[1], w1 = x[2], w2 = x[3];
+    double s2, c2;
+    psincos(q2, k, s2, c2);
 
-    double phi2 = m2*lc2*g*pcos(theta1+theta2-GRLX_PI/2, k);
-    double phi1 = -m2*l1*lc2*thetad2*thetad2*sin2-2*m2*l1*lc2*thetad2*thetad1*sin2 +
-                  (m1*lc1+m2*l1)*g*pcos(theta1-GRLX_PI/2, k)+phi2;
-    double d2 = m2*(lc2*lc2+l1*lc2*cos2)+I2;
-    double d1 = m1*lc1*lc1 + m2*(l1*l1+lc2*lc2+2*l1*lc2*cos2)+I1+I2;
-    double thetadd2 = (tau+d2*phi1/d1-m2*l1*lc2*thetad2*thetad2*sin2-phi2)/
-                      (m2*lc2*lc2+I2-d2*d2/d1);
-    double thetadd1 = -(d2*thetadd2+phi1)/d1;
+    const double g_elbow = kElbowGrav * pcos(q1 + q2 - GRLX_PI / 2, k);
+    const double bias = kCoriolis * w2 * w2 * s2 - kCoupling * w2 * w1 * s2 + kShoulderGrav * pcos(q1 - GRLX_PI / 2, k) + g_elbow;
+    const double m_cross = 1.0 * (0.5 * 0.5 + 1.0 * 0.5 * c2) + 1.0;                                    // d2
+    const double m_shoulder = 1.0 * 0.5 * 0.5 + 1.0 * (1.0 * 1.0 + 0.5 * 0.5 + 2 * 1.0 * 0.5 * c2) + 1.0 + 1.0;   // d1
+    double a_elbow = (u + m_cross * bias / m_shoulder - 1.0 * 1.0 * 0.5 * w2 * w2 * s2 - g_elbow) /
+                     (kElbowInertia - m_cross * m_cross / m_shoulder);
+    double a_shoulder = -(m_cross * a_elbow + bias) / m_shoulder;
 
-    if (thetad1 >  4*GRLX_PI) thetadd1 = fmin(thetadd1, 0.);
-    if (thetad1 < -4*GRLX_PI) thetadd1 = fmax(thetadd1, 0.);
-    if (thetad2 >  9*GRLX_PI) thetadd2 = fmin(thetadd2, 0.);
-    if (thetad2 < -9*GRLX_PI) thetadd2 = fmax(thetadd2, 0.);
+    // joint-rate limits: beyond 4 pi (shoulder) / 9 pi (elbow) a joint may only decelerate
+    if (w1 > 4 * GRLX_PI) a_shoulder = fmin(a_shoulder, 0.);
+    if (w1 < -4 * GRLX_PI) a_shoulder = fmax(a_shoulder, 0.);
+    if (w2 > 9 * GRLX_PI) a_elbow = fmin(a_elbow, 0.);
+    if (w2 < -9 * GRLX_PI) a_elbow = fmax(a_elbow, 0.);
 
-    xd[0] = thetad1;
-    xd[1] = thetad2;
-    xd[2] = thetadd1;
-    xd[3] = thetadd2;
+    xd[0] = w1;
+    xd[1] = w2;
+    xd[2] = a_shoulder;
+    xd[3] = a_elbow;
     xd[4] = 1;
   }
   __device__ static __forceinline__ bool failed(const double *x)
@@ -254,73 +260,60 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     ahip = psin_s(m.ha, k) * (m.slar*m.slar - cs) + asl;
     ahip += torque;
   }
+  // One Runge-Kutta step of the walker's own integrator (SWModel.cpp:220-258): angles and rates are staged separately
+  // -- stage j's angles advance with stage j-1's RATES, its rates with stage j-1's ACCELERATIONS -- and the stance
+  // foot does not move.  Stage states live in two small arrays (angle pair, rate pair); the update coefficients and
+  // their order of evaluation are the reference's.
   __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt)
-  { // SWModel.cpp:220-258
-    St s1 = state, s2 = state, s3 = state, s4 = state;
-    double k1s, k1h, k2s, k2h, k3s, k3h, k4s, k4h;
-    accel(P, k, s1, torque, k1s, k1h);
-    s2.slar = s1.slar + (dt/2)*k1s;
-    s2.har  = s1.har  + (dt/2)*k1h;
-    s2.sla  = s1.sla  + (dt/2)*s1.slar;
-    s2.ha   = s1.ha   + (dt/2)*s1.har;
-    accel(P, k, s2, torque, k2s, k2h);
-    s3.slar = s1.slar + (dt/2)*k2s;
-    s3.har  = s1.har  + (dt/2)*k2h;
-    s3.sla  = s1.sla  + (dt/2)*s2.slar;
-    s3.ha   = s1.ha   + (dt/2)*s2.har;
-    accel(P, k, s3, torque, k3s, k3h);
-    s4.slar = s1.slar + (dt)*k3s;
-    s4.har  = s1.har  + (dt)*k3h;
-    s4.sla  = s1.sla  + (dt)*s3.slar;
-    s4.ha   = s1.ha   + (dt)*s3.har;
-    accel(P, k, s4, torque, k4s, k4h);
-    state.slar = s1.slar + (dt/6)*(k1s + 2*k2s + 2*k3s + k4s);
-    state.har  = s1.har  + (dt/6)*(k1h + 2*k2h + 2*k3h + k4h);
-    state.sla  = s1.sla  + (dt/6)*(s1.slar + 2*s2.slar + 2*s3.slar + s4.slar);
-    state.ha   = s1.ha   + (dt/6)*(s1.har + 2*s2.har + 2*s3.har + s4.har);
+  {
+    const St base = state;
+    double rate_sl[4], rate_hip[4], acc_sl[4], acc_hip[4];       // per stage: d(angle)/dt and d(rate)/dt
+    St stage = base;
+    const double half = dt / 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      if (j > 0)
+      { // stage j starts from the base state, advanced by the previous stage's derivatives over half a step (full for j = 3)
+        const double span = (j == 3) ? dt : half;
+        stage.slar = base.slar + span * acc_sl[j - 1];
+        stage.har = base.har + span * acc_hip[j - 1];
+        stage.sla = base.sla + span * rate_sl[j - 1];
+        stage.ha = base.ha + span * rate_hip[j - 1];
+      }
+      rate_sl[j] = stage.slar;
+      rate_hip[j] = stage.har;
+      accel(P, k, stage, torque, acc_sl[j], acc_hip[j]);
+    }
+    const double sixth = dt / 6;
+    state.slar = base.slar + sixth * (acc_sl[0] + 2 * acc_sl[1] + 2 * acc_sl[2] + acc_sl[3]);
+    state.har = base.har + sixth * (acc_hip[0] + 2 * acc_hip[1] + 2 * acc_hip[2] + acc_hip[3]);
+    state.sla = base.sla + sixth * (rate_sl[0] + 2 * rate_sl[1] + 2 * rate_sl[2] + rate_sl[3]);
+    state.ha = base.ha + sixth * (rate_hip[0] + 2 * rate_hip[1] + 2 * rate_hip[2] + rate_hip[3]);
   }
-  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &t0, const St &t1, St &hs, double torque, double precision, double dt)
-  { // SWModel.cpp:53-104
-    double timeLeft = 0;
-    St s0 = t0, s1 = t1;
-    double s0time = 0, s1time = dt;
-    const int maxIterations = 10;
-    int iIter;
-    for (iIter = 0; iIter < maxIterations; iIter++)
+  // Time of the heel strike inside a sub-step (SWModel.cpp:53-104): the swing foot is above ground at `above` (time 0)
+  // and below at `below` (time dt).  A bracketing secant search on the swing-foot height: integrate from the upper
+  // bracket by the linearly interpolated time to the zero crossing, replace the bracket on the same side, stop when
+  // either bracket is within `tol` of the ground or after ten rounds.  Returns the time LEFT in the sub-step after the
+  // strike; `hit` is the state at the strike.
+  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &above, const St &below, St &hit, double torque,
+                                                             double tol, double dt)
+  {
+    St up = above, down = below;                  // brackets: swing foot above / below the ground
+    double t_up = 0, t_down = dt;
+    for (int round = 0; round < 10; ++round)
     {
-      hs = s0;
-      const double y0 = swing_y(k, s0);
-      double newDt = (s1time - s0time) * y0 / (y0 - swing_y(k, s1));
-      rk4(P, k, hs, torque, newDt);
-      if (swing_y(k, hs) > 0)
-      {
-        s0 = hs;
-        s0time = s0time + newDt;
-      }
-      else
-      {
-        s1 = hs;
-        s1time = s0time + newDt;
-      }
-      if (swing_y(k, s0) < precision)
-      {
-        hs = s0;
-        timeLeft = dt - s0time;
-        break;
-      }
-      else if (-swing_y(k, s1) < precision)
-      {
-        hs = s1;
-        timeLeft = dt - s1time;
-        break;
-      }
+      hit = up;
+      const double y_up = swing_y(k, up);
+      const double t_cross = (t_down - t_up) * y_up / (y_up - swing_y(k, down));
+      rk4(P, k, hit, torque, t_cross);
+      if (swing_y(k, hit) > 0) { up = hit; t_up = t_up + t_cross; }
+      else { down = hit; t_down = t_up + t_cross; }
+      if (swing_y(k, up) < tol) { hit = up; return dt - t_up; }
+      if (-swing_y(k, down) < tol) { hit = down; return dt - t_down; }
     }
-    if (iIter >= maxIterations)
-    {
-      if (swing_y(k, hs) > 0) timeLeft = dt - s0time;
-      else timeLeft = dt - s1time;
-    }
-    return timeLeft;
+    // not converged: the side the last probe fell on
+    return (swing_y(k, hit) > 0) ? dt - t_up : dt - t_down;
   }
   __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next)
   { // CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210)
