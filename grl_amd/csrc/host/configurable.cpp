@@ -262,7 +262,8 @@ static Configurator *walk(Configurator *from, const std::string &path)
 }
 
 Configurator *Configurator::find(const std::string &p)
-{
+{ // configurable.h:418-449: a leading '/' addresses the root; otherwise relative to this node first, then from the root
+  if (!p.empty() && p[0] == '/') return walk(root(), p.substr(1));
   Configurator *c = walk(this, p);
   if (!c) c = walk(root(), p);
   return c;
@@ -292,7 +293,7 @@ const std::vector<Configurator *> &instantiate_order() { return g_order; }
 static bool looks_like_path(const std::string &v)
 { // an identifier path such as experiment/agent/policy/projector or ../../projector/memory
   if (v.empty()) return false;
-  if (!(std::isalpha((unsigned char)v[0]) || v[0] == '.' || v[0] == '_')) return false;
+  if (!(std::isalpha((unsigned char)v[0]) || v[0] == '.' || v[0] == '_' || (v[0] == '/' && v.size() > 1))) return false;
   for (char ch : v)
     if (!(std::isalnum((unsigned char)ch) || ch == '/' || ch == '_' || ch == '.')) return false;
   return true;

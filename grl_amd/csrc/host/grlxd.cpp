@@ -58,7 +58,12 @@ int main(int argc, char **argv)
       for (auto &kv : root.children)
         if (kv.first == "experiment")
           for (auto &p : kv.second.children)
+          {
             if (p.first == "trials") p.second.scalar = std::to_string(trials_override);
+            if (p.first == "experiment")                       // experiment/multi { experiment: experiment/online_learning }
+              for (auto &q : p.second.children)
+                if (q.first == "trials") q.second.scalar = std::to_string(trials_override);
+          }
     log(2, "Instantiating configuration");
     std::unique_ptr<Configurator> tree = instantiate(root);
     Configurator *expconf = tree->child("experiment");

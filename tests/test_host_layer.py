@@ -96,3 +96,86 @@ def test_exporter_parameters_are_validated(grlxd, tmp_path, body, needle):
     res = run(grlxd, ["-s", "1", "-q", _variant(tmp_path, '  load_file: ""\n', "  exporter:\n" + body + '  load_file: ""\n')], tmp_path)
     assert res.returncode == 1
     assert needle in res.stderr, res.stderr
+
+
+def test_absolute_references_and_shared_top_level_objects(grlxd, tmp_path):
+    """cfg/pendulum/multi_sarsa_tc.yaml of the reference: the agents' policy is a TOP-LEVEL object referred to by the
+    absolute path `/policy` (configurable.h:418-449: a leading '/' addresses the root) from inside an experiment/multi."""
+    from grl_amd import capi
+    text = """environment:
+  type: environment/modeled
+  model:
+    type: model/dynamical
+    control_step: 0.03
+    integration_steps: 5
+    dynamics:
+      type: dynamics/pendulum
+  task:
+    type: task/pendulum/swingup
+    timeout: 2.99
+policy:
+  type: mapping/policy/discrete/value/q
+  discretizer:
+    type: discretizer/uniform
+    min: environment/task/action_min
+    max: environment/task/action_max
+    steps: [3]
+  projector:
+    type: projector/tile_coding
+    tilings: 16
+    memory: 8388608
+    resolution: [0.31415, 3.1415, 3]
+    wrapping: [6.283, 0, 0]
+  representation:
+    type: representation/parameterized/linear
+    init_min: [0]
+    init_max: [1]
+    memory: policy/projector/memory
+    outputs: 1
+    output_min: []
+    output_max: []
+  sampler:
+    type: sampler/epsilon_greedy
+    epsilon: 0.05
+experiment:
+  type: experiment/multi
+  instances: 3
+  experiment:
+    type: experiment/online_learning
+    runs: 1
+    trials: 0
+    steps: 0
+    rate: 0
+    test_interval: 10
+    output: multi
+    environment: /environment
+    agent:
+      type: agent/td
+      policy: /policy
+      predictor:
+        type: predictor/critic/sarsa
+        alpha: 0.2
+        gamma: 0.97
+        lambda: 0.65
+        projector: policy/projector
+        representation: policy/representation
+        trace:
+          type: trace/enumerated/replacing
+    test_agent:
+      type: agent/fixed
+      policy:
+        type: mapping/policy/discrete/value/q
+        discretizer: /policy/discretizer
+        projector: /policy/projector
+        representation: /policy/representation
+        sampler:
+          type: sampler/greedy
+"""
+    p = tmp_path / "multi.yaml"
+    p.write_text(text)
+    res = run(grlxd, ["-s", "1", "-t", "11", "-q", str(p)], tmp_path)
+    assert "does not name an object" not in res.stderr and "unknown" not in res.stderr, res.stderr
+    if capi.load().grlx_device_count() == 0:
+        assert res.returncode == 1 and "no HIP device" in res.stderr, res.stderr
+    else:
+        assert res.returncode == 0, res.stderr
