@@ -61,26 +61,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 HOST_SOURCES = ["configurable.cpp", "objects.cpp", "grlxd.cpp"]
+OPS_SOURCES = ["configurable.cpp", "objects.cpp", "grlx_ops.cpp"]      # grlx_ops: Projector::project / Environment::step from the command line
 HOST_HEADERS = ["configurable.h", "objects.h"]
 BINDIR = os.path.join(HERE, "bin")
 GRLXD = os.path.join(BINDIR, "grlxd")
+GRLX_OPS = os.path.join(BINDIR, "grlx_ops")
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """Compile the C++ host layer + deployer (grlxd) against libgrlx.so."""
     build(force=False, verbose=verbose)
     hostdir = os.path.join(CSRC, "host")
-    deps = [os.path.join(hostdir, f) for f in HOST_SOURCES + HOST_HEADERS] + [LIB, os.path.join(HERE, "..", "include", "grlx.h")]
-    if not force and os.path.exists(GRLXD) and all(os.path.getmtime(d) <= os.path.getmtime(GRLXD) for d in deps):
+    deps = [os.path.join(hostdir, f) for f in HOST_SOURCES + HOST_HEADERS + ["grlx_ops.cpp"]] + [LIB, os.path.join(HERE, "..", "include", "grlx.h")]
+    if not force and os.path.exists(GRLXD) and os.path.exists(GRLX_OPS) and all(os.path.getmtime(d) <= min(os.path.getmtime(GRLXD), os.path.getmtime(GRLX_OPS)) for d in deps):
         return GRLXD
     os.makedirs(BINDIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", GRLXD] + [os.path.join(hostdir, f) for f in HOST_SOURCES] + \
-          ["-L" + LIBDIR, "-lgrlx", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("g++ failed:\n" + res.stdout + res.stderr)
+    for out, sources in ((GRLXD, HOST_SOURCES), (GRLX_OPS, OPS_SOURCES)):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", out] + [os.path.join(hostdir, f) for f in sources] + \
+              ["-L" + LIBDIR, "-lgrlx", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("g++ failed:\n" + res.stdout + res.stderr)
     return GRLXD
 
 

@@ -102,7 +102,11 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
   if (variant) *variant = GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
   // stamps and per-step taps are recorded by the instantiation that updates in place
+#ifdef GRLX_WIDE_STAMPS
+  const bool inplace = P.tap_replica >= 0 && P.tap_capacity > 0;      // stamped wide build: diag_out feeds the wide kernel
+#else
   const bool inplace = P.diag_out != nullptr || (P.tap_replica >= 0 && P.tap_capacity > 0);
+#endif
   if (P.diag_out && P.diag_deferred && P.env == GRLX_ENV_PENDULUM && P.A == 3 && !(P.tap_replica >= 0 && P.tap_capacity > 0))
   {
     if (variant) *variant = GRLX_KERNEL_GENERIC;

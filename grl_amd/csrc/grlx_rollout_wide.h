@@ -262,6 +262,9 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   {
     for (;;)
     {
+#ifdef GRLX_WIDE_STAMPS
+      const unsigned long long st0 = stamp();
+#endif
       // ================= environment phase: every replica of the wave that is in mid-episode takes its step;
       // a replica whose trial has just started takes its start state over from the table role instead (sh_step = 2)
       {
@@ -295,6 +298,10 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
         wave_sync();
       }
 
+#ifdef GRLX_WIDE_STAMPS
+      const unsigned long long st1 = stamp();
+      if (P.diag_out && lane == 0) { P.diag_out[(size_t)blockIdx.x * 8 + 0] += st1 - st0; P.diag_out[(size_t)blockIdx.x * 8 + 2] += 1; }
+#endif
       // ================= table phase, one sub-batch after the other
       bool more = false;
       for (int b = 0; b < B; ++b)
@@ -581,6 +588,9 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
         wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
       }
       wave_sync();
+#ifdef GRLX_WIDE_STAMPS
+      if (P.diag_out && lane == 0) P.diag_out[(size_t)blockIdx.x * 8 + 1] += stamp() - st1;
+#endif
       if (!__any(more)) break;
     }
 

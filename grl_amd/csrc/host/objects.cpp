@@ -229,8 +229,24 @@ struct DynamicalModel : Model {
 GRLX_REGISTER(DynamicalModel)
 
 // environment/modeled (modeled.cpp:35-119)
-struct ModeledEnvironment : Configurable {
+struct ModeledEnvironment : Environment {
   GRLX_TYPEINFO("environment/modeled")
+  void lower_env(grlx_config *c) const;                 // model + task -> the environment fields of a grlx_config
+  void dims(int *state_dims, int *obs_dims) const override
+  {
+    if (grlx_env_dims(task->env_id(), state_dims, obs_dims) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
+  }
+  void step(double *state, const double *action, int n, double *obs, double *reward, int32_t *terminal) const override
+  { // ModeledEnvironment::step for n independent instances, on the GPU
+    grlx_config c;
+    grlx_config_pendulum_sarsa(&c);
+    lower_env(&c);
+    int S = 0, D = 0;
+    dims(&S, &D);
+    c.projector.dims = D + 1;                           // the fine-grained operator only reads the environment fields
+    for (int i = 0; i < GRLX_MAX_DIMS; ++i) { c.projector.resolution[i] = 1.; c.projector.wrapping[i] = 0.; }
+    if (grlx_env_step(&c, state, action, n, obs, reward, terminal) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
+  }
   Model *model = nullptr;
   Task *task = nullptr;
   int discrete_time = 1;
@@ -266,6 +282,26 @@ struct ModeledEnvironment : Configurable {
 };
 GRLX_REGISTER(ModeledEnvironment)
 
+void ModeledEnvironment::lower_env(grlx_config *c) const
+{
+  const Model *m = model;
+  const Task *t = task;
+  c->env = t->env_id();
+  c->control_step = m->control_step;
+  c->integration_steps = m->integration_steps;
+  c->discrete_time = discrete_time;
+  c->timeout = t->timeout;
+  c->randomization = t->randomization;
+  if (const CartPoleSwingupTask *cp = dynamic_cast<const CartPoleSwingupTask *>(t))
+  { c->end_stop_penalty = cp->end_stop_penalty; c->action_penalty = cp->action_penalty; }
+  if (const CompassWalkerWalkTask *w = dynamic_cast<const CompassWalkerWalkTask *>(t))
+  {
+    const CompassWalkerModel *wm = dynamic_cast<const CompassWalkerModel *>(m);
+    if (!wm || wm->slope_angle != w->slope_angle) throw Exception(w->path() + ": slope_angle must match model/compass_walker");
+    c->slope_angle = w->slope_angle; c->initial_state_variation = w->initial_state_variation; c->negative_reward = w->negative_reward;
+  }
+}
+
 // ------------------------------------------------------------------ agent ---
 // discretizer/uniform (uniform.cpp:34-95)
 struct UniformDiscretizer : Configurable {
@@ -287,8 +323,19 @@ struct UniformDiscretizer : Configurable {
 GRLX_REGISTER(UniformDiscretizer)
 
 // projector/tile_coding (tile_coding.cpp:34-80)
-struct TileCodingProjector : Configurable {
+struct TileCodingProjector : Projector {
   GRLX_TYPEINFO("projector/tile_coding")
+  int n_tilings() const override { return tilings; }
+  int n_dims() const override { return (int)resolution.size(); }
+  void project(const double *in, int n, uint32_t *out) const override
+  { // TileCodingProjector::_project for n inputs, on the GPU
+    grlx_tile_spec t;
+    memset(&t, 0, sizeof(t));
+    t.tilings = tilings; t.memory = memory; t.dims = (int)resolution.size();
+    if (resolution.size() > GRLX_MAX_DIMS) throw bad_param("projector/tile_coding:resolution");
+    for (size_t i = 0; i < resolution.size(); ++i) { t.resolution[i] = resolution[i]; t.wrapping[i] = wrapping[i]; }
+    if (grlx_project(&t, in, n, out) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
+  }
   int tilings = 16, memory = 8 * 1024 * 1024, safe = 0;
   VecD resolution, wrapping;
   void request(const std::string &, ConfigurationRequest *config) override
@@ -816,23 +863,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
   void lower(grlx_config *c) const
   {
     grlx_config_pendulum_sarsa(c);
-    const Model *m = environment->model;
-    const Task *t = environment->task;
     c->test_interval = test_interval;
-    c->env = t->env_id();
-    c->control_step = m->control_step;
-    c->integration_steps = m->integration_steps;
-    c->discrete_time = environment->discrete_time;
-    c->timeout = t->timeout;
-    c->randomization = t->randomization;
-    if (const CartPoleSwingupTask *cp = dynamic_cast<const CartPoleSwingupTask *>(t))
-    { c->end_stop_penalty = cp->end_stop_penalty; c->action_penalty = cp->action_penalty; }
-    if (const CompassWalkerWalkTask *w = dynamic_cast<const CompassWalkerWalkTask *>(t))
-    {
-      const CompassWalkerModel *wm = dynamic_cast<const CompassWalkerModel *>(m);
-      if (!wm || wm->slope_angle != w->slope_angle) throw Exception(w->path() + ": slope_angle must match model/compass_walker");
-      c->slope_angle = w->slope_angle; c->initial_state_variation = w->initial_state_variation; c->negative_reward = w->negative_reward;
-    }
+    environment->lower_env(c);
 
     if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))
     { // ---- actor-critic (cfg/cart_pole/ac_tc.yaml)

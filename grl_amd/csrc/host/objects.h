@@ -14,6 +14,21 @@ struct RunOptions {
   bool print_rows = true;
 };
 
+// Environment::step (environment.h:48-51 -> ModeledEnvironment::step, modeled.cpp:160-213) for a batch of instances:
+// state[n][S] is advanced in place; obs[n][D], reward[n], terminal[n].  Forwards to grlx_env_step (HIP kernel).
+struct Environment : Configurable {
+  virtual void dims(int *state_dims, int *obs_dims) const = 0;
+  virtual void step(double *state, const double *action, int n, double *obs, double *reward, int32_t *terminal) const = 0;
+};
+
+// Projector::project (projector.h:55-69 -> TileCodingProjector::_project, tile_coding.cpp:103-149) for a batch of
+// inputs in[n][dims] -> out[n][tilings] reference slot indices.  Forwards to grlx_project (HIP kernel).
+struct Projector : Configurable {
+  virtual int n_tilings() const = 0;
+  virtual int n_dims() const = 0;
+  virtual void project(const double *in, int n, uint32_t *out) const = 0;
+};
+
 // Experiment::run (experiment.h:44) -> learning curve of replica 0
 struct OnlineLearningExperiment : Configurable {
   virtual std::vector<double> run(const RunOptions &opt) = 0;

@@ -247,3 +247,39 @@ def test_wide_waves_actor_critic_bit_exact(grlx, over):
             assert_bit_equal(w0, e.weights(slots, 0), f"rpw {rpw}: critic weights of replica {k}")
             assert_bit_equal(w1, e.weights(slots, 1), f"rpw {rpw}: actor weights of replica {k}")
         e.close()
+
+
+def test_host_layer_plugin_interfaces(grlx, tmp_path):
+    """The C++ host layer's Projector::project and Environment::step (grl_amd/csrc/host/objects.h), instantiated from the
+    reference's own yaml and driven through grl_amd/bin/grlx_ops: indices and transitions equal the oracle's bit for bit."""
+    import subprocess
+    from grl_amd import _build
+    from tests import configs
+    _build.build_host()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(17)
+    # Projector::project
+    yaml = os.path.join(root, "tests", "golden", "pendulum-sarsa-tc.yaml")
+    x = np.column_stack([rng.uniform(0, 6.28, 200), rng.uniform(-30, 30, 200), rng.choice([-3.0, 0.0, 3.0], 200)])
+    f = tmp_path / "in.txt"
+    f.write_text("\n".join(" ".join(repr(float(v)) for v in row) for row in x) + "\n")
+    res = subprocess.run([_build.GRLX_OPS, "project", yaml, "experiment/agent/policy/projector", str(f)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = np.array([[int(v) for v in line.split()] for line in res.stdout.splitlines()], dtype=np.uint32)
+    want = ob.tile_project(ob.pendulum_sarsa_spec().projector, x)
+    assert (got == want).all()
+    # Environment::step: pendulum and cart-pole
+    for yaml_name, spec, S, D, amax in (("pendulum-sarsa-tc.yaml", ob.pendulum_sarsa_spec(), 3, 2, 3.0),
+                                        ("cart_pole-ac-tc.yaml", configs.cart_pole_ac(None, 1)[1], 5, 4, 15.0)):
+        yaml = os.path.join(root, "tests", "golden", yaml_name)
+        st = rng.uniform(-2, 2, (150, S)); st[:, -1] = rng.uniform(0, 1, 150)
+        act = rng.uniform(-amax, amax, 150)
+        f.write_text("\n".join(" ".join(repr(float(v)) for v in list(row) + [a]) for row, a in zip(st, act)) + "\n")
+        res = subprocess.run([_build.GRLX_OPS, "envstep", yaml, "experiment/environment", str(f)], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        out = np.array([[float(v) for v in line.split()] for line in res.stdout.splitlines()])
+        nst, nobs, nrew, nterm = ob.env_step(spec, st, act)
+        assert_bit_equal(out[:, :S], nst, yaml_name + ": next state")
+        assert_bit_equal(out[:, S:S + D], nobs, yaml_name + ": observation")
+        assert_bit_equal(out[:, S + D], nrew, yaml_name + ": reward")
+        assert list(out[:, S + D + 1].astype(int)) == list(nterm)
