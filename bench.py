@@ -58,13 +58,13 @@ def measured_pmc(key: str, n_replicas: int, trials_per_launch: int):
 SECONDARY = [
     dict(key="cart_pole_ac", replicas=16384, trials=11, steps=5, warmup=1, bytes_learn=2224, bytes_test=128,
          workload="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml), 16384 replicas, 11 trials (2200 env-steps) per replica per step",
-         kernel="rollout_ac_kernel<cart_pole, SpecCartPoleAc, deferred update>", want_kernel=2),
-    dict(key="acrobot_q", replicas=8192, trials=22, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
-         workload="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 22 trials per replica per step",
-         kernel="rollout_kernel<acrobot, 3 actions, generic, deferred update>", want_kernel=1),
-    dict(key="compass_walker_q", replicas=8192, trials=11, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
-         workload="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 11 trials per replica per step",
-         kernel="rollout_kernel<compass_walker, 3 actions, generic, deferred update>", want_kernel=1),
+         kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>", want_kernel=2),
+    dict(key="acrobot_q", replicas=8192, trials=32, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
+         workload="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 32 trials per replica per step",
+         kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, generic, deferred update>", want_kernel=1),
+    dict(key="compass_walker_q", replicas=8192, trials=32, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
+         workload="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 32 trials per replica per step",
+         kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, generic, deferred update>", want_kernel=1),
 ]
 
 
@@ -188,6 +188,7 @@ def run_secondary(w, torch, no_cpu_baseline, replicas=None):
     runner.sync(sptr)                                          # raises on table overflow etc.
     l1, t1s = runner.step_counts()
     variant = runner.last_kernel()
+    rpw = runner.replicas_per_wave()
     runner.close()
     learn, test = l1 - l0, t1s - t0s
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
@@ -198,7 +199,7 @@ def run_secondary(w, torch, no_cpu_baseline, replicas=None):
     out = {"workload": w["workload"], "value": (learn + test) / elapsed, "unit": "env-steps/s", "steps": w["steps"], "warmup": w["warmup"],
            "ms_per_step": 1e3 * elapsed / w["steps"], "replicas": n, "trials_per_step": w["trials"],
            "env_steps_per_step": (learn + test) / w["steps"], "learn_steps": learn, "test_steps": test, "dtype": "f64", "data": "synthetic",
-           "last_kernel": variant, "kernel_is_expected_instantiation": variant == w["want_kernel"],
+           "last_kernel": variant, "kernel_is_expected_instantiation": variant == w["want_kernel"], "replicas_per_wave": rpw,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "issue": issue, "kernel": w["kernel"], "kernel_ms_avg": avg_ms,
                         "algorithmic_bytes_per_launch": alg_bytes}}
@@ -254,6 +255,7 @@ def main():
     ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations (cart-pole AC, acrobot, walker)")
+    ap.add_argument("--no-fqi", action="store_true", help="skip the batch-path entry (its rebuild is ~20000 launches: keeps profiler output small)")
     ap.add_argument("--only", default="", help="profiling: run only this secondary workload (cart_pole_ac | acrobot_q | compass_walker_q) and print its entry")
     ap.add_argument("--secondary-replicas", type=int, default=0, help="tests: override the replica count of the secondary workloads")
     ap.add_argument("--table-log2", type=int, default=17)
@@ -370,7 +372,8 @@ def main():
         if world == 1 and not args.no_secondary:
             # the other single-GPU configurations BASELINE.json names, each timed the same way on this GPU
             out["secondary"] = [run_secondary(w, torch, args.no_cpu_baseline, args.secondary_replicas or None) for w in SECONDARY]
-            out["secondary"].append(run_fqi(torch, args.no_cpu_baseline))
+            if not args.no_fqi:
+                out["secondary"].append(run_fqi(torch, args.no_cpu_baseline))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

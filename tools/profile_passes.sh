@@ -8,13 +8,16 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_stats.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline --no-fqi > $OUT/bench_under_stats.json 2> $OUT/stats.err
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_pmc$i.json 2> $OUT/pmc$i.err || echo "pass $i ($set) failed" >> $OUT/failed.txt
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-fqi > $OUT/bench_under_pmc$i.json 2> $OUT/pmc$i.err || echo "pass $i ($set) failed" >> $OUT/failed.txt
   echo "pass $i done: $set"
 done
 cd $ROOT
 python3 tools/pmc_to_json.py $OUT > $OUT/summary.txt 2>&1 || true
+# keep what gets committed (kernel statistics, per-kernel counter means); the raw per-launch csv files are large
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null || true
+rm -rf $OUT/stats $OUT/pmc[0-9]
 cat $OUT/summary.txt
