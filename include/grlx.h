@@ -57,7 +57,10 @@ enum { GRLX_TRACE_NONE = 0, GRLX_TRACE_REPLACING = 1, GRLX_TRACE_ACCUMULATING = 
  * (timeout / control_step; twice that for the compass walker's test episodes) than this. */
 #define GRLX_MAX_EPISODE_STEPS 100000
 
-/* projector/tile_coding (tile_coding.cpp:34-80): tilings, memory, resolution, wrapping; safe = 0 */
+/* projector/tile_coding (tile_coding.cpp:34-80): tilings, memory, resolution, wrapping; safe = 0.
+ * HARD LIMIT of the fused rollout kernels (grlx_create): tilings == 16 -- one lane per tiling, 16 lanes per replica, four (or
+ * eight) replicas per 64-lane wavefront; anything else is GRLX_ERR_INVALID.  The reference takes any count (tile_coding.cpp:47);
+ * the stateless operator grlx_project takes 1..32.  memory: 1 .. 2^26-1 slots. */
 typedef struct {
   int32_t tilings;
   int32_t memory;
