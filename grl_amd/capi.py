@@ -44,7 +44,7 @@ class Config(C.Structure):
                 ("tap_capacity", C.c_int32), ("end_stop_penalty", C.c_int32), ("action_penalty", C.c_int32),
                 ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
-                ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("reserved0", C.c_int32)]
+                ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("tap_deferred", C.c_int32)]
 
 
 class FqiConfig(C.Structure):

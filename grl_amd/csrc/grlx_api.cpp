@@ -425,6 +425,12 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   if (cfg->max_rows < 1) return fail(GRLX_ERR_INVALID, "max_rows must be >= 1");
   if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8)
     return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8");
+  if (cfg->tap_deferred && cfg->tap_replica >= 0 && cfg->tap_capacity > 0)
+  {
+    const bool td = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA);
+    if (!td || cfg->trace == GRLX_TRACE_ACCUMULATING || (cfg->env != GRLX_ENV_PENDULUM && cfg->env != GRLX_ENV_ACROBOT) || cfg->action_steps != 3)
+      return fail(GRLX_ERR_INVALID, "tap_deferred is built for SARSA / Q / Expected SARSA on the pendulum and the acrobot with 3 actions");
+  }
   DevParams P;
   int rc = make_params(*cfg, &P);
   if (rc != GRLX_OK) return rc;
@@ -445,6 +451,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_replica = cfg->tap_replica;
   P.tap_capacity = cfg->tap_replica >= 0 ? cfg->tap_capacity : 0;
   P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
+  P.tap_deferred = (cfg->tap_deferred != 0 && P.tap_capacity > 0) ? 1 : 0;
   { // replicas per wave: wide waves once the batch outnumbers the SIMDs four to one (taps and stamps: always 4)
     const bool has_wide = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA ||
                            cfg->agent == GRLX_AGENT_AC) && cfg->trace != GRLX_TRACE_ACCUMULATING;

@@ -103,6 +103,7 @@ struct DevParams {
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
   double   kappa;               // predictor/critic/advantage: advantage scaling factor
   double   beta;                // predictor/critic/qv: state-value learning rate
+  int32_t  tap_deferred;        // taps are recorded by the deferred-update (production) ordering instead of the in-place one
   int32_t  replicas_per_wave;   // 4 (one sub-batch) or 8 (two): chosen at create from the replica count and the SIMD count
 };
 

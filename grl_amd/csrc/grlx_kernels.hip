@@ -113,6 +113,20 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
     hipLaunchKernelGGL((rollout_kernel<GRLX_ENV_PENDULUM, 3, true, SpecNone, true>), dim3(waves), dim3(64), 0, stream, P, n_trials);
     return hipGetLastError();
   }
+  if (P.tap_deferred && P.tap_replica >= 0 && P.tap_capacity > 0 && !P.diag_out && P.agent != GRLX_AGENT_ADVANTAGE)
+  { // per-step records of the production ordering (tests): generic instantiation, deferred update, taps
+    if (variant) *variant = GRLX_KERNEL_GENERIC;
+#define GRLX_LAUNCH_TAPDEF(ENVID, NACT)                                                                               \
+    if (P.env == ENVID && P.A == NACT)                                                                              \
+    {                                                                                                               \
+      hipLaunchKernelGGL((rollout_kernel<ENVID, NACT, false, SpecNone, true, false, true>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                     \
+    }
+    GRLX_LAUNCH_TAPDEF(GRLX_ENV_PENDULUM, 3)
+    GRLX_LAUNCH_TAPDEF(GRLX_ENV_ACROBOT, 3)
+#undef GRLX_LAUNCH_TAPDEF
+    return hipErrorInvalidValue;
+  }
 #define GRLX_LAUNCH(ENVID, NACT)                                                                              \
   if (P.env == ENVID && P.A == NACT)                                                                        \
   {                                                                                                         \

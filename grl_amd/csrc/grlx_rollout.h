@@ -82,7 +82,10 @@ struct SpecNone {
 // ADV: advantage learning (predictor/critic/advantage, advantage.cpp:222-268) also reads A(s, .) of the
 // PREVIOUS state for every action with the current weights: NA more rows (their table positions are
 // those of the previous pass), Q(s,a) being one of them.  Built without the deferred update.
-template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG, bool ADV = false>
+// TAP: per-step records of the tapped replica.  Normally the instantiation that updates in place; TAP with DEFER
+// records the PRODUCTION ordering step by step (grlx_config.tap_deferred), the trace length being the one the pending
+// update will leave.
+template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG, bool ADV = false, bool TAP = !DEFER>
 __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 {
   static_assert(!(ADV && DEFER), "the advantage-learning instantiation updates in place");
@@ -454,6 +457,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           const double dT = N.alpha * delta;                   // VectorConstructor(alpha_*delta)
           if (DEFER)
           { // applied on the next pass, after that pass's loads are in flight
+            if (TAP && up.use_trace)
+            { // the length trace_->add will leave (trace.h:215-234), for the record of this step
+              int l = tr.len;
+              double tot = tr.total;
+              if (up.ee < up.cut) { l = 0; tot = 1.; }
+              l = (l < kMaxTrace) ? l + 1 : kMaxTrace;
+              tot *= up.ee;
+              while (tot < up.cut && l > 1) { tot /= up.ee; l--; }
+              tr_len_ref = l;
+            }
             pd = true;
             pd_dW = dW;
             pd_dT = dT;
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
 
         DIAG_STAMP(5)
         // -------- tap (debug / parity tests; only the immediate-update instantiation records taps)
-        if (!DEFER && tapped && (!first || P.tap_starts))
+        if (TAP && tapped && (!first || P.tap_starts))
         {
           uint32_t n = *P.tap_count;
           if (n < (uint32_t)P.tap_capacity)

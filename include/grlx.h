@@ -128,7 +128,10 @@ typedef struct {
    * replica, lane = tiling) while the batch has no more than 4 replicas per SIMD of the device, else 8 (two sub-batches
    * of four share one environment phase; grlx_rollout_wide.h).  4 / 8 force the choice (tests); results are identical. */
   int32_t  replicas_per_wave;
-  int32_t  reserved0;
+  /* 1: the taps are recorded by the PRODUCTION ordering of the rollout kernel (TD update applied one pass later, under the
+   * next step's table loads) instead of the in-place diagnostic ordering: per-step parity of the kernel that is benchmarked.
+   * Built for the pendulum and the acrobot with 3 actions (SARSA / Q / Expected SARSA, replacing or no trace). */
+  int32_t  tap_deferred;
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;

@@ -283,3 +283,35 @@ def test_host_layer_plugin_interfaces(grlx, tmp_path):
         assert_bit_equal(out[:, S:S + D], nobs, yaml_name + ": observation")
         assert_bit_equal(out[:, S + D], nrew, yaml_name + ": reward")
         assert list(out[:, S + D + 1].astype(int)) == list(nterm)
+
+
+@pytest.mark.parametrize("env,agent,memory", [("pendulum", 0, 8388608), ("pendulum", 1, 8388608), ("pendulum", 3, 8388608),
+                                              ("pendulum", 0, 2048), ("acrobot", 1, 8388608)])
+def test_production_ordering_step_by_step(grlx, env, agent, memory):
+    """Per-step records of the DEFERRED-update ordering (the one that is benchmarked; grlx_config.tap_deferred), not of
+    the in-place diagnostic one: tile indices, Q-values, actions, rewards, TD errors and trace lengths of every step
+    equal the oracle's -- a divergence that healed itself before the next row would show here.  2048-slot memory: nearly
+    every slot is shared between tilings, so the reload / write-through paths of the deferred update run on every pass."""
+    from tests import configs
+    from tests.test_gpu_parity import _compare_taps
+    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot}[env]
+    seeds, trials, cap = [41, 42, 43, 44, 45, 46], 23, 2600
+    cfg, spec = make(grlx, len(seeds), agent=agent, tap_replica=4, tap_capacity=cap, tap_deferred=1)
+    cfg.projector.memory = memory
+    spec.projector.memory = memory
+    r = grlx.Runner(cfg, seeds)
+    r.run(12); r.run(11); r.sync()
+    assert r.last_kernel() == 1                                # generic instantiation, NOT the in-place diagnostic one (3)
+    e = ob.Experiment(spec, seed=seeds[4])
+    rows, otaps = e.run(trials, tap_cap=cap)
+    gtaps = r.taps()
+    assert len(gtaps) == len(otaps) and len(otaps) > 100
+    D = 2 if env == "pendulum" else 4
+    for k, (gt, ot) in enumerate(zip(gtaps, otaps)):
+        try:
+            _compare_taps(gt, ot, A=3, D=D)
+        except AssertionError as ex:
+            raise AssertionError(f"step {k}: {ex}")
+    t, s, rew = r.rows(4)
+    assert_bit_equal(rew, [x.reward for x in rows], "returns")
+    r.close()
