@@ -315,3 +315,50 @@ def test_production_ordering_step_by_step(grlx, env, agent, memory):
     t, s, rew = r.rows(4)
     assert_bit_equal(rew, [x.reward for x in rows], "returns")
     r.close()
+
+
+def test_read_back_waits_for_a_non_blocking_run_stream(grlx):
+    """Stream contract of include/grlx.h: grlx_run is asynchronous on the caller's stream; every read-back entry point first
+    waits for that stream.  A torch side stream is created non-blocking (it does not synchronise with the NULL stream), so
+    without the wait these reads would see rollouts in flight."""
+    torch = pytest.importorskip("torch")
+    seeds = [61, 62, 63, 64, 65, 66, 67, 68]
+    cfg = grlx.pendulum_sarsa_config(len(seeds))
+    r = grlx.Runner(cfg, seeds)
+    side = torch.cuda.Stream()
+    r.run(55, side.cuda_stream)                               # no sync: the launches are still queued / running
+    rows_now = [r.rows(k) for k in range(len(seeds))]         # grlx_rows + grlx_read_rows
+    counts = r.step_counts()
+    state = [r.env_state(k) for k in range(len(seeds))]
+    slots = np.arange(0, 8388608, 4099, dtype=np.uint32)
+    w = [r.weights(k, slots) for k in range(len(seeds))]
+    assert counts == (len(seeds) * 50 * 100, len(seeds) * 5 * 100)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=seed)
+        rows, _ = e.run(55)
+        assert list(rows_now[k][1]) == [x.steps for x in rows]
+        assert_bit_equal(rows_now[k][2], [x.reward for x in rows], f"returns of seed {seed}")
+        assert_bit_equal(state[k], e.state(), f"env state of seed {seed}")
+        assert_bit_equal(w[k], e.weights(slots), f"weights of seed {seed}")
+        e.close()
+    r.sync(side.cuda_stream)
+    r.close()
+
+
+def test_repeated_policy_loads_do_not_accumulate_device_memory(grlx):
+    """grlx_load_weights keeps one dense image (64 MiB) per load on the device; an image no replica refers to any more is
+    freed at the next load, so loading N times costs one image, not N."""
+    torch = pytest.importorskip("torch")
+    r = grlx.Runner(grlx.pendulum_sarsa_config(4), [1, 2, 3, 4])
+    dense = np.random.default_rng(3).uniform(0, 1, 8388608)
+    r.load_weights(dense)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(6):
+        r.load_weights(dense + k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 2 * 8388608 * 8, (free0, free1)    # at most one more image outstanding, not six
+    r.run(3); r.sync()
+    assert_bit_equal(r.weights(0, np.array([5, 77, 4242], np.uint32)) >= 0, [True] * 3)
+    r.close()
