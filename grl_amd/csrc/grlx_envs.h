@@ -8,6 +8,18 @@ namespace grlx {
 // ----------------------------------------------------------- environments --
 template <int ENV> struct Env;
 
+// Lanes that integrate the same replica hold identical values and would each evaluate every sin/cos of an equation of
+// motion.  With a LaneShare they split the INDEPENDENT evaluations instead: the lane whose role is r evaluates the r-th
+// angle (the same psincos code in every lane, another argument per role) and the results are exchanged by ds_bpermute.
+// Every value is produced by the operations the unsplit code performs on the same argument, so the bits are the same.
+struct NoShare { static constexpr bool kSplit = false; };
+struct LaneShare {
+  static constexpr bool kSplit = true;
+  int src[3];          // lane of my replica that evaluates role 0, 1, 2
+  int role3, role2;    // my role when three / two evaluations are shared out
+};
+__device__ __forceinline__ double lane_fetch(double v, int src) { return __shfl(v, src, 64); }
+
 // dynamics/pendulum + task/pendulum/swingup (pendulum.cpp:40-145)
 template <> struct Env<GRLX_ENV_PENDULUM> {
   static constexpr int S = 3, D = 2;
@@ -96,6 +108,38 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
     if (w2 > 9 * GRLX_PI) a_elbow = fmin(a_elbow, 0.);
     if (w2 < -9 * GRLX_PI) a_elbow = fmax(a_elbow, 0.);
 
+    xd[0] = w1;
+    xd[1] = w2;
+    xd[2] = a_shoulder;
+    xd[3] = a_elbow;
+    xd[4] = 1;
+  }
+  // the same with the three sin/cos evaluations shared out over the lanes of the replica
+  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd, const LaneShare &ls)
+  {
+    constexpr double kElbowGrav = 1.0 * 0.5 * 9.8;
+    constexpr double kCoriolis = -1.0 * 1.0 * 0.5;
+    constexpr double kCoupling = 2 * 1.0 * 1.0 * 0.5;
+    constexpr double kShoulderGrav = (1.0 * 0.5 + 1.0 * 1.0) * 9.8;
+    constexpr double kElbowInertia = 1.0 * 0.5 * 0.5 + 1.0;
+    const double q1 = x[0], q2 = x[1], w1 = x[2], w2 = x[3];
+    const double angle = (ls.role3 == 0) ? q2 : (ls.role3 == 1) ? q1 + q2 - GRLX_PI / 2 : q1 - GRLX_PI / 2;
+    double sn, cs;
+    psincos(angle, k, sn, cs);                                   // psincos' cosine == pcos (same quadrant logic, same kernels)
+    const double s2 = lane_fetch(sn, ls.src[0]), c2 = lane_fetch(cs, ls.src[0]);
+    const double cos_elbow = lane_fetch(cs, ls.src[1]), cos_shoulder = lane_fetch(cs, ls.src[2]);
+
+    const double g_elbow = kElbowGrav * cos_elbow;
+    const double bias = kCoriolis * w2 * w2 * s2 - kCoupling * w2 * w1 * s2 + kShoulderGrav * cos_shoulder + g_elbow;
+    const double m_cross = 1.0 * (0.5 * 0.5 + 1.0 * 0.5 * c2) + 1.0;
+    const double m_shoulder = 1.0 * 0.5 * 0.5 + 1.0 * (1.0 * 1.0 + 0.5 * 0.5 + 2 * 1.0 * 0.5 * c2) + 1.0 + 1.0;
+    double a_elbow = (u + m_cross * bias / m_shoulder - 1.0 * 1.0 * 0.5 * w2 * w2 * s2 - g_elbow) /
+                     (kElbowInertia - m_cross * m_cross / m_shoulder);
+    double a_shoulder = -(m_cross * a_elbow + bias) / m_shoulder;
+    if (w1 > 4 * GRLX_PI) a_shoulder = fmin(a_shoulder, 0.);
+    if (w1 < -4 * GRLX_PI) a_shoulder = fmax(a_shoulder, 0.);
+    if (w2 > 9 * GRLX_PI) a_elbow = fmin(a_elbow, 0.);
+    if (w2 < -9 * GRLX_PI) a_elbow = fmax(a_elbow, 0.);
     xd[0] = w1;
     xd[1] = w2;
     xd[2] = a_shoulder;
@@ -252,19 +296,33 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     if (m.ha >= GRLX_PI) m.ha -= 2*GRLX_PI;
     if (m.ha < -GRLX_PI) m.ha += 2*GRLX_PI;
   }
-  __device__ static __forceinline__ void accel(const DevParams &P, const SinConsts &k, const St &m, double torque, double &asl, double &ahip)
+  template <typename SH>
+  __device__ static __forceinline__ void accel(const DevParams &P, const SinConsts &k, const St &m, double torque, double &asl, double &ahip, const SH &sh)
   { // SWModel.cpp:212-218
-    double sn, cs;
-    psincos_s(m.sla - P.slope_angle, k, sn, cs);
+    double sn, cs, sin_hip;
+    if constexpr (SH::kSplit)
+    { // two independent angles: one psincos per lane (role 0: stance leg against the slope, role 1: hip), results exchanged
+      double a_sn, a_cs;
+      psincos_s(sh.role2 == 0 ? m.sla - P.slope_angle : m.ha, k, a_sn, a_cs);     // psincos_s' sine == psin_s (same kernels)
+      sn = lane_fetch(a_sn, sh.src[0]);
+      cs = lane_fetch(a_cs, sh.src[0]);
+      sin_hip = lane_fetch(a_sn, sh.src[1]);
+    }
+    else
+    {
+      psincos_s(m.sla - P.slope_angle, k, sn, cs);
+      sin_hip = psin_s(m.ha, k);
+    }
     asl = sn;
-    ahip = psin_s(m.ha, k) * (m.slar*m.slar - cs) + asl;
+    ahip = sin_hip * (m.slar*m.slar - cs) + asl;
     ahip += torque;
   }
   // One Runge-Kutta step of the walker's own integrator (SWModel.cpp:220-258): angles and rates are staged separately
   // -- stage j's angles advance with stage j-1's RATES, its rates with stage j-1's ACCELERATIONS -- and the stance
   // foot does not move.  Stage states live in two small arrays (angle pair, rate pair); the update coefficients and
   // their order of evaluation are the reference's.
-  __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt)
+  template <typename SH>
+  __device__ static __forceinline__ void rk4(const DevParams &P, const SinConsts &k, St &state, double torque, double dt, const SH &sh)
   {
     const St base = state;
     double rate_sl[4], rate_hip[4], acc_sl[4], acc_hip[4];       // per stage: d(angle)/dt and d(rate)/dt
@@ -283,7 +341,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
       }
       rate_sl[j] = stage.slar;
       rate_hip[j] = stage.har;
-      accel(P, k, stage, torque, acc_sl[j], acc_hip[j]);
+      accel(P, k, stage, torque, acc_sl[j], acc_hip[j], sh);
     }
     const double sixth = dt / 6;
     state.slar = base.slar + sixth * (acc_sl[0] + 2 * acc_sl[1] + 2 * acc_sl[2] + acc_sl[3]);
@@ -296,8 +354,9 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
   // bracket by the linearly interpolated time to the zero crossing, replace the bracket on the same side, stop when
   // either bracket is within `tol` of the ground or after ten rounds.  Returns the time LEFT in the sub-step after the
   // strike; `hit` is the state at the strike.
+  template <typename SH>
   __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &above, const St &below, St &hit, double torque,
-                                                             double tol, double dt)
+                                                             double tol, double dt, const SH &sh)
   {
     St up = above, down = below;                  // brackets: swing foot above / below the ground
     double t_up = 0, t_down = dt;
@@ -306,7 +365,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
       hit = up;
       const double y_up = swing_y(k, up);
       const double t_cross = (t_down - t_up) * y_up / (y_up - swing_y(k, down));
-      rk4(P, k, hit, torque, t_cross);
+      rk4(P, k, hit, torque, t_cross, sh);
       if (swing_y(k, hit) > 0) { up = hit; t_up = t_up + t_cross; }
       else { down = hit; t_down = t_up + t_cross; }
       if (swing_y(k, up) < tol) { hit = up; return dt - t_up; }
@@ -315,7 +374,8 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     // not converged: the side the last probe fell on
     return (swing_y(k, hit) > 0) ? dt - t_up : dt - t_down;
   }
-  __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next)
+  template <typename SH>
+  __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next, const SH &sh)
   { // CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210)
     St st, prev, hs;
     st.sfx = x[SFX]; st.sla = x[SLA]; st.slar = x[SLAR]; st.ha = x[HA]; st.har = x[HAR];
@@ -327,7 +387,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     double y_prev = swing_y(k, prev);            // swing_y(prev) of the next sub-step is this sub-step's swing_y(st)
     for (int i = 0; i < P.integration_steps; i++)
     {
-      rk4(P, k, st, torque, partial);
+      rk4(P, k, st, torque, partial, sh);
       wrap(st);
       // detectEvents (SWModel.cpp:30-45)
       double timeleft = 0;
@@ -338,7 +398,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
           if ((st.slar < 0) && (st.ha < 0))
           { // processStanceLegChange (:106-124)
             struck = true;
-            timeleft = heelstrike_moment(P, k, prev, st, hs, torque, 1.0E-11, partial);
+            timeleft = heelstrike_moment(P, k, prev, st, hs, torque, 1.0E-11, partial, sh);
             const double c2 = pcos(2.0*hs.sla, k);
             st.har  = hs.slar*(c2*(1.0 - c2));
             st.slar = hs.slar*(c2);
@@ -349,7 +409,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
       changed = changed || (timeleft > 0);
       if (timeleft > 0)
       {
-        rk4(P, k, st, torque, timeleft);
+        rk4(P, k, st, torque, timeleft, sh);
         wrap(st);
       }
       // a pure function of the state: recomputed only where a heel strike replaced the state
@@ -430,8 +490,18 @@ template <> struct HasCustomModel<GRLX_ENV_COMPASS_WALKER> { static constexpr bo
 // The last state component is time (xd = 1 in every supported dynamics, and no eom reads
 // it), so its stage values are the constant h and its update the constant
 // (h + 2h + 2h + h)/6 -- the same operations the reference performs, hoisted.
-template <int ENV, bool PIN>
-__device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next)
+// eom with or without shared-out sin/cos evaluations (only the acrobot has a split form)
+template <int ENV, typename SH>
+__device__ __forceinline__ void env_eom(const typename Env<ENV>::Consts &ec, const double *x, double u, double *xd, const SH &sh)
+{
+  if constexpr (SH::kSplit && ENV == GRLX_ENV_ACROBOT)
+    Env<ENV>::eom(ec, x, u, xd, sh);
+  else
+    Env<ENV>::eom(ec, x, u, xd);
+}
+
+template <int ENV, bool PIN, typename SH = NoShare>
+__device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, double u, double *next, const SH &sh = SH())
 {
   constexpr int S = Env<ENV>::S, SD = S - 1;
   const double h = P.h;
@@ -442,16 +512,16 @@ __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, do
   const typename Env<ENV>::Consts ec = Env<ENV>::template consts<PIN>();   // PIN: constants held in vector registers
   for (int ii = 0; ii < P.integration_steps; ++ii)
   {
-    Env<ENV>::eom(ec, next, u, xd);
+    env_eom<ENV>(ec, next, u, xd, sh);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k1[i] = h * xd[i]; t[i] = next[i] + k1[i] / 2; }
-    Env<ENV>::eom(ec, t, u, xd);
+    env_eom<ENV>(ec, t, u, xd, sh);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k2[i] = h * xd[i]; t[i] = next[i] + k2[i] / 2; }
-    Env<ENV>::eom(ec, t, u, xd);
+    env_eom<ENV>(ec, t, u, xd, sh);
 #pragma unroll
     for (int i = 0; i < SD; ++i) { k3[i] = h * xd[i]; t[i] = next[i] + k3[i]; }
-    Env<ENV>::eom(ec, t, u, xd);
+    env_eom<ENV>(ec, t, u, xd, sh);
 #pragma unroll
     for (int i = 0; i < SD; ++i)
     {
@@ -465,15 +535,17 @@ __device__ __forceinline__ void rk4_step(const DevParams &P, const double *x, do
 // ModeledEnvironment::step (modeled.cpp:160-213), window 1, no delta, discrete_time 1
 // PIN: hold the dynamics' constants in vector registers across the integration loop (pays at one
 // wave per SIMD, costs registers)
-template <int ENV, bool PIN = true>
-__device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal, uint32_t &status)
+// SH: NoShare, or a LaneShare when several lanes integrate the same replica (rollout kernels)
+template <int ENV, bool PIN = true, typename SH = NoShare>
+__device__ __forceinline__ void env_step(const DevParams &P, double *x, double action, double *obs, double &reward, int &terminal, uint32_t &status,
+                                         const SH &sh = SH())
 {
   constexpr int S = Env<ENV>::S;
   double next[S];
   if constexpr (HasCustomModel<ENV>::value)
-    Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next);     // model/compass_walker integrates itself
+    Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next, sh);  // model/compass_walker integrates itself
   else
-    rk4_step<ENV, PIN>(P, x, Env<ENV>::actuate(action), next);
+    rk4_step<ENV, PIN, SH>(P, x, Env<ENV>::actuate(action), next, sh);
   terminal = Env<ENV>::observe(P, next, obs);
   reward = Env<ENV>::evaluate(P, x, action, next);
   // the branch-free sin/cos need |angle| < 2^20; 2^19 at step ends leaves room for the stages

@@ -144,6 +144,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
     key_act[a] = in_reg(murmur_key(tile_coord<T>(N.tile, D, tile_quant(N.tile, D, N.actions[a]), j)));
   const uint32_t key_j = in_reg(murmur_key(j));
 
+  // the 16 lanes of a replica share out the independent sin/cos evaluations of its equations of motion (grlx_envs.h)
+  LaneShare lshare;
+  lshare.src[0] = g * 16; lshare.src[1] = g * 16 + 1; lshare.src[2] = g * 16 + 2;
+  lshare.role3 = j % 3; lshare.role2 = j & 1;
+
   TraceRegs tr;
   trace_init(tr);
   int tr_len_ref = 0;           // length as the reference reports it (its trace survives test trials)
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         // -------- environment step (skipped on the start() pass)
         if (!first)
         {
-          env_step<ENV>(N, x, action, obs, reward, terminal, status);     // online_learning.cpp:196
+          env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, status, lshare);   // online_learning.cpp:196
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
         }

@@ -209,6 +209,11 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
 #pragma unroll
   for (int i = 0; i < S; ++i) x[i] = P.states[elive ? wave0 + eq : 0].x[i];
   uint32_t estatus = 0;
+  // the 64/R lanes of a replica share out the independent sin/cos evaluations of its equations of motion (grlx_envs.h)
+  LaneShare lshare;
+  lshare.src[0] = eq; lshare.src[1] = eq + R; lshare.src[2] = eq + 2 * R;
+  lshare.role3 = (lane / R) % 3; lshare.role2 = (lane / R) & 1;
+  static_assert(64 / R >= 3, "three lanes per replica share an equation of motion");
   if (lane < R) { sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0; }
 
   // ---- table role: lane (g, j) of sub-batch b serves tiling j of replica wave0 + 4b + g
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
           if (step)
           {
             const double action = sh_act[eq];
-            env_step<ENV>(N, x, action, obs, reward, terminal, estatus);     // online_learning.cpp:196
+            env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, estatus, lshare);     // online_learning.cpp:196
             // the 64/R lanes of a replica hold identical values: all of them store (same address, same bits)
 #pragma unroll
             for (int i = 0; i < D; ++i) sh_obs[i * R + eq] = obs[i];
