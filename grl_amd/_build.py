@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgrlx.so")
 SOURCES = ["grlx_kernels.hip", "grlx_fqi.hip", "grlx_api.cpp"]
 HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", "grlx_policy.h", "grlx_update.h",
-           "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h",
+           "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h",
            os.path.join("..", "..", "include", "grlx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

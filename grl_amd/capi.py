@@ -44,7 +44,8 @@ class Config(C.Structure):
                 ("tap_capacity", C.c_int32), ("end_stop_penalty", C.c_int32), ("action_penalty", C.c_int32),
                 ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
-                ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("tap_deferred", C.c_int32)]
+                ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("tap_deferred", C.c_int32),
+                ("target_interval", C.c_int32), ("reserved1", C.c_int32), ("target_tau", C.c_double)]
 
 
 class FqiConfig(C.Structure):
@@ -92,6 +93,7 @@ _SIGS = {
     "grlx_get_rng": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint64)]),
     "grlx_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double)]),
     "grlx_table_load": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32)]),
+    "grlx_get_target_weights": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double), _P(C.c_uint32)]),
     "grlx_export_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_load_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_uint64]),
     "grlx_read_taps": (C.c_int, [C.c_void_p, _P(Tap), C.c_int, _P(C.c_int)]),

@@ -229,6 +229,18 @@ int make_params(const grlx_config &c, DevParams *P)
     P->beta = c.beta;
   }
 
+  if (c.target_interval < 0 || !std::isfinite(c.target_tau)) return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:{interval,tau}");
+  if (c.target_interval > 0)
+  { // target network of the Q table: its own (plain) kernel
+    if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q)
+      return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:interval (a target network is built for predictor/critic/sarsa and predictor/critic/q)");
+    if ((c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) || c.action_steps != 3 || c.trace == GRLX_TRACE_ACCUMULATING)
+      return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:interval (built for the pendulum and the acrobot with 3 actions, replacing or no trace)");
+    if (c.target_tau < 0 || c.target_tau > 1) return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:tau");
+    P->target_interval = c.target_interval;
+    P->target_tau = c.target_tau;
+    P->lin.draws_before = (uint64_t)c.projector.memory;     // the target is instantiated -- and draws -- first (representation.h:186-190)
+  }
   P->epsilon = c.epsilon;
   P->decay_rate = c.decay_rate;
   P->decay_min = c.decay_min;
@@ -270,6 +282,7 @@ struct grlx_ctx {
   uint64_t     *scratch = nullptr;        // 8 x u64
   unsigned long long *diag = nullptr;
   uint32_t     *trace_state = nullptr;
+  double       *tvals = nullptr;          // target network values per table position (target_interval > 0)
   // loaded policy images (grlx_load_weights): image k serves the replicas r with image_of[table][r] == k;
   // an image no replica refers to any more is freed at the next load, the rest with the context
   std::vector<double *> images;
@@ -453,7 +466,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
   P.tap_deferred = (cfg->tap_deferred != 0 && P.tap_capacity > 0) ? 1 : 0;
   { // replicas per wave: wide waves once the batch outnumbers the SIMDs four to one (taps and stamps: always 4)
-    const bool has_wide = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA ||
+    const bool has_wide = cfg->target_interval == 0 && (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA ||
                            cfg->agent == GRLX_AGENT_AC) && cfg->trace != GRLX_TRACE_ACCUMULATING;
     int rpw = cfg->replicas_per_wave;
     if (rpw == 0)
@@ -503,6 +516,12 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
     for (size_t i = 0; i < words; i += 2) init[i] = kInvalidPos;
     CTX_TRY(hipMemcpy(ctx->trace_state, init.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
+  if (P.target_interval > 0)
+  {
+    const size_t bytes = ((size_t)N * sizeof(double)) << logC;
+    CTX_TRY(hipMalloc((void **)&ctx->tvals, bytes));
+    CTX_TRY(hipMemset(ctx->tvals, 0xFF, bytes));                     // all ones = not materialised
+  }
   if (P.tap_capacity > 0)
   {
     CTX_TRY(hipMalloc((void **)&ctx->taps, sizeof(grlx_tap) * (size_t)P.tap_capacity));
@@ -516,6 +535,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   std::vector<ReplicaState> hs((size_t)N);
   uint64_t table_draws = (uint64_t)cfg->projector.memory;              // outputs = 1
   if (cfg->agent == GRLX_AGENT_AC || cfg->agent == GRLX_AGENT_QV) table_draws += (uint64_t)cfg->actor_projector.memory;
+  if (cfg->target_interval > 0) table_draws += (uint64_t)cfg->projector.memory;      // the target network's own initial draws
   for (int r = 0; r < N; ++r)
   {
     ReplicaState &s = hs[(size_t)r];
@@ -546,6 +566,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.row_trial = ctx->row_trial;
   P.taps = ctx->taps;
   P.trace_state = ctx->trace_state;
+  P.tvals = ctx->tvals;
   P.tap_count = ctx->tap_count;
   ctx->P = P;
   *out = ctx;
@@ -566,6 +587,7 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->diag);
   (void)hipFree(ctx->trace_state);
+  (void)hipFree(ctx->tvals);
   for (double *img : ctx->images)
     if (img) (void)hipFree(img);
   delete ctx;
@@ -619,6 +641,8 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
       HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.agent == GRLX_AGENT_QV)
       HIP_TRY(launch_rollout_qv(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+    else if (ctx->cfg.target_interval > 0)
+      HIP_TRY(launch_rollout_tgt(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
       HIP_TRY(launch_rollout_acc(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else
@@ -739,6 +763,27 @@ int grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_use
   return GRLX_OK;
 }
 
+int grlx_get_target_weights(grlx_ctx *ctx, int replica, const uint32_t *slots, int n, double *out, uint32_t *n_syncs)
+{
+  if (!ctx || !slots || !out || n < 0 || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (ctx->cfg.target_interval <= 0) return fail(GRLX_ERR_INVALID, "this context has no target network (target_interval = 0)");
+  DRAIN(ctx);
+  if (n_syncs)
+  {
+    ReplicaState s;
+    HIP_TRY(hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost));
+    *n_syncs = s.syncs;
+  }
+  if (n == 0) return GRLX_OK;
+  DevBuf ds, dout;
+  HIP_TRY(ds.alloc(sizeof(uint32_t) * (size_t)n));
+  HIP_TRY(dout.alloc(sizeof(double) * (size_t)n));
+  HIP_TRY(hipMemcpy(ds.p, slots, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(launch_get_target_weights(ctx->P, replica, ds.as<uint32_t>(), n, dout.as<double>(), nullptr));
+  HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
 int grlx_read_taps(grlx_ctx *ctx, grlx_tap *out, int cap, int *n)
 {
   if (!ctx || !out || !n) return fail(GRLX_ERR_INVALID, "bad argument");
@@ -789,6 +834,8 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
     return fail(GRLX_ERR_INVALID, "configuration mismatch: %llu weights given, the table has %zu", (unsigned long long)count, memory);
   if (ctx->cfg.agent == GRLX_AGENT_AC && ctx->trials_run != 0)
     return fail(GRLX_ERR_INVALID, "actor-critic: load before the first run (the critic's trace refers to table positions)");
+  if (ctx->cfg.target_interval > 0)
+    return fail(GRLX_ERR_INVALID, "loading parameters into a representation with a target network is not built");
   if (n_replicas == 0) return GRLX_OK;
   HIP_TRY(hipDeviceSynchronize());
   ctx->run_pending = false;

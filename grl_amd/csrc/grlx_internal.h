@@ -50,6 +50,10 @@ struct __attribute__((aligned(16))) ReplicaState {
   // image double[memory] that replaces the drawn initial value of every slot not yet in the
   // sparse table; NULL = the reference's random initialisation.  Shared between replicas.
   const double *lazy_base[2];
+  // target network of table 0 (rollout_tgt_kernel): ParameterizedRepresentation::count_ and the synchronisations so far
+  int64_t  sync_count;
+  uint32_t syncs;
+  uint32_t pad1;
 };
 
 struct TileParams {
@@ -103,6 +107,9 @@ struct DevParams {
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
   double   kappa;               // predictor/critic/advantage: advantage scaling factor
   double   beta;                // predictor/critic/qv: state-value learning rate
+  int32_t  target_interval;     // > 0: the Q table has a target network synchronised every so many update() calls
+  double   target_tau;          // synchronisation strength (representation.h:284-296)
+  double  *tvals;               // [replica][2^logC]: the target network's value per table position (all ones: not materialised)
   int32_t  tap_deferred;        // taps are recorded by the deferred-update (production) ordering instead of the in-place one
   int32_t  replicas_per_wave;   // 4 (one sub-batch) or 8 (two): chosen at create from the replica count and the SIMD count
 };
@@ -114,6 +121,8 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_qv(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+hipError_t launch_rollout_tgt(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+hipError_t launch_get_target_weights(const DevParams &P, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);

@@ -46,6 +46,7 @@ namespace grlx {
 #include "grlx_rollout_ac_wide.h"
 #include "grlx_rollout_qv.h"
 #include "grlx_rollout_acc.h"
+#include "grlx_rollout_tgt.h"
 
 namespace grlx {
 

@@ -1,0 +1,506 @@
+// grlx_rollout_tgt.h -- rollout with a TARGET NETWORK on the Q table (ParameterizedRepresentation `interval` / `tau`,
+// representation.h:161-306): SARSA and Q-learning read their targets from a second copy of the parameters that is
+// synchronised every `interval` LinearRepresentation::update calls (sarsa.cpp:107, advantage.cpp:88, linear.cpp:267).
+// Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
+//
+// A plain path in the manner of rollout_acc_kernel: nothing is cached -- the trace holds table positions, every update
+// is a read-modify-write of the table in the reference's order -- because a synchronisation falls BETWEEN two update
+// calls of one step (the count advances once per call: the write of p, then one call per trace entry) and must see the
+// table exactly as those calls left it.
+//   * the target's parameters live in a parallel array tvals[position] of the sparse table;
+//   * synchronise() = tau * params + (1 - tau) * target over the WHOLE parameter vector: here a pass of the replica's 16
+//     lanes over its sparse table; a slot that is not in the table has never been written, so its parameter is still its
+//     initial draw p0 and its target value follows t <- tau*p0 + (1-tau)*t once per synchronisation from the target's OWN
+//     initial draw (the target is instantiated, and draws, BEFORE the main table: representation.h:186-190) -- evaluated
+//     when the slot first gets an entry (K-fold recurrence, K = synchronisations so far; tau = 0 or 1: no recurrence);
+//   * replacing trace (ssub across tilings through LDS) or no trace.
+#pragma once
+
+namespace grlx {
+
+constexpr unsigned long long kTvalUnset = 0xFFFFFFFFFFFFFFFFull;       // tvals[] entry not materialised yet
+
+// target value of a slot that has had no entry during the first K synchronisations (its parameter is its initial draw)
+__device__ inline double target_from_init(const DevParams &P, const ReplicaState &rs, uint32_t slot, uint32_t K)
+{
+  LinearParams first = P.lin;
+  first.draws_before = 0;                                               // the target table's own draws come first
+  double t = lazy_weight(rs.TL0, first, slot);
+  const double p0 = lazy_weight(rs.TL0, P.lin, slot);
+  const double tau = P.target_tau;
+  if (tau == 0.) return p0;                                             // setParams(params()) at reset and ever after
+  t = tau * p0 + (1 - tau) * t;                                         // synchronize() at the end of reset (linear.cpp:122)
+  if (tau == 1.) return t;                                              // (1 - tau) * t == +-0: every later round returns the same bits
+  for (uint32_t k = 0; k < K; ++k) t = tau * p0 + (1 - tau) * t;
+  return t;
+}
+
+__device__ __forceinline__ double tval_get(const DevParams &P, const ReplicaState &rs, double *tv, uint32_t pos, uint32_t slot, uint32_t K)
+{
+  double t = tv[pos];
+  if ((unsigned long long)__double_as_longlong(t) == kTvalUnset)
+  {
+    t = target_from_init(P, rs, slot, K);
+    tv[pos] = t;
+  }
+  return t;
+}
+
+// ParameterizedRepresentation::synchronize for the replicas flagged in `todo` (wave lanes of those 16-lane groups):
+// every entry of the sparse table; K = synchronisations BEFORE this one
+__device__ __noinline__ void target_sync_pass(const DevParams &P, const Table &tab, const ReplicaState &rs, double *tv, uint32_t K, bool todo, int j)
+{
+  if (!todo) return;
+  const double tau = P.target_tau;
+  const uint32_t nb = tab.bmask + 1u;
+  for (uint32_t b = (uint32_t)j; b < nb; b += 16u)
+  {
+    const BucketRegs br = bucket_load(tab, b);
+    const uint32_t keys[4] = {br.k.x, br.k.y, br.k.z, br.k.w};
+#pragma unroll
+    for (int way = 0; way < 4; ++way)
+    {
+      const uint32_t kk = keys[way] & kKeyMask;
+      if (kk == 0u) continue;
+      const uint32_t pos = (b << 2) | (uint32_t)way;
+      const double t = tval_get(P, rs, tv, pos, kk - 1u, K);
+      tv[pos] = (tau != 0.) ? tau * br.v[way] + (1 - tau) * t : br.v[way];
+    }
+  }
+}
+
+template <int ENV, int NA>
+__global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_trials)
+{
+  constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
+  constexpr int NROWS = 2 * NA + 1;                  // Q(s', .), Q(s, a), Q_target(s', .)
+  static_assert(NROWS <= 16, "one lane per row of sums");
+  __shared__ double   sh_w[NROWS * 16 * 4];
+  __shared__ uint32_t sh_mb[4 * NA * 16];
+  __shared__ uint32_t sh_ms[4 * NA * 16];
+  __shared__ uint32_t sh_mail[4];
+  __shared__ double   sh_res[4 * 16];
+  __shared__ uint32_t sh_ppos[4 * 16];
+  __shared__ uint64_t sh_jump[2048];
+  jump_table_to_lds(sh_jump);
+
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  const int r_raw = blockIdx.x * kReplicasPerWave + g;
+  const bool live = r_raw < P.n_replicas;
+  const int r = live ? r_raw : 0;
+  const bool tapped = live && (r == P.tap_replica);
+  const unsigned long long gmask = 0xFFFFull << (16 * g);
+
+  ReplicaState &RS = P.states[r];
+  double x[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) x[i] = RS.x[i];
+  uint64_t G = RS.G, TL = RS.TL, S1 = RS.S1;
+  double eps_decay = RS.eps_decay;
+  int64_t tt = RS.tt, ss = RS.ss;
+  uint64_t test_steps = RS.test_steps;
+  uint32_t status = RS.status, rows = RS.rows, inserted = 0;
+  int64_t sync_count = RS.sync_count;
+  uint32_t K = RS.syncs;
+
+  const Table tab = table_of(P, 0, r);
+  double *tv = P.tvals + ((size_t)r << P.logC);
+  const double out_min = P.lin.out_min, out_max = P.lin.out_max;
+  const bool limit = P.lin.limit != 0;
+  const bool use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
+  const double ee = P.gl, cut = 0.01;
+
+  double acts[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acts[a] = P.actions[a];
+  uint32_t key_act[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+    key_act[a] = in_reg(murmur_key(tile_coord<T>(P.tile, D, tile_quant(P.tile, D, P.actions[a]), j)));
+  const uint32_t key_j = in_reg(murmur_key(j));
+
+  // the trace of this lane's tiling: table positions, newest first (kInvalidPos: index removed by ssub); bit e of tsh:
+  // entry e is a slot shared between tilings.  tlen is the reference's entry count (equal in all lanes).
+  uint32_t tpos[kMaxTrace];
+#pragma unroll
+  for (int e = 0; e < kMaxTrace; ++e) tpos[e] = kInvalidPos;
+  uint32_t tsh = 0;
+  int tlen = 0;
+  double ttotal = 1.;
+
+  auto add_to = [&](uint32_t pos, double d) {       // LinearRepresentation::update of one index (linear.cpp:198-216)
+    const double v = value_load(tab, pos) + d;
+    value_store(tab, pos, limit ? clampd(v, out_min, out_max) : v);
+  };
+  // checkSynchronize after one update() call (linear.cpp:267, representation.h:298-305)
+  auto count_call = [&](bool doit) {
+    bool fire = false;
+    if (doit)
+    {
+      sync_count++;
+      fire = sync_count >= (int64_t)P.target_interval;
+    }
+    if (rarely(__any(fire)))
+    {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");           // the pass reads what the calls so far have stored
+      target_sync_pass(P, tab, RS, tv, K, fire, j);
+      if (fire) { sync_count = 0; K++; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+  };
+
+  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  {
+    const int ti = P.test_interval;
+    const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
+    double obs[D], reward = 0, total_reward = 0;
+    int terminal = 0;
+    bool running = live;
+    if (live)
+    {
+      Env<ENV>::start(P, test, TL, G, x);
+      Env<ENV>::observe(P, x, obs);
+    }
+    double time = 0, action = 0;
+    int action_index = 0;
+    uint32_t p_pos = kInvalidPos, p_slot = 0;
+    bool p_sh = false;
+    if (!test)
+    { // TDAgent::start -> predictor->finalize() -> trace_->clear()
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e) tpos[e] = kInvalidPos;
+      tsh = 0; tlen = 0; ttotal = 1.;
+    }
+    bool first = true;
+
+    for (;;)
+    {
+      if (!__any(running)) break;
+      bool has_next = false, update = false;
+      uint32_t slot[NA], pos[NA];
+      double w[NA], tw[NA];
+      bool sh[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) { slot[a] = 0; pos[a] = kInvalidPos; w[a] = 0; tw[a] = 0; sh[a] = false; }
+      double q[NA], qt[NA], qsa = 0;
+      int a_next = 0, mai = 0, man = 1;
+      double best = 0, delta = 0, dW = 0, dT = 0;
+      if (running)
+      {
+        if (!first)
+        {
+          env_step<ENV>(P, x, action, obs, reward, terminal, status);
+          total_reward += reward;
+          time += 1;
+        }
+        has_next = first || terminal != 2;
+        update = !first && !test;
+        if (has_next)
+        {
+          uint32_t hpre = 449u ^ (uint32_t)(D + 2);
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+            hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, tile_quant(P.tile, i, obs[i]), j));
+          const uint32_t hpm = hpre * 0x5bd1e995u;
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+          {
+            uint32_t h = murmur_absorb(hpm ^ key_act[a], key_j);
+            const uint32_t hm = murmur_final(h), mem = (uint32_t)P.tile.memory;
+            slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (has_next)
+        {
+          table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+                        [&](uint32_t mp) {
+                          if (p_pos == mp) p_sh = true;
+#pragma unroll
+                          for (int e = 0; e < kMaxTrace; ++e) tsh |= (tpos[e] == mp) ? (1u << e) : 0u;
+                        });
+          // the target's value of the same slots.  A slot shared between tilings is materialised by one lane at a time
+          // (same value either way; the serialisation only keeps the first store from racing a second lane's read).
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+          {
+            if (!sh[a]) tw[a] = tval_get(P, RS, tv, pos[a], slot[a], K);
+            const uint32_t pa = pos[a], sa = slot[a];
+            double got = 0;
+            if (rarely(__any(sh[a]))) serial_lanes(sh[a], [&]() { got = tval_get(P, RS, tv, pa, sa, K); });
+            if (sh[a]) tw[a] = got;
+          }
+        }
+        double wp = 0;
+        if (update) wp = value_load(tab, p_pos);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { SHW(a, j, g) = w[a]; SHW(NA + 1 + a, j, g) = tw[a]; }
+        SHW(NA, j, g) = wp;
+      }
+      wave_sync();
+      if (running)
+      {
+        const int row = (j < NROWS) ? j : 0;
+        double sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += SHW(row, k, g);
+        sh_res[g * 16 + j] = sum / 16;
+      }
+      wave_sync();
+      if (running)
+      {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+        {
+          q[a] = has_next ? clampd(sh_res[g * 16 + a], out_min, out_max) : 0.;
+          qt[a] = has_next ? clampd(sh_res[g * 16 + NA + 1 + a], out_min, out_max) : 0.;
+        }
+        qsa = clampd(sh_res[g * 16 + NA], out_min, out_max);
+
+        // sampler (greedy.cpp:63-86, 144-218): the POLICY reads the main table
+        if (has_next)
+        {
+          findmax<NA>(q, mai, man, best);
+          if (test)
+            a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
+          else
+          {
+            if (time == 0.) eps_decay = fmax(eps_decay * P.decay_rate, P.decay_min);
+            S1 = lcg_next(S1);
+            const double rnd = lcg_double(S1);
+            if (rnd < eps_decay * P.epsilon)
+            {
+              G = lcg_next(G);
+              a_next = (int)(lcg_long(G) % (uint32_t)NA);
+            }
+            else
+              a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
+          }
+        }
+        if (update)
+        { // the TARGET comes from the target network (sarsa.cpp:107 / advantage.cpp:88)
+          double target = reward;
+          if (has_next)
+          {
+            if (P.agent == GRLX_AGENT_SARSA)
+              target += P.gamma * pick<double, NA>(qt, a_next);
+            else
+            {
+              double v = -__builtin_inf();
+#pragma unroll
+              for (int kk = 0; kk < NA; ++kk) v = fmax(v, qt[kk]);
+              target += P.gamma * v;
+            }
+          }
+          delta = target - qsa;
+          dW = P.alpha * (target - qsa);
+          dT = P.alpha * delta;
+        }
+      }
+
+      // -------- the update calls, one after the other, each followed by checkSynchronize()
+      if (__any(update))
+      {
+        // call 1: write(p, target, alpha) -- every index of p, in tiling order where tilings share the slot
+        if (update && !p_sh) add_to(p_pos, dW);
+        if (rarely(__any(update && p_sh))) serial_lanes(update && p_sh, [&]() { add_to(p_pos, dW); });
+        count_call(update);
+        if (use_trace)
+        {
+          // calls 2..: update(trace, alpha*delta, e), newest entry first while its weight exceeds 0.001
+          double weight = 1.;
+#pragma unroll
+          for (int e = 0; e < kMaxTrace; ++e)
+          {
+            const bool go = update && e < tlen && weight > 0.001;
+            if (__any(go))
+            {
+              const double de = weight * dT * ee;
+              const bool valid = go && tpos[e] != kInvalidPos;
+              const bool shared = ((tsh >> e) & 1u) != 0u;
+              const uint32_t at = tpos[e];
+              if (valid && !shared) add_to(at, de);
+              if (rarely(__any(valid && shared))) serial_lanes(valid && shared, [&]() { add_to(at, de); });
+              count_call(go);
+            }
+            weight *= ee;
+          }
+          // trace_->add(p, e) (trace.h:215-234): ssub against EVERY index of p (other tilings' through LDS), push, pop
+          if (update) sh_ppos[g * 16 + j] = p_sh ? p_pos : kInvalidPos;
+          wave_sync();
+          if (update)
+          {
+            if (ee < cut) { tlen = 0; ttotal = 1.; tsh = 0; }
+            const uint32_t shm = (uint32_t)((__ballot(update && p_sh) >> (16 * g)) & 0xFFFFull);
+#pragma unroll
+            for (int e = 0; e < kMaxTrace; ++e)
+            {
+              bool hit = tpos[e] == p_pos;
+              for (uint32_t mm = shm; mm != 0u; mm &= mm - 1u)
+                hit = hit || (tpos[e] != kInvalidPos && tpos[e] == sh_ppos[g * 16 + __builtin_ctz(mm)]);
+              if (e < tlen && hit) { tpos[e] = kInvalidPos; tsh &= ~(1u << e); }
+            }
+            if (tlen >= kMaxTrace) status |= ST_TRACE_OVERFLOW;       // cannot happen: validated at create
+#pragma unroll
+            for (int e = kMaxTrace - 1; e > 0; --e) tpos[e] = tpos[e - 1];
+            tsh = (tsh << 1) & ((1u << kMaxTrace) - 1u);
+            tpos[0] = p_pos;
+            if (p_sh) tsh |= 1u;
+            tlen = (tlen < kMaxTrace) ? tlen + 1 : kMaxTrace;
+            ttotal *= ee;
+            while (ttotal < cut && tlen > 1)
+            {
+              ttotal /= ee;
+              tlen--;
+            }
+#pragma unroll
+            for (int e = 0; e < kMaxTrace; ++e)
+              if (e >= tlen) { tpos[e] = kInvalidPos; tsh &= ~(1u << e); }
+          }
+          wave_sync();
+        }
+      }
+
+      if (running)
+      {
+        // -------- tap
+        if (tapped && (!first || P.tap_starts))
+        {
+          uint32_t n = *P.tap_count;
+          if (n < (uint32_t)P.tap_capacity)
+          {
+            grlx_tap *tp = &P.taps[n];
+            tp->p_idx[j] = update ? p_slot : 0u;
+            tp->p_idx[16 + j] = 0u;
+            if (j == 0)
+            {
+              tp->test = test;
+              tp->action_index = has_next ? a_next : action_index;
+              tp->terminal = first ? -1 : terminal;
+              tp->trace_len = tlen;
+              for (int i = 0; i < GRLX_MAX_DIMS; ++i) tp->obs[i] = (i < D) ? obs[i] : 0.;
+              tp->action = has_next ? pick<double, NA>(acts, a_next) : action;
+              tp->reward = reward;
+              for (int i = 0; i < GRLX_MAX_STATE; ++i) tp->state[i] = (i < S) ? x[i] : 0.;
+              tp->delta = delta;
+              for (int a = 0; a < kMaxActions; ++a) tp->q[a] = 0.;
+#pragma unroll
+              for (int a = 0; a < NA; ++a) tp->q[a] = has_next ? q[a] : 0.;
+            }
+          }
+          wave_sync();
+          if (j == 0) *P.tap_count = n + 1u;
+        }
+        if (!first)
+        {
+          if (test) test_steps++;
+          else ss++;
+        }
+        if (has_next)
+        {
+          action_index = a_next;
+          action = pick<double, NA>(acts, a_next);
+          p_pos = pick<uint32_t, NA>(pos, a_next);
+          p_slot = pick<uint32_t, NA>(slot, a_next);
+          p_sh = pick<bool, NA>(sh, a_next);
+        }
+        if (!first && terminal) running = false;
+        first = false;
+      }
+    }
+
+    if (live && (ti >= 0 ? test : 1))
+    {
+      if (rows < (uint32_t)P.max_rows)
+      {
+        if (j == 0)
+        {
+          size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
+          P.row_reward[at] = total_reward;
+          P.row_time[at] = time;
+          P.row_steps[at] = ss;
+          P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
+        }
+        rows++;
+      }
+      else
+        status |= ST_ROWS_FULL;
+    }
+  }
+
+  uint32_t ins = inserted;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) ins += __shfl_xor(ins, off, 16);
+  if (live && j == 0)
+  {
+#pragma unroll
+    for (int i = 0; i < S; ++i) RS.x[i] = x[i];
+    RS.G = G;
+    RS.TL = TL;
+    RS.S1 = S1;
+    RS.eps_decay = eps_decay;
+    RS.tt = tt;
+    RS.ss = ss;
+    RS.test_steps = test_steps;
+    RS.n_slots[0] += ins;
+    RS.rows = rows;
+    RS.sync_count = sync_count;
+    RS.syncs = K;
+  }
+  uint32_t st = status;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+  if (live && j == 0) RS.status = st;
+}
+
+hipError_t launch_rollout_tgt(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
+{
+  if (variant) *variant = GRLX_KERNEL_IN_PLACE;
+  int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (P.env == GRLX_ENV_PENDULUM && P.A == 3)
+    hipLaunchKernelGGL((rollout_tgt_kernel<GRLX_ENV_PENDULUM, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+  else if (P.env == GRLX_ENV_ACROBOT && P.A == 3)
+    hipLaunchKernelGGL((rollout_tgt_kernel<GRLX_ENV_ACROBOT, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// current target-network value of reference slots (no insertion)
+__global__ void get_target_weights_kernel(DevParams P, int replica, const uint32_t *slots, int n, double *out)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Table tab = table_of(P, 0, replica);
+  const ReplicaState &rs = P.states[replica];
+  const double *tv = P.tvals + ((size_t)replica << P.logC);
+  const uint32_t slot = slots[i];
+  uint32_t b = table_home(tab, slot);
+  double v = target_from_init(P, rs, slot, rs.syncs);
+  for (int it = 0; it < kMaxProbe; ++it)
+  {
+    const BucketRegs br = bucket_load(tab, b);
+    uint32_t empty;
+    const int way = bucket_find(br.k, slot, empty);
+    if (way >= 0)
+    {
+      const double t = tv[(b << 2) | (uint32_t)way];
+      if ((unsigned long long)__double_as_longlong(t) != kTvalUnset) v = t;
+      break;
+    }
+    if (empty != 0u) break;
+    b = (b + 1u) & tab.bmask;
+  }
+  out[i] = v;
+}
+
+hipError_t launch_get_target_weights(const DevParams &P, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream)
+{
+  int blocks = (n + 255) / 256;
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(get_target_weights_kernel, dim3(blocks), dim3(256), 0, stream, P, replica, slots_dev, n, out_dev);
+  return hipGetLastError();
+}
+
+} // namespace grlx

@@ -366,7 +366,8 @@ GRLX_REGISTER(TileCodingProjector)
 struct LinearRepresentation : Configurable {
   GRLX_TYPEINFO("representation/parameterized/linear")
   VecD init_min, init_max, output_min, output_max;
-  int memory = 8 * 1024 * 1024, outputs = 1, limit = 1;
+  int memory = 8 * 1024 * 1024, outputs = 1, limit = 1, interval = 0;
+  double tau = 1;
   void request(const std::string &, ConfigurationRequest *config) override
   {
     config->push_back(CRP("init_min", "Lower initial value limit", VecD{0.}));
@@ -393,8 +394,9 @@ struct LinearRepresentation : Configurable {
     output_max = config["output_max"].v();
     if (output_max.empty()) output_max.assign((size_t)outputs, DBL_MAX);
     if ((int)output_max.size() != outputs) throw bad_param("representation/parameterized/linear:output_max");
-    if ((double)config["interval"] != 0. || (double)config["tau"] != 1.)
-      throw Exception(path() + ": target networks are outside the accelerated path");
+    interval = (int)(double)config["interval"];                   // ParameterizedRepresentation (representation.h:173-190)
+    tau = config["tau"];
+    if (interval < 0 || !(tau >= 0 && tau <= 1)) throw bad_param("representation/parameterized/linear:{interval,tau}");
   }
 };
 GRLX_REGISTER(LinearRepresentation)
@@ -887,6 +889,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       lower_linear(cr->representation, cr->projector, &c->representation);
       lower_tile(pol->projector, &c->actor_projector);
       lower_linear(pol->representation, pol->projector, &c->actor_representation);
+      if (cr->representation->interval || pol->representation->interval)
+        throw Exception(path() + ": target networks (interval) are built for predictor/critic/sarsa and predictor/critic/q only");
       c->alpha = cr->alpha; c->gamma = cr->gamma; c->lambda = cr->lambda;
       c->trace = cr->trace ? cr->trace->kind() : GRLX_TRACE_NONE;
       c->actor_alpha = ac->alpha;
@@ -924,6 +928,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     const EpsilonGreedySampler *sm = static_cast<const EpsilonGreedySampler *>(pol->sampler);
     c->epsilon = sm->epsilon[0]; c->decay_rate = sm->decay_rate; c->decay_min = sm->decay_min;
     c->agent = pred->agent_id();
+    c->target_interval = pol->representation->interval;              // target network of the Q table (representation.h:161-306)
+    c->target_tau = pol->representation->tau;
     c->alpha = pred->alpha; c->gamma = pred->gamma; c->lambda = pred->lambda; c->kappa = pred->kappa;
     c->trace = pred->trace ? pred->trace->kind() : GRLX_TRACE_NONE;
     if (const QVPredictor *qv = dynamic_cast<const QVPredictor *>(pred))

@@ -164,6 +164,14 @@ class Runner:
         capi.check(self.lib.grlx_get_weights(self._ctx, table, replica, _ptr(slots, C.c_uint32), slots.size, _ptr(out, C.c_double)))
         return out
 
+    def target_weights(self, replica: int, slots):
+        """Values of the Q table's target network (representation `interval` / `tau`) and the synchronisations so far."""
+        slots = np.ascontiguousarray(slots, dtype=np.uint32)
+        out = np.zeros(slots.size, np.float64)
+        n = C.c_uint32()
+        capi.check(self.lib.grlx_get_target_weights(self._ctx, replica, _ptr(slots, C.c_uint32), slots.size, _ptr(out, C.c_double), C.byref(n)))
+        return out, n.value
+
     def export_weights(self, replica: int, table: int = 0):
         """Dense double[memory] parameter vector, as grl's .dat files hold it (representation.h:201-229)."""
         t = self.cfg.actor_projector if table == 1 else self.cfg.projector

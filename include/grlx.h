@@ -132,6 +132,14 @@ typedef struct {
    * next step's table loads) instead of the in-place diagnostic ordering: per-step parity of the kernel that is benchmarked.
    * Built for the pendulum and the acrobot with 3 actions (SARSA / Q / Expected SARSA, replacing or no trace). */
   int32_t  tap_deferred;
+  /* representation/parameterized/linear: interval, tau (ParameterizedRepresentation, representation.h:161-306): a TARGET
+   * NETWORK on the Q table.  target_interval > 0: SARSA / Q-learning read their targets from a second copy of the
+   * parameters (sarsa.cpp:107, advantage.cpp:88), synchronised as tau*params + (1-tau)*target (tau = 0: plain copy) every
+   * target_interval LinearRepresentation::update calls (linear.cpp:267: one per write and one per trace entry).  Served by
+   * its own plain kernel (pendulum / acrobot, 3 actions, replacing or no trace); 0 = none. */
+  int32_t  target_interval;
+  int32_t  reserved1;
+  double   target_tau;
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;
@@ -222,6 +230,9 @@ int  grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4] /* G, TL, S1, S2 *
  * representation.h:201-263): current weights of the given reference slots. */
 int  grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out);
 int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used);
+/* Replaces reading target()->params() (representation.h:266-282): the target network's current value of the given
+ * reference slots of the Q table, and the number of synchronisations so far; contexts with target_interval > 0 only. */
+int  grlx_get_target_weights(grlx_ctx *ctx, int replica, const uint32_t *slots, int n, double *out, uint32_t *n_syncs);
 /* Replaces ParameterizedRepresentation's {action: load} (representation.h:231-263, driven by
  * experiment/online_learning:load_file, online_learning.cpp:140-150): setParams() with the raw
  * little-endian double[memory] image of a .dat file.  Every weight of `table` of the replicas

@@ -81,6 +81,18 @@ static double lin_read(orc_exp *e, int table, const orc_linear_spec *ls, const o
   return r;
 }
 
+static void target_synchronize(orc_exp *e)
+{ /* ParameterizedRepresentation::synchronize (representation.h:284-296): over the WHOLE parameter vector */
+  const size_t n = (size_t)e->spec.projector.memory;
+  const double tau = e->spec.target_tau;
+  if (tau)
+    for (size_t i = 0; i < n; ++i) e->wt[i] = tau * e->w[0][i] + (1 - tau) * e->wt[i];
+  else
+    memcpy(e->wt, e->w[0], n * sizeof(double));
+  e->sync_count = 0;
+  e->syncs++;
+}
+
 static void lin_update(orc_exp *e, int table, const orc_linear_spec *ls, const orc_proj *p, double delta)
 { /* linear.cpp:198-216: every valid index, duplicates applied twice */
   double *w = e->w[table];
@@ -93,6 +105,21 @@ static void lin_update(orc_exp *e, int table, const orc_linear_spec *ls, const o
         w[p->idx[i]] = w[p->idx[i]] + delta;
       e->stats.weight_rmws++;
     }
+  if (table == 0 && e->wt)
+  { /* checkSynchronize (linear.cpp:267, representation.h:298-305): once per update() call */
+    e->sync_count++;
+    if (e->sync_count >= e->spec.target_interval) target_synchronize(e);
+  }
+}
+
+static double lin_read_target(orc_exp *e, const orc_linear_spec *ls, const orc_proj *p)
+{ /* representation_->target()->read(...): the target network when there is one (representation.h:266-272) */
+  if (!e->wt) return lin_read(e, 0, ls, p);
+  double *keep = e->w[0];
+  e->w[0] = e->wt;
+  const double r = lin_read(e, 0, ls, p);
+  e->w[0] = keep;
+  return r;
 }
 
 static void lin_write(orc_exp *e, int table, const orc_linear_spec *ls, const orc_proj *p, double target, double alpha)
@@ -260,7 +287,7 @@ static double sarsa_update(orc_exp *e, const double *prev_obs, double prev_actio
   if (has_action)
   {
     project_sa(e, obs, action, &pn);
-    target += orc_m_powtau(s, s->gamma, tau) * lin_read(e, 0, &s->representation, &pn);
+    target += orc_m_powtau(s, s->gamma, tau) * lin_read_target(e, &s->representation, &pn);     /* sarsa.cpp:107 */
   }
   double delta = target - lin_read(e, 0, &s->representation, &p);
   lin_write(e, 0, &s->representation, &p, target, s->alpha);
@@ -328,7 +355,7 @@ static double q_update(orc_exp *e, const double *prev_obs, double prev_action, d
     for (int kk = 0; kk < e->A; ++kk)
     {
       project_sa(e, obs, e->actions[kk], &pa);
-      v = fmax(v, lin_read(e, 0, &s->representation, &pa));
+      v = fmax(v, lin_read_target(e, &s->representation, &pa));                                /* advantage.cpp:88 */
     }
     target += orc_m_powtau(s, s->gamma, tau) * v;
   }
@@ -590,8 +617,17 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
     e->w[1] = table_alloc_init(e, &spec->actor_projector, &spec->actor_representation);
     if (!e->w[1]) { free(e); return NULL; }
   }
+  if (spec->target_interval > 0)
+  { /* ParameterizedRepresentation::configure (representation.h:186-190) reinstantiates the representation as its
+     * target BEFORE the object's own configure() continues: the target's reset() draws its memory*outputs uniforms
+     * first, the main table's reset() draws the next ones and then synchronises (linear.cpp:117-122) */
+    if (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q) { free(e); return NULL; }
+    e->wt = table_alloc_init(e, &spec->projector, &spec->representation);
+    if (!e->wt) { free(e); return NULL; }
+  }
   e->w[0] = table_alloc_init(e, &spec->projector, &spec->representation);
-  if (!e->w[0]) { free(e->w[1]); free(e); return NULL; }
+  if (!e->w[0]) { free(e->w[1]); free(e->wt); free(e); return NULL; }
+  if (e->wt) { target_synchronize(e); e->syncs = 0; }
   if (spec->agent == ORC_AGENT_QV)
   { /* cfg/pendulum/qv_tc.yaml order: the policy's Q representation first, then the predictor's
      * v_representation; both draw from the same thread-local stream */
@@ -617,6 +653,7 @@ void orc_destroy(orc_exp *e)
   if (!e) return;
   free(e->w[0]);
   free(e->w[1]);
+  free(e->wt);
   free(e);
 }
 
@@ -785,7 +822,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
 
 /* ------------------------------------------------------------ accessors -- */
 void orc_get_stats(const orc_exp *e, orc_stats *out) { *out = e->stats; }
-const double *orc_weights(const orc_exp *e, int table) { return (table == 0 || table == 1) ? e->w[table] : NULL; }
+const double *orc_weights(const orc_exp *e, int table) { return (table == 0 || table == 1) ? e->w[table] : (table == 2 ? e->wt : NULL); }
+int64_t orc_target_syncs(const orc_exp *e) { return e->syncs; }
 
 /* ParameterizedRepresentation {action: load} (representation.h:231-263): setParams() overwrites
  * every weight of the table; nothing else of the experiment changes. */

@@ -132,6 +132,11 @@ typedef struct {
   /* policy/parameterized/pid (ORC_AGENT_PID): `p` gains and `setpoint`, one per observation dimension, one output */
   double pid_p[ORC_MAX_DIMS];
   double pid_setpoint[ORC_MAX_DIMS];
+  /* ParameterizedRepresentation target network of the Q table (representation.h:161-306; SARSA and Q-learning read their
+   * targets from it, sarsa.cpp:107, advantage.cpp:88): `interval` counts LinearRepresentation::update calls (one per
+   * write, one per trace entry: linear.cpp:267), 0 = no target network; `tau` is the synchronisation strength */
+  int    target_interval;
+  double target_tau;
 } orc_spec;
 
 /* fill with the values of the reference's tests/pendulum-sarsa-tc.yaml */
@@ -199,7 +204,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             orc_tap *tap, int tap_cap, int *tap_n);
 
 void          orc_get_stats(const orc_exp *e, orc_stats *out);
-const double *orc_weights(const orc_exp *e, int table);        /* table 0: Q/critic, 1: actor */
+const double *orc_weights(const orc_exp *e, int table);        /* table 0: Q/critic, 1: actor, 2: target network of table 0 */
+int64_t       orc_target_syncs(const orc_exp *e);              /* synchronisations of the target network so far */
 /* {action: load} of a representation (representation.h:231-263): overwrite all n = memory weights; 0 or -1 */
 int           orc_set_weights(orc_exp *e, int table, const double *w, size_t n);
 void          orc_get_state(const orc_exp *e, double *state);  /* current env state           */

@@ -28,6 +28,9 @@ struct orc_exp {
   orc_rand48 TL;                        /* thread-local RandGen instance              */
   orc_rand48 S1, S2;                    /* learning / test sampler private Rand       */
   double    *w[2];                      /* weight tables: 0 = Q or critic, 1 = actor  */
+  double    *wt;                        /* target network of table 0 (NULL without one) */
+  int64_t    sync_count;                /* ParameterizedRepresentation::count_          */
+  int64_t    syncs;                     /* synchronisations so far (diagnostics)        */
   int        A;                         /* number of discrete actions                 */
   double     actions[ORC_MAX_ACTIONS];
   double     state[ORC_MAX_STATE];

@@ -43,7 +43,8 @@ class Spec(C.Structure):
                 ("actor_alpha", C.c_double), ("sigma", C.c_double), ("theta", C.c_double),
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double),
                 ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int), ("kappa", C.c_double), ("beta", C.c_double),
-                ("pid_p", C.c_double * MAX_DIMS), ("pid_setpoint", C.c_double * MAX_DIMS)]
+                ("pid_p", C.c_double * MAX_DIMS), ("pid_setpoint", C.c_double * MAX_DIMS),
+                ("target_interval", C.c_int), ("target_tau", C.c_double)]
 
 
 class FqiSpec(C.Structure):
@@ -104,6 +105,7 @@ def load():
     L.orc_get_stats.argtypes = [C.c_void_p, P(Stats)]
     L.orc_weights.argtypes = [C.c_void_p, C.c_int]; L.orc_weights.restype = P(C.c_double)
     L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_double), C.c_size_t]; L.orc_set_weights.restype = C.c_int
+    L.orc_target_syncs.argtypes = [C.c_void_p]; L.orc_target_syncs.restype = C.c_int64
     L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
     L.orc_rng_states.argtypes = [C.c_void_p, P(C.c_uint64)]
     L.orc_format_row.argtypes = [P(Row), C.c_char_p, C.c_size_t]; L.orc_format_row.restype = C.c_int

@@ -1,0 +1,79 @@
+"""Target networks on the Q table (representation/parameterized/linear: interval, tau; representation.h:161-306):
+rollout_tgt_kernel against the oracle -- per-step records, rows, RNG positions, the main table, the target table and
+the number of synchronisations.  The reference ships no test for them: parity unpinned by reference tests."""
+import numpy as np
+import pytest
+
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shapes {a.shape} vs {b.shape}"
+    bad = np.nonzero(bits(a).ravel() != bits(b).ravel())[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}: {a.ravel()[bad[0]]!r} vs {b.ravel()[bad[0]]!r}"
+
+
+@pytest.mark.parametrize("env,agent,interval,tau,trace,memory", [
+    ("pendulum", 0, 1000, 1.0, 1, 8388608),       # hard update every 1000 update() calls (~ every 100 steps)
+    ("pendulum", 1, 137, 0.0, 1, 8388608),        # tau = 0: setParams(params()); a synchronisation in the middle of most steps' trace updates
+    ("pendulum", 0, 500, 0.25, 1, 8388608),       # Polyak averaging: untouched slots follow the K-fold recurrence from the target's own draw
+    ("pendulum", 1, 64, 0.5, 0, 8388608),         # no trace: one update() call per step
+    ("pendulum", 0, 300, 0.3, 1, 2048),           # tiny hash memory: nearly every slot shared between tilings
+    ("acrobot", 1, 200, 0.1, 1, 8388608),
+])
+def test_target_network_bit_exact(grlx, env, agent, interval, tau, trace, memory):
+    from tests import configs
+    from tests.test_gpu_parity import _compare_taps
+    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot}[env]
+    seeds, trials, cap = [71, 72, 73, 74, 75, 76, 77], 24, 2600
+    cfg, spec = make(grlx, len(seeds), agent=agent, tap_replica=5, tap_capacity=cap)
+    for obj in (cfg, spec):
+        obj.target_interval, obj.target_tau, obj.trace = interval, tau, trace
+        obj.projector.memory = memory
+    r = grlx.Runner(cfg, seeds)
+    r.run(7); r.run(9); r.run(8); r.sync()                    # three launches: count_ and the synchronisation number persist
+    rng = np.random.default_rng(23)
+    slots = np.unique(np.concatenate([rng.integers(0, memory, 1500), np.arange(0, min(memory, 4096))])).astype(np.uint32)
+    D = 2 if env == "pendulum" else 4
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(spec, seed=int(seed))
+        rows, otaps = e.run(trials, tap_cap=cap)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        assert list(r.rng(k))[:3] == list(e.rng())[:3], f"RNG positions of replica {k}"
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+        assert_bit_equal(r.weights(k, slots), e.weights(slots), f"main table of replica {k}")
+        tw, syncs = r.target_weights(k, slots)
+        assert syncs == e.L.orc_target_syncs(e.h) and syncs > 0, (syncs, e.L.orc_target_syncs(e.h))
+        assert_bit_equal(tw, e.weights(slots, table=2), f"target table of replica {k}")
+        if k == 5:
+            gtaps = r.taps()
+            assert len(gtaps) == len(otaps) and len(otaps) > 100
+            for i, (gt, ot) in enumerate(zip(gtaps, otaps)):
+                try:
+                    _compare_taps(gt, ot, A=3, D=D)
+                except AssertionError as ex:
+                    raise AssertionError(f"step {i}: {ex}")
+        e.close()
+    r.close()
+
+
+def test_target_network_validation(grlx):
+    capi = grlx.capi
+    for over in (dict(target_interval=-1), dict(target_interval=10, target_tau=1.5), dict(target_interval=10, agent=3),
+                 dict(target_interval=10, trace=2), dict(target_interval=10, action_steps=5)):
+        with pytest.raises(capi.GrlxError) as ei:
+            grlx.Runner(grlx.pendulum_sarsa_config(1, **over), [1])
+        assert ei.value.code == capi.ERR_INVALID
+    r = grlx.Runner(grlx.pendulum_sarsa_config(2), [1, 2])
+    with pytest.raises(capi.GrlxError):
+        r.target_weights(0, [1, 2, 3])                      # no target network in this context
+    r.close()
