@@ -77,3 +77,24 @@ def test_target_network_validation(grlx):
     with pytest.raises(capi.GrlxError):
         r.target_weights(0, [1, 2, 3])                      # no target network in this context
     r.close()
+
+
+def test_deployer_target_network(grlx, tmp_path):
+    """grlxd on the reference's golden yaml with `interval: 700` / `tau: 0.4` on the policy's representation (the yaml keys of
+    ParameterizedRepresentation, representation.h:173-176): rows = the oracle's."""
+    import os
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+    old = "        output_max: [  ]\n        type: representation/parameterized/linear"
+    assert old in text
+    y = tmp_path / "tgt.yaml"
+    y.write_text(text.replace(old, "        output_max: [  ]\n        interval: 700\n        tau: 0.4\n        type: representation/parameterized/linear")
+                 .replace("trials: 2000", "trials: 33"))
+    res = subprocess.run([grlxd, "-s", "5", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.Experiment(ob.pendulum_sarsa_spec(target_interval=700, target_tau=0.4), seed=5)
+    rows, _ = e.run(33)
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)
+    assert e.L.orc_target_syncs(e.h) > 10
