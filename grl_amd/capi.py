@@ -18,7 +18,7 @@ TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
 
 class TileSpec(C.Structure):
-    _fields_ = [("tilings", C.c_int32), ("memory", C.c_int32), ("dims", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("tilings", C.c_int32), ("memory", C.c_int32), ("dims", C.c_int32), ("safe", C.c_int32),
                 ("resolution", C.c_double * MAX_DIMS), ("wrapping", C.c_double * MAX_DIMS)]
 
 

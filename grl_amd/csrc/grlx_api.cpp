@@ -85,6 +85,7 @@ int make_tile_params(const grlx_tile_spec &ts, TileParams *tp)
   if (ts.dims < 1 || ts.dims > GRLX_MAX_DIMS) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution (dims %d)", ts.dims);
   if (ts.tilings < 1 || ts.tilings > 32) return fail(GRLX_ERR_INVALID, "projector/tile_coding:tilings (%d)", ts.tilings);
   if (ts.memory < 1 || ts.memory >= (1 << 26)) return fail(GRLX_ERR_INVALID, "projector/tile_coding:memory (1 .. 2^26-1 supported)");
+  if (ts.safe < 0 || ts.safe > 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe (0 and 1 are built; 2 = claim always is not)");
   memset(tp, 0, sizeof(*tp));
   tp->T = ts.tilings;
   tp->D = ts.dims;
@@ -229,6 +230,16 @@ int make_params(const grlx_config &c, DevParams *P)
     P->beta = c.beta;
   }
 
+  if (c.projector.safe == 1)
+  { // claim table of the tile coding: its own (plain) kernel
+    if ((c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q) || (c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) ||
+        c.action_steps != 3 || c.trace == GRLX_TRACE_ACCUMULATING)
+      return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe = 1 is built for predictor/critic/sarsa and predictor/critic/q on the pendulum and the "
+                                    "acrobot with 3 actions, replacing or no trace");
+    if (c.env == GRLX_ENV_ACROBOT && c.target_interval > 0) return fail(GRLX_ERR_INVALID, "safe = 1 together with a target network is built for the pendulum");
+    P->tile_safe = 1;
+  }
+  if ((ac || qv) && c.actor_projector.safe != 0) return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe on the second table");
   if (c.target_interval < 0 || !std::isfinite(c.target_tau)) return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:{interval,tau}");
   if (c.target_interval > 0)
   { // target network of the Q table: its own (plain) kernel
@@ -466,7 +477,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   P.tap_starts = cfg->tap_starts != 0 ? 1 : 0;
   P.tap_deferred = (cfg->tap_deferred != 0 && P.tap_capacity > 0) ? 1 : 0;
   { // replicas per wave: wide waves once the batch outnumbers the SIMDs four to one (taps and stamps: always 4)
-    const bool has_wide = cfg->target_interval == 0 && (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA ||
+    const bool has_wide = cfg->target_interval == 0 && cfg->projector.safe == 0 && (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA ||
                            cfg->agent == GRLX_AGENT_AC) && cfg->trace != GRLX_TRACE_ACCUMULATING;
     int rpw = cfg->replicas_per_wave;
     if (rpw == 0)
@@ -641,7 +652,7 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
       HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.agent == GRLX_AGENT_QV)
       HIP_TRY(launch_rollout_qv(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
-    else if (ctx->cfg.target_interval > 0)
+    else if (ctx->cfg.target_interval > 0 || ctx->cfg.projector.safe != 0)
       HIP_TRY(launch_rollout_tgt(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
       HIP_TRY(launch_rollout_acc(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
@@ -879,6 +890,7 @@ int grlx_project(const grlx_tile_spec *spec, const double *in, int n, uint32_t *
   TileParams tp;
   int rc = make_tile_params(*spec, &tp);
   if (rc != GRLX_OK) return rc;
+  if (spec->safe != 0) return fail(GRLX_ERR_INVALID, "grlx_project is stateless: projector/tile_coding:safe needs the claim table of a context");
   if (!have_device()) return fail(GRLX_ERR_NO_DEVICE, "no HIP device: grlx has no CPU fallback");
   if (n == 0) return GRLX_OK;
   DevBuf din, dout;

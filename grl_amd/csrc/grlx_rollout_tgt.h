@@ -69,11 +69,18 @@ __device__ __noinline__ void target_sync_pass(const DevParams &P, const Table &t
   }
 }
 
-template <int ENV, int NA>
+// SAFE: projector/tile_coding:safe = 1 (tile_coding.h:116-151).  A slot can be CLAIMED by the full 32-bit hash sum of a
+// projection; a projection with another hash sum that lands on a claimed slot walks on to the next slot that is free or
+// its own.  Single projections claim -- project(prev_obs, prev_action), SARSA's project(obs, action), the critique's
+// project(prev_obs, action) -- the policy's batch projections do not (tile_coding.h:62-73).  The claim lives in the `aux`
+// word of the sparse entry (hash sum + 1; 0 = free, the reference's -1).  Claims of one projection are made in tiling
+// order: a lane finalises its slot only when every lower tiling of its replica has, and not on a slot a lower tiling is
+// taking with another hash sum in the same round.
+template <int ENV, int NA, bool TARGET, bool SAFE>
 __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_trials)
 {
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
-  constexpr int NROWS = 2 * NA + 1;                  // Q(s', .), Q(s, a), Q_target(s', .)
+  constexpr int NROWS = 2 * NA + 2;                  // Q(s', .), Q(s, a), Q_target(s', .), SAFE: Q_target at the claimed project(s', a')
   static_assert(NROWS <= 16, "one lane per row of sums");
   __shared__ double   sh_w[NROWS * 16 * 4];
   __shared__ uint32_t sh_mb[4 * NA * 16];
@@ -81,6 +88,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
   __shared__ uint32_t sh_mail[4];
   __shared__ double   sh_res[4 * 16];
   __shared__ uint32_t sh_ppos[4 * 16];
+  __shared__ uint32_t sh_pii[4 * 16], sh_ph[4 * 16];      // SAFE: tentative slot and hash sum of every tiling of a projection
   __shared__ uint64_t sh_jump[2048];
   jump_table_to_lds(sh_jump);
 
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
   uint32_t K = RS.syncs;
 
   const Table tab = table_of(P, 0, r);
-  double *tv = P.tvals + ((size_t)r << P.logC);
+  double *tv = TARGET ? P.tvals + ((size_t)r << P.logC) : nullptr;
   const double out_min = P.lin.out_min, out_max = P.lin.out_max;
   const bool limit = P.lin.limit != 0;
   const bool use_trace = P.trace_kind == GRLX_TRACE_REPLACING;
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
   };
   // checkSynchronize after one update() call (linear.cpp:267, representation.h:298-305)
   auto count_call = [&](bool doit) {
+    if (!TARGET) return;
     bool fire = false;
     if (doit)
     {
@@ -147,6 +156,58 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
       target_sync_pass(P, tab, RS, tv, K, fire, j);
       if (fire) { sync_count = 0; K++; }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+  };
+
+  // SAFE: getFeatureLocation (tile_coding.h:116-151) for the lanes of the groups flagged `active` (group-uniform):
+  // walk from h % memory over slots claimed by other hash sums; with `claim`, take the slot in tiling order.
+  const uint32_t mem_u = (uint32_t)P.tile.memory;
+  auto probe = [&](bool active, uint32_t h, bool claim, uint32_t &slot_out, uint32_t &pos_out, double &w_out, bool &sh_out, auto on_share) {
+    uint32_t ii = h % mem_u;
+    bool pend = active;
+    uint32_t pos1[1] = {kInvalidPos};
+    double w1[1] = {0};
+    bool sh1[1] = {false};
+    for (int round = 0; round < 4096; ++round)
+    {
+      if (!__any(pend)) break;
+      // walk: every lane of an active group looks its current slot up (finished lanes repeat theirs: idempotent)
+      bool moved = false;
+      if (active)
+      {
+        uint32_t s1[1] = {ii};
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        table_get<1>(tab, P.lin, RS, 0, s1, pos1, w1, sh1, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, on_share);
+        const uint32_t aux = tab.base[(pos1[0] >> 2) & tab.bmask].aux[pos1[0] & 3u];
+        moved = pend && aux != 0u && aux != h + 1u;                       // claimed by another hash sum
+        if (moved) ii = (ii + 1u >= mem_u) ? 0u : ii + 1u;
+      }
+      if (__any(moved)) continue;                                          // someone is still walking
+      if (!claim) { pend = false; continue; }
+      // every pending lane stands on a slot that is free or its own: finalise in tiling order
+      if (active) { sh_pii[g * 16 + j] = pend ? ii : 0xFFFFFFFFu; sh_ph[g * 16 + j] = h; }
+      wave_sync();
+      bool lose = false;
+      if (pend)
+        for (int k = 0; k < j; ++k)
+          lose = lose || (sh_pii[g * 16 + k] == ii && sh_ph[g * 16 + k] != h);
+      const uint32_t losers = (uint32_t)((__ballot(pend && lose) >> (16 * g)) & 0xFFFFull);
+      const bool fin = pend && !lose && (losers & ((1u << j) - 1u)) == 0u;   // no lower tiling still has to move
+      if (fin)
+      {
+        tab.base[(pos1[0] >> 2) & tab.bmask].aux[pos1[0] & 3u] = h + 1u;
+        pend = false;
+      }
+      wave_sync();
+      // a loser's slot is being claimed by a lower tiling with another hash sum: it walks on next round
+    }
+    if (pend) status |= ST_TABLE_FULL;
+    if (active)
+    {
+      slot_out = ii;
+      pos_out = pos1[0];
+      w_out = w1[0];
+      sh_out = sh1[0];
     }
   };
 
@@ -164,7 +225,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
     }
     double time = 0, action = 0;
     int action_index = 0;
-    uint32_t p_pos = kInvalidPos, p_slot = 0;
+    uint32_t p_pos = kInvalidPos, p_slot = 0, hp = 0, hpm_prev = 0;
     bool p_sh = false;
     if (!test)
     { // TDAgent::start -> predictor->finalize() -> trace_->clear()
@@ -178,14 +239,29 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
     {
       if (!__any(running)) break;
       bool has_next = false, update = false;
-      uint32_t slot[NA], pos[NA];
+      uint32_t slot[NA], pos[NA], hfull[NA];
       double w[NA], tw[NA];
       bool sh[NA];
 #pragma unroll
-      for (int a = 0; a < NA; ++a) { slot[a] = 0; pos[a] = kInvalidPos; w[a] = 0; tw[a] = 0; sh[a] = false; }
+      for (int a = 0; a < NA; ++a) { slot[a] = 0; pos[a] = kInvalidPos; hfull[a] = 0; w[a] = 0; tw[a] = 0; sh[a] = false; }
       double q[NA], qt[NA], qsa = 0;
       int a_next = 0, mai = 0, man = 1;
       double best = 0, delta = 0, dW = 0, dT = 0;
+      uint32_t hpm = 0;
+      auto share_event = [&](uint32_t mp) {               // a slot became shared between tilings: its entries are updated serially from now on
+        if (p_pos == mp) p_sh = true;
+#pragma unroll
+        for (int e = 0; e < kMaxTrace; ++e) tsh |= (tpos[e] == mp) ? (1u << e) : 0u;
+      };
+      // the target network's value of a looked-up slot (TARGET), else the main table's; shared slots one lane at a time
+      // (same value either way; the serialisation only keeps the first store from racing a second lane's read)
+      auto target_value = [&](bool active, uint32_t pa, uint32_t sa, bool shared, double main_value) -> double {
+        if (!TARGET) return main_value;
+        double got = 0;
+        if (active && !shared) got = tval_get(P, RS, tv, pa, sa, K);
+        if (rarely(__any(active && shared))) serial_lanes(active && shared, [&]() { got = tval_get(P, RS, tv, pa, sa, K); });
+        return got;
+      };
       if (running)
       {
         if (!first)
@@ -202,36 +278,56 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
 #pragma unroll
           for (int i = 0; i < D; ++i)
             hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, tile_quant(P.tile, i, obs[i]), j));
-          const uint32_t hpm = hpre * 0x5bd1e995u;
+          hpm = hpre * 0x5bd1e995u;
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
             uint32_t h = murmur_absorb(hpm ^ key_act[a], key_j);
-            const uint32_t hm = murmur_final(h), mem = (uint32_t)P.tile.memory;
-            slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
+            hfull[a] = murmur_final(h);
+            const uint32_t mem = (uint32_t)P.tile.memory;
+            slot[a] = ((mem & (mem - 1u)) == 0u) ? (hfull[a] & (mem - 1u)) : (hfull[a] % mem);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        if (has_next)
+      }
+      // -------- policy: Q(s', .) -- the batch projections of QPolicy::values (no claims under safe = 1)
+      if (SAFE)
+      {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) probe(running && has_next, hfull[a], false, slot[a], pos[a], w[a], sh[a], share_event);
+      }
+      else if (running && has_next)
+        table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, share_event);
+      // -------- criticize: p = project(prev_obs, prev_action), a single projection (claims under safe = 1)
+      if (SAFE)
+      {
+        uint32_t ps = 0;
+        double unused = 0;
+        probe(running && update, hp, true, ps, p_pos, unused, p_sh, share_event);
+        if (running && update) p_slot = ps;
+      }
+      // the rows the TARGET is formed from.  Q-learning projects the variants of obs AGAIN inside criticize
+      // (advantage.cpp:85-86), i.e. after p's claim, which may have moved one of them off the slot the policy saw.
+      if (SAFE && P.agent != GRLX_AGENT_SARSA)
+      {
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
         {
-          table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
-                        [&](uint32_t mp) {
-                          if (p_pos == mp) p_sh = true;
-#pragma unroll
-                          for (int e = 0; e < kMaxTrace; ++e) tsh |= (tpos[e] == mp) ? (1u << e) : 0u;
-                        });
-          // the target's value of the same slots.  A slot shared between tilings is materialised by one lane at a time
-          // (same value either way; the serialisation only keeps the first store from racing a second lane's read).
-#pragma unroll
-          for (int a = 0; a < NA; ++a)
-          {
-            if (!sh[a]) tw[a] = tval_get(P, RS, tv, pos[a], slot[a], K);
-            const uint32_t pa = pos[a], sa = slot[a];
-            double got = 0;
-            if (rarely(__any(sh[a]))) serial_lanes(sh[a], [&]() { got = tval_get(P, RS, tv, pa, sa, K); });
-            if (sh[a]) tw[a] = got;
-          }
+          const bool act = running && update && has_next;
+          uint32_t s2 = 0, p2 = kInvalidPos;
+          double w2 = 0;
+          bool sh2 = false;
+          probe(act, hfull[a], false, s2, p2, w2, sh2, share_event);
+          tw[a] = target_value(act, p2, s2, sh2, w2);
         }
+      }
+      else
+      {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) tw[a] = target_value(running && has_next, pos[a], slot[a], sh[a], w[a]);
+      }
+      if (running)
+      {
         double wp = 0;
         if (update) wp = value_load(tab, p_pos);
 #pragma unroll
@@ -241,7 +337,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
       wave_sync();
       if (running)
       {
-        const int row = (j < NROWS) ? j : 0;
+        const int row = (j < NROWS - 1) ? j : 0;
         double sum = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) sum += SHW(row, k, g);
@@ -278,26 +374,60 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
               a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
           }
         }
-        if (update)
-        { // the TARGET comes from the target network (sarsa.cpp:107 / advantage.cpp:88)
-          double target = reward;
-          if (has_next)
-          {
-            if (P.agent == GRLX_AGENT_SARSA)
-              target += P.gamma * pick<double, NA>(qt, a_next);
-            else
-            {
-              double v = -__builtin_inf();
-#pragma unroll
-              for (int kk = 0; kk < NA; ++kk) v = fmax(v, qt[kk]);
-              target += P.gamma * v;
-            }
-          }
-          delta = target - qsa;
-          dW = P.alpha * (target - qsa);
-          dT = P.alpha * delta;
-        }
       }
+      // SARSA under safe = 1: the target reads project(obs, action), a SINGLE projection -- it claims, and a claim made a
+      // moment ago (p's) may have moved it off the slot the policy's batch projection saw
+      double q_claimed = 0;
+      if (SAFE && P.agent == GRLX_AGENT_SARSA)
+      {
+        const bool act = running && update && has_next;
+        uint32_t ns = 0, npos = kInvalidPos;
+        double nw = 0;
+        bool nsh = false;
+        probe(act, pick<uint32_t, NA>(hfull, a_next), true, ns, npos, nw, nsh, share_event);
+        const double ntw = target_value(act, npos, ns, nsh, nw);
+        if (act) SHW(NROWS - 1, j, g) = ntw;
+        wave_sync();
+        if (act)
+        {
+          double sum = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sum += SHW(NROWS - 1, k, g);
+          q_claimed = clampd(sum / 16, out_min, out_max);
+        }
+        wave_sync();
+      }
+      if (running && update)
+      { // the TARGET comes from the target network when there is one (sarsa.cpp:107 / advantage.cpp:88)
+        double target = reward;
+        if (has_next)
+        {
+          if (P.agent == GRLX_AGENT_SARSA)
+            target += P.gamma * (SAFE ? q_claimed : pick<double, NA>(qt, a_next));
+          else
+          {
+            double v = -__builtin_inf();
+#pragma unroll
+            for (int kk = 0; kk < NA; ++kk) v = fmax(v, qt[kk]);
+            target += P.gamma * v;
+          }
+        }
+        delta = target - qsa;
+        dW = P.alpha * (target - qsa);
+        dT = P.alpha * delta;
+      }
+      // Q-learning's critique reads project(prev_obs, action) BEFORE the write (advantage.cpp:95-97); SARSA's after the trace
+      // (sarsa.cpp:120-121): a single projection -- it claims its slots; its value is not used by agent/td
+      auto critique_claim = [&]() {
+        if (!SAFE) return;
+        const bool act = running && update && has_next;
+        uint32_t cs = 0, cpos = kInvalidPos;
+        double cw = 0;
+        bool csh = false;
+        const uint32_t hc = murmur_final(murmur_absorb(hpm_prev ^ pick<uint32_t, NA>(key_act, a_next), key_j));
+        probe(act, hc, true, cs, cpos, cw, csh, share_event);
+      };
+      if (P.agent != GRLX_AGENT_SARSA) critique_claim();
 
       // -------- the update calls, one after the other, each followed by checkSynchronize()
       if (__any(update))
@@ -361,6 +491,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
           wave_sync();
         }
       }
+      if (P.agent == GRLX_AGENT_SARSA) critique_claim();
 
       if (running)
       {
@@ -404,6 +535,8 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
           p_pos = pick<uint32_t, NA>(pos, a_next);
           p_slot = pick<uint32_t, NA>(slot, a_next);
           p_sh = pick<bool, NA>(sh, a_next);
+          hp = pick<uint32_t, NA>(hfull, a_next);          // SAFE: p is projected again, with a claim, when it is criticized
+          hpm_prev = hpm;
         }
         if (!first && terminal) running = false;
         first = false;
@@ -458,13 +591,20 @@ hipError_t launch_rollout_tgt(const DevParams &P, int n_trials, hipStream_t stre
 {
   if (variant) *variant = GRLX_KERNEL_IN_PLACE;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
-  if (P.env == GRLX_ENV_PENDULUM && P.A == 3)
-    hipLaunchKernelGGL((rollout_tgt_kernel<GRLX_ENV_PENDULUM, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
-  else if (P.env == GRLX_ENV_ACROBOT && P.A == 3)
-    hipLaunchKernelGGL((rollout_tgt_kernel<GRLX_ENV_ACROBOT, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
-  else
-    return hipErrorInvalidValue;
-  return hipGetLastError();
+  const bool target = P.target_interval > 0, safe = P.tile_safe != 0;
+#define GRLX_LAUNCH_PLAIN(ENVID, TG, SF)                                                                              \
+  if (P.env == ENVID && P.A == 3 && target == TG && safe == SF)                                                     \
+  {                                                                                                                 \
+    hipLaunchKernelGGL((rollout_tgt_kernel<ENVID, 3, TG, SF>), dim3(waves), dim3(64), 0, stream, P, n_trials);      \
+    return hipGetLastError();                                                                                       \
+  }
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_PENDULUM, true, false)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_PENDULUM, false, true)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_PENDULUM, true, true)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_ACROBOT, true, false)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_ACROBOT, false, true)
+#undef GRLX_LAUNCH_PLAIN
+  return hipErrorInvalidValue;
 }
 
 // current target-network value of reference slots (no insertion)

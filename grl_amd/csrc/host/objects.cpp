@@ -357,7 +357,7 @@ struct TileCodingProjector : Projector {
       double w = wrapping[ii] * (tilings / resolution[ii]);
       if (std::fabs(w - std::round(w)) > 0.001) throw bad_param("projector/tile_coding:wrapping");
     }
-    if (safe != 0) throw Exception(path() + ": safe >= 1 (collision claim table) is outside the accelerated path");
+    if (safe != 0 && safe != 1) throw Exception(path() + ": safe >= 1: only safe = 1 (claim on write) is built; safe = 2 is outside the accelerated path");
   }
 };
 GRLX_REGISTER(TileCodingProjector)
@@ -844,6 +844,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
   {
     memset(t, 0, sizeof(*t));
     t->tilings = p->tilings; t->memory = p->memory; t->dims = (int)p->resolution.size();
+    t->safe = p->safe;
     if (p->resolution.size() > GRLX_MAX_DIMS) throw bad_param("projector/tile_coding:resolution");
     for (size_t i = 0; i < p->resolution.size(); ++i) { t->resolution[i] = p->resolution[i]; t->wrapping[i] = p->wrapping[i]; }
   }

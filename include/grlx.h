@@ -65,7 +65,9 @@ typedef struct {
   int32_t tilings;
   int32_t memory;
   int32_t dims;
-  int32_t reserved;
+  int32_t safe;                       /* collision detection (tile_coding.cpp:39): 0 = off; 1 = claim on write (single projections
+                                         claim their slots with their hash sum, tile_coding.h:116-151) -- served by the plain kernel
+                                         for SARSA / Q-learning on the pendulum and the acrobot; 2 (claim always) is not built */
   double  resolution[GRLX_MAX_DIMS];
   double  wrapping[GRLX_MAX_DIMS];
 } grlx_tile_spec;

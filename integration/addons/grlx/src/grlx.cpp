@@ -94,9 +94,10 @@ void GrlxOnlineLearningExperiment::lowerTile(const Configurable *projector, grlx
 { // projector/tile_coding: tilings, memory, safe, resolution, wrapping (tile_coding.cpp:34-42)
   if (!typeIs(projector, "projector/tile_coding"))
     throw bad_param(projector->path() + ": the fused path needs projector/tile_coding");
-  if ((*projector)["safe"].i() != 0)
-    throw bad_param(projector->path() + ":safe (collision detection is not implemented by the fused kernels)");
+  if ((*projector)["safe"].i() > 1)
+    throw bad_param(projector->path() + ":safe (0 and 1 are built; 2 = claim always is not)");
   memset(t, 0, sizeof(*t));
+  t->safe = (*projector)["safe"];
   t->tilings = (*projector)["tilings"];
   t->memory = (*projector)["memory"];
   const LargeVector res = (*projector)["resolution"].v(), wrap = (*projector)["wrapping"].v();
@@ -114,7 +115,6 @@ void GrlxOnlineLearningExperiment::lowerLinear(const Configurable *representatio
   if (!typeIs(representation, "representation/parameterized/linear"))
     throw bad_param(representation->path() + ": the fused path needs representation/parameterized/linear");
   if ((*representation)["outputs"].i() != 1) throw bad_param(representation->path() + ":outputs (must be 1)");
-  if ((*representation)["interval"].i() != 0) throw bad_param(representation->path() + ":interval (target representations are not implemented)");
   l->init_min = first((*representation)["init_min"].v(), 0.);
   l->init_max = first((*representation)["init_max"].v(), 1.);
   l->output_min = first((*representation)["output_min"].v(), -std::numeric_limits<double>::max());
@@ -232,6 +232,8 @@ void GrlxOnlineLearningExperiment::lower(grlx_config *c) const
   c->action_steps = (int)dsteps[0];
   lowerTile(projector, &c->projector);
   lowerLinear(representation, &c->representation);
+  c->target_interval = (*representation)["interval"];               // target network of the Q table (representation.h:173-190)
+  c->target_tau = (*representation)["tau"];
   c->epsilon = first((*sampler)["epsilon"].v(), 0.);
   c->decay_rate = (*sampler)["decay_rate"];
   c->decay_min = (*sampler)["decay_min"];

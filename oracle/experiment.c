@@ -188,21 +188,39 @@ static void lin_update_trace(orc_exp *e, int table, const orc_linear_spec *ls, c
 }
 
 /* ------------------------------------------------------------ projector -- */
-static void project_sa(orc_exp *e, const double *obs, double action, orc_proj *p)
-{ /* tile_coding.h:67-73: _project(extend(base, variant)) */
+static void project_sa_claim(orc_exp *e, const double *obs, double action, int claim, orc_proj *p)
+{ /* tile_coding.h:62-73: project(in) = _project(in, true); project(base, variants) = _project(., safe_ > 1) */
   const orc_tile_spec *ts = &e->spec.projector;
   double in[ORC_MAX_DIMS];
   uint32_t out[ORC_MAX_TILINGS];
   int D = ts->dims - 1;
   for (int i = 0; i < D; ++i) in[i] = obs[i];
   in[D] = action;
-  if (orc_tile_project(ts, in, out) != 0)
+  if ((e->claim ? orc_tile_project_hash(ts, in, out) : orc_tile_project(ts, in, out)) != 0)
   {
     fprintf(stderr, "oracle: invalid tile coding spec\n");
     abort();
   }
   p->n = ts->tilings;
-  for (int j = 0; j < p->n; ++j) p->idx[j] = out[j];
+  for (int j = 0; j < p->n; ++j)
+  {
+    if (!e->claim) { p->idx[j] = out[j]; continue; }
+    /* getFeatureLocation (tile_coding.h:116-151): linear probing from h % memory over slots claimed by OTHER hash sums */
+    const uint32_t h = out[j], mem = (uint32_t)ts->memory;
+    uint32_t ii = h % mem;
+    while (e->claim[ii] != (int32_t)h && e->claim[ii] != -1)
+      if (++ii >= mem) ii = 0;
+    if (claim) e->claim[ii] = (int32_t)h;
+    p->idx[j] = ii;
+  }
+}
+static void project_sa(orc_exp *e, const double *obs, double action, orc_proj *p)
+{ /* a SINGLE projection: claims under safe >= 1 (tile_coding.h:62-66) */
+  project_sa_claim(e, obs, action, 1, p);
+}
+static void project_sa_batch(orc_exp *e, const double *obs, double action, orc_proj *p)
+{ /* one variant of project(base, variants): claims only under safe = 2 (tile_coding.h:67-73) */
+  project_sa_claim(e, obs, action, e->spec.safe > 1, p);
 }
 
 static void project_obs(const orc_tile_spec *ts, const double *obs, orc_proj *p)
@@ -271,7 +289,7 @@ static void q_values(orc_exp *e, const double *obs, double *q)
   orc_proj p;
   for (int a = 0; a < e->A; ++a)
   {
-    project_sa(e, obs, e->actions[a], &p);
+    project_sa_batch(e, obs, e->actions[a], &p);                  /* projector_->project(in, variants, &actions) */
     q[a] = lin_read(e, 0, &e->spec.representation, &p);
   }
 }
@@ -296,6 +314,11 @@ static double sarsa_update(orc_exp *e, const double *prev_obs, double prev_actio
     double ee = orc_m_powtau(s, s->gamma * s->lambda, tau);
     lin_update_trace(e, 0, &s->representation, &e->trace, s->alpha * delta, ee);
     trace_add(&e->trace, s->trace, &p, ee);
+  }
+  if (has_action && e->claim)
+  { /* sarsa.cpp:120-121: the critique reads project(prev_obs, action) -- a single projection, which CLAIMS its slots */
+    orc_proj pc;
+    project_sa(e, prev_obs, action, &pc);
   }
   *pout = p;
   return delta;
@@ -343,7 +366,7 @@ static double expected_sarsa_update(orc_exp *e, const double *prev_obs, double p
 }
 
 static double q_update(orc_exp *e, const double *prev_obs, double prev_action, double tau,
-                       double reward, const double *obs, int has_action, orc_proj *pout)
+                       double reward, const double *obs, int has_action, double action, orc_proj *pout)
 { /* advantage.cpp:71-110 (QPredictor::criticize).  parity unpinned by reference tests. */
   const orc_spec *s = &e->spec;
   orc_proj p, pa;
@@ -354,12 +377,17 @@ static double q_update(orc_exp *e, const double *prev_obs, double prev_action, d
     double v = -INFINITY;
     for (int kk = 0; kk < e->A; ++kk)
     {
-      project_sa(e, obs, e->actions[kk], &pa);
+      project_sa_batch(e, obs, e->actions[kk], &pa);                                            /* advantage.cpp:85-86 */
       v = fmax(v, lin_read_target(e, &s->representation, &pa));                                /* advantage.cpp:88 */
     }
     target += orc_m_powtau(s, s->gamma, tau) * v;
   }
   double delta = target - lin_read(e, 0, &s->representation, &p);
+  if (has_action && e->claim)
+  { /* advantage.cpp:95-97: the critique reads project(prev_obs, action) -- a single projection, which CLAIMS its slots */
+    orc_proj pc;
+    project_sa(e, prev_obs, action, &pc);
+  }
   lin_write(e, 0, &s->representation, &p, target, s->alpha);
   if (s->trace != ORC_TRACE_NONE)
   {
@@ -617,6 +645,13 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
     e->w[1] = table_alloc_init(e, &spec->actor_projector, &spec->actor_representation);
     if (!e->w[1]) { free(e); return NULL; }
   }
+  if (spec->safe != 0)
+  { /* TileCodingProjector::configure (tile_coding.cpp:50-55): indices_ = -1 everywhere */
+    if (spec->safe != 1 || (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q)) { free(e); return NULL; }
+    e->claim = (int32_t *)malloc((size_t)spec->projector.memory * sizeof(int32_t));
+    if (!e->claim) { free(e); return NULL; }
+    memset(e->claim, 0xFF, (size_t)spec->projector.memory * sizeof(int32_t));
+  }
   if (spec->target_interval > 0)
   { /* ParameterizedRepresentation::configure (representation.h:186-190) reinstantiates the representation as its
      * target BEFORE the object's own configure() continues: the target's reset() draws its memory*outputs uniforms
@@ -654,6 +689,7 @@ void orc_destroy(orc_exp *e)
   free(e->w[0]);
   free(e->w[1]);
   free(e->wt);
+  free(e->claim);
   free(e);
 }
 
@@ -750,7 +786,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
           if (s->agent == ORC_AGENT_SARSA)
             delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
           else if (s->agent == ORC_AGENT_Q)
-            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
+            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
           else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
             delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
           else if (s->agent == ORC_AGENT_ADVANTAGE)
@@ -768,7 +804,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
           if (s->agent == ORC_AGENT_SARSA)
             delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
           else if (s->agent == ORC_AGENT_Q)
-            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
+            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
           else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
             delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
           else if (s->agent == ORC_AGENT_ADVANTAGE)

@@ -137,6 +137,10 @@ typedef struct {
    * write, one per trace entry: linear.cpp:267), 0 = no target network; `tau` is the synchronisation strength */
   int    target_interval;
   double target_tau;
+  /* projector/tile_coding:safe (tile_coding.cpp:39, tile_coding.h:116-151): 0 = off, 1 = a slot is CLAIMED by the hash sum
+   * of the first projection that is written through it (single projections claim, the policy's batch projections do
+   * not); a later projection with another hash sum that lands on a claimed slot moves on to the next free one */
+  int    safe;
 } orc_spec;
 
 /* fill with the values of the reference's tests/pendulum-sarsa-tc.yaml */
@@ -148,6 +152,7 @@ void orc_spec_cart_pole_balancing_pid(orc_spec *s);
 /* a7: TileCodingProjector::_project. in[dims] -> out[tilings]; returns 0, or
  * -1 when the spec is invalid (wrapping*scaling not an integer). */
 int orc_tile_project(const orc_tile_spec *t, const double *in, uint32_t *out);
+int orc_tile_project_hash(const orc_tile_spec *t, const double *in, uint32_t *out);   /* full hash sums (safe >= 1) */
 
 /* a3/a4/a5: one ModeledEnvironment::step on an explicit state.
  * state[S] is updated in place; obs[D], *reward, *terminal are outputs.

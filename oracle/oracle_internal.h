@@ -29,6 +29,7 @@ struct orc_exp {
   orc_rand48 S1, S2;                    /* learning / test sampler private Rand       */
   double    *w[2];                      /* weight tables: 0 = Q or critic, 1 = actor  */
   double    *wt;                        /* target network of table 0 (NULL without one) */
+  int32_t   *claim;                     /* TileCodingProjector::indices_ (safe >= 1), -1 = free */
   int64_t    sync_count;                /* ParameterizedRepresentation::count_          */
   int64_t    syncs;                     /* synchronisations so far (diagnostics)        */
   int        A;                         /* number of discrete actions                 */

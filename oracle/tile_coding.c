@@ -33,7 +33,14 @@ static uint32_t murmur2_ints(const int *v, uint32_t n, uint32_t seed)
   return h;
 }
 
-int orc_tile_project(const orc_tile_spec *t, const double *in, uint32_t *out)
+static int tile_project_impl(const orc_tile_spec *t, const double *in, uint32_t *out, int full_hash);
+
+int orc_tile_project(const orc_tile_spec *t, const double *in, uint32_t *out) { return tile_project_impl(t, in, out, 0); }
+/* the same with the full 32-bit hash sums (createHashSum, tile_coding.h:78-113) instead of `% memory`: what the collision
+ * table of safe >= 1 keys its claims with (getFeatureLocation, tile_coding.h:116-151) */
+int orc_tile_project_hash(const orc_tile_spec *t, const double *in, uint32_t *out) { return tile_project_impl(t, in, out, 1); }
+
+static int tile_project_impl(const orc_tile_spec *t, const double *in, uint32_t *out, int full_hash)
 {
   int q[ORC_MAX_DIMS], base[ORC_MAX_DIMS], wrap[ORC_MAX_DIMS], c[ORC_MAX_DIMS + 1];
   double scaling[ORC_MAX_DIMS];
@@ -69,7 +76,8 @@ int orc_tile_project(const orc_tile_spec *t, const double *in, uint32_t *out)
     }
     c[i] = j;
     /* tile_coding.h:118: unsigned % int -> unsigned arithmetic */
-    out[j] = murmur2_ints(c, (uint32_t)(D + 1), 449u) % (uint32_t)t->memory;
+    out[j] = murmur2_ints(c, (uint32_t)(D + 1), 449u);
+    if (!full_hash) out[j] %= (uint32_t)t->memory;
   }
   return 0;
 }
