@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
     int    action_index = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0;
     bool   p_sh = false;
+    double wp_seen = 0;                   // weight of p's slot as looked up (and forwarded from the trace) one pass ago
     uint32_t pos_prev[NA];                // ADV: positions of project(s, a_k) for every action
 #pragma unroll
     for (int a = 0; a < NA; ++a) pos_prev[a] = 0u;
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
         // full RK4 ago, so this wait is free; it makes the ordering explicit)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         DIAG_STAMP(6)
-        if (update) wp = value_load(tab, p_pos);                           // weights of project(s, a) as stored
+        // weights of project(s, a): with the deferred ordering the value this lane saw when it looked the slot up one pass
+        // ago is still the table's (anything newer lives in the trace, is the held eviction, or belongs to a slot shared
+        // between tilings -- all reconciled below); the in-place ordering may have evicted it meanwhile and loads it
+        if (update) wp = DEFER ? wp_seen : value_load(tab, p_pos);
         if (ADV && update)
         {
 #pragma unroll
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
           p_pos = pick<uint32_t, NA>(pos, a_next);
           p_slot = pick<uint32_t, NA>(slot, a_next);
           p_sh = pick<bool, NA>(sh, a_next);
+          wp_seen = pick<double, NA>(w, a_next);
           if (ADV)
           {
 #pragma unroll
