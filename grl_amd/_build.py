@@ -16,14 +16,18 @@ SOURCES = ["grlx_kernels.hip", "grlx_fqi.hip", "grlx_api.cpp"]
 HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", "grlx_policy.h", "grlx_update.h",
            "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h",
            os.path.join("..", "..", "include", "grlx.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
-
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# The device code is not taken from hipcc as is: it is compiled to assembly, passed through _exec_prologue.fix (a
+# work-around for a register-allocation bug of this compiler, see that file and DESIGN.md section 4.1f), assembled,
+# linked and bundled with the same tools and options the hipcc driver uses (`hipcc -###`), and handed to the host
+# compilation of the same source with -fcuda-include-gpubinary.
+PIPELINE = "device-asm+exec-prologue-fix/1"
 
 FLAGS_FILE = LIB + ".flags"      # the flags the library was built with: a change of flags makes it stale
 
 
 def _flags() -> str:
-    return " ".join(FLAGS + os.environ.get("GRLX_EXTRA_FLAGS", "").split())
+    return " ".join(FLAGS + os.environ.get("GRLX_EXTRA_FLAGS", "").split() + [PIPELINE])
 
 
 def _stale() -> bool:
@@ -36,27 +40,75 @@ def _stale() -> bool:
     except OSError:
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "_exec_prologue.py")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd, verbose=False):
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("build step failed: " + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+    return res
+
+
+def _llvm_tool(name: str) -> str:
+    for d in ("/opt/rocm/lib/llvm/bin", "/opt/rocm/llvm/bin"):
+        if os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    raise RuntimeError(name + " not found under /opt/rocm: cannot build the HIP extension")
+
+
+def _build_hip_object(hipcc, src, tmp, flags, verbose, report):
+    """One .hip source -> host object carrying the filtered device code."""
+    from . import _exec_prologue
+    stem = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0])
+    _run([hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", stem + ".s"], verbose)
+    with open(stem + ".s") as f:
+        fixed, n_fixed, n_skipped = _exec_prologue.fix(f.read().split("\n"))
+    with open(stem + ".fixed.s", "w") as f:
+        f.write("\n".join(fixed))
+    report[os.path.basename(src)] = (n_fixed, n_skipped)
+    if n_skipped:
+        raise RuntimeError(f"{src}: {n_skipped} block head(s) with vector writes before the exec restore could not be rewritten")
+    _run([_llvm_tool("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", stem + ".fixed.s", "-o", stem + ".dev.o"], verbose)
+    _run([_llvm_tool("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", stem + ".out", stem + ".dev.o"], verbose)
+    _run([_llvm_tool("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + stem + ".out",
+          "-output=" + stem + ".hipfb"], verbose)
+    _run([hipcc] + flags + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb", "-o", stem + ".host.o"], verbose)
+    return stem + ".host.o"
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libgrlx.so if missing or older than its sources; return its path."""
     if not force and not _stale():
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the HIP extension")
     os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get("GRLX_EXTRA_FLAGS", "").split()       # experiments only; the default build uses FLAGS
-    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    flags = FLAGS + os.environ.get("GRLX_EXTRA_FLAGS", "").split()       # extra flags: experiments only
+    report = {}
+    with tempfile.TemporaryDirectory(prefix="grlx_build_") as tmp:
+        def one(name):
+            src = os.path.join(CSRC, name)
+            if name.endswith(".hip"):
+                return _build_hip_object(hipcc, src, tmp, flags, verbose, report)
+            obj = os.path.join(tmp, os.path.splitext(name)[0] + ".o")
+            _run([hipcc] + flags + ["-c", src, "-o", obj], verbose)
+            return obj
+        with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+            objs = list(pool.map(one, SOURCES))
+        _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs, verbose)
     with open(FLAGS_FILE, "w") as f:
         f.write(_flags() + "\n")
+    with open(LIB + ".asmfix", "w") as f:       # how many block heads the assembly filter rewrote, per source
+        for k in sorted(report):
+            f.write(f"{k}: {report[k][0]} rewritten, {report[k][1]} left alone\n")
     return LIB
 
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -303,6 +304,8 @@ struct grlx_ctx {
   int          n_tables = 1;
   int64_t      trials_run = 0;
   int          last_kernel = GRLX_KERNEL_NONE;
+  bool         poison = false;            // GRLX_POISON_REGISTERS=<pattern>: diagnostic, see launch_poison_registers
+  uint32_t     poison_pattern = 0;
 };
 
 // small RAII helper for the copy-in / copy-out entry points
@@ -452,8 +455,9 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   if (cfg->tap_deferred && cfg->tap_replica >= 0 && cfg->tap_capacity > 0)
   {
     const bool td = (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA);
-    if (!td || cfg->trace == GRLX_TRACE_ACCUMULATING || (cfg->env != GRLX_ENV_PENDULUM && cfg->env != GRLX_ENV_ACROBOT) || cfg->action_steps != 3)
-      return fail(GRLX_ERR_INVALID, "tap_deferred is built for SARSA / Q / Expected SARSA on the pendulum and the acrobot with 3 actions");
+    const bool built = (cfg->env == GRLX_ENV_PENDULUM && (cfg->action_steps == 3 || cfg->action_steps == 5)) || (cfg->env == GRLX_ENV_ACROBOT && cfg->action_steps == 3);
+    if (!td || cfg->trace == GRLX_TRACE_ACCUMULATING || !built)
+      return fail(GRLX_ERR_INVALID, "tap_deferred is built for SARSA / Q / Expected SARSA on the pendulum (3 or 5 actions) and the acrobot (3 actions)");
   }
   DevParams P;
   int rc = make_params(*cfg, &P);
@@ -464,6 +468,11 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
 
   grlx_ctx *ctx = new grlx_ctx();
   ctx->cfg = *cfg;
+  if (const char *pz = getenv("GRLX_POISON_REGISTERS"))
+  { // diagnostic (tests): every rollout launch is preceded by a kernel that fills the register files with this pattern
+    ctx->poison = pz[0] != 0;
+    ctx->poison_pattern = (uint32_t)strtoul(pz, nullptr, 0);
+  }
   env_dims(cfg->env, &ctx->S, &ctx->D);
   const int N = cfg->n_replicas;
   uint32_t logC = cfg->table_log2_capacity ? (uint32_t)cfg->table_log2_capacity : 17u;
@@ -648,6 +657,7 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
   for (int done = 0; done < n_trials; done += kTrialsPerLaunch)
   {
     const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
+    if (ctx->poison) HIP_TRY(launch_poison_registers(ctx->poison_pattern, (hipStream_t)stream));
     if (ctx->cfg.agent == GRLX_AGENT_AC)
       HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.agent == GRLX_AGENT_QV)

@@ -123,6 +123,10 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
 hipError_t launch_rollout_qv(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_tgt(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+// diagnostic: overwrite the whole vector register file (512 registers per lane) and the user SGPRs of every SIMD with
+// `pattern`, so that a kernel launched next on `stream` that reads a register it never wrote computes with that
+// pattern instead of with whatever the previous wave left (GRLX_POISON_REGISTERS)
+hipError_t launch_poison_registers(uint32_t pattern, hipStream_t stream);
 hipError_t launch_get_target_weights(const DevParams &P, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,

@@ -50,6 +50,46 @@ namespace grlx {
 
 namespace grlx {
 
+// ------------------------------------------------------ register poisoning ---
+// Every vector register (v0..v255, a0..a255: one wave owns a SIMD's whole file) and the SGPRs a kernel may be given
+// are set to `pattern`.  The clobber lists make the compiler declare all of them for this kernel; the writes
+// themselves are assembler repeat blocks.
+#define GRLX_D10(p) p "0", p "1", p "2", p "3", p "4", p "5", p "6", p "7", p "8", p "9"
+#define GRLX_D100(p) GRLX_D10(p "0"), GRLX_D10(p "1"), GRLX_D10(p "2"), GRLX_D10(p "3"), GRLX_D10(p "4"), GRLX_D10(p "5"), GRLX_D10(p "6"), GRLX_D10(p "7"), GRLX_D10(p "8"), GRLX_D10(p "9")
+#define GRLX_ALL256(p) GRLX_D10(p), GRLX_D10(p "1"), GRLX_D10(p "2"), GRLX_D10(p "3"), GRLX_D10(p "4"), GRLX_D10(p "5"), GRLX_D10(p "6"), GRLX_D10(p "7"), GRLX_D10(p "8"), GRLX_D10(p "9"), \
+  GRLX_D100(p "1"), GRLX_D10(p "20"), GRLX_D10(p "21"), GRLX_D10(p "22"), GRLX_D10(p "23"), GRLX_D10(p "24"), p "250", p "251", p "252", p "253", p "254", p "255"
+__global__ __launch_bounds__(64) void poison_registers_kernel(uint32_t pattern)
+{
+  asm volatile(
+      "v_mov_b32 v0, %0\n"
+      ".set grlx_i, 0\n"
+      ".rept 256\n"
+      "  v_accvgpr_write_b32 a[grlx_i], v0\n"
+      "  .set grlx_i, grlx_i + 1\n"
+      ".endr\n"
+      ".set grlx_i, 1\n"
+      ".rept 255\n"
+      "  v_mov_b32 v[grlx_i], %0\n"
+      "  .set grlx_i, grlx_i + 1\n"
+      ".endr\n"
+      ".set grlx_i, 20\n"
+      ".rept 80\n"
+      "  s_mov_b32 s[grlx_i], %0\n"
+      "  .set grlx_i, grlx_i + 1\n"
+      ".endr\n"
+      :: "s"(pattern) : "memory", GRLX_ALL256("v"), GRLX_ALL256("a"), GRLX_D10("s2"), GRLX_D10("s3"), GRLX_D10("s4"), GRLX_D10("s5"),
+         GRLX_D10("s6"), GRLX_D10("s7"), GRLX_D10("s8"), GRLX_D10("s9"));
+}
+#undef GRLX_ALL256
+#undef GRLX_D100
+#undef GRLX_D10
+
+hipError_t launch_poison_registers(uint32_t pattern, hipStream_t stream)
+{ // one wave fills a SIMD; several rounds over the chip's SIMDs so that none is missed
+  hipLaunchKernelGGL(poison_registers_kernel, dim3(8192), dim3(64), 0, stream, pattern);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------- launchers ---
 
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
@@ -124,6 +164,7 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
       return hipGetLastError();                                                                                     \
     }
     GRLX_LAUNCH_TAPDEF(GRLX_ENV_PENDULUM, 3)
+    GRLX_LAUNCH_TAPDEF(GRLX_ENV_PENDULUM, 5)
     GRLX_LAUNCH_TAPDEF(GRLX_ENV_ACROBOT, 3)
 #undef GRLX_LAUNCH_TAPDEF
     return hipErrorInvalidValue;

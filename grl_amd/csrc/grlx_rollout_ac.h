@@ -177,6 +177,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     double time = 0, action = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0, ap_pos = kInvalidPos, ap_slot = 0;
     bool p_sh = false, ap_sh = false;
+    double wap_seen = 0, wpc_seen = 0;
     bool first = true;
 
     for (;;)
@@ -206,9 +207,10 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (update)
-        {
-          wap = value_load(tabA, ap_pos);                // actor weights of project(prev_obs), current
-          wpc = value_load(tabC, p_pos);                 // critic weights of project(prev_obs), as stored
+        { // weights of project(prev_obs): with the deferred ordering as looked up one pass ago (the actor's: or as written by
+          // the last actor update to the same slot; shared slots are loaded); the in-place ordering loads them
+          wap = (DEFER && !ap_sh) ? wap_seen : value_load(tabA, ap_pos);
+          wpc = DEFER ? wpc_seen : value_load(tabC, p_pos);
         }
         // both tables' home buckets in flight together: one memory round trip for the two lookups
         if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
             double nv = wap;
             for (uint32_t c = 0; c < cpa; ++c) nv = a_limit ? clampd(nv + dA, a_min, a_max) : nv + dA;
             value_store(tabA, ap_pos, nv);
+            if (has_next && posA[0] == ap_pos) wA[0] = nv;          // the next step updates the same slot: it continues from this value
           }
         }
 
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         {
           action = a_next;
           ap_pos = posA[0]; ap_slot = slotA[0]; ap_sh = shA[0];
-          if (need_critic) { p_pos = posC[0]; p_slot = slotC[0]; p_sh = shC[0]; }
+          wap_seen = wA[0];
+          if (need_critic) { p_pos = posC[0]; p_slot = slotC[0]; p_sh = shC[0]; wpc_seen = wC[0]; }
         }
         if (!first && terminal) running = false;
         first = false;

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     c.status = RS.status;
     c.inserted = 0;
     c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
+    c.wp_seen = 0; c.wap_seen = 0;
     wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
     WideRep s;
     s.G = RS.G; s.TL = RS.TL;
@@ -186,9 +187,10 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (update)
-        {
-          wap = value_load(tabA, c.ap_pos);
-          wpc = value_load(tabC, c.p_pos);
+        { // as looked up one pass ago (the actor's: or as written by the last actor update to the same slot); slots shared
+          // between tilings are loaded (another lane may have written them)
+          wap = c.ap_sh ? value_load(tabA, c.ap_pos) : c.wap_seen;
+          wpc = c.wp_seen;
         }
         if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
         if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
             double nv = wap;
             for (uint32_t cc = 0; cc < cpa; ++cc) nv = a_limit ? clampd(nv + dA, a_min, a_max) : nv + dA;
             value_store(tabA, c.ap_pos, nv);
+            if (has_next && posA[0] == c.ap_pos) wA[0] = nv;       // the next step updates the same slot: it continues from this value
           }
         }
 
@@ -335,7 +338,8 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         {
           s.action = a_next;
           c.ap_pos = posA[0]; c.ap_sh = shA[0];
-          if (need_critic) { c.p_pos = posC[0]; c.p_sh = shC[0]; }
+          c.wap_seen = wA[0];
+          if (need_critic) { c.p_pos = posC[0]; c.p_sh = shC[0]; c.wp_seen = wC[0]; }
         }
         if (!s.first && terminal) { s.running = false; s.ending = true; }
         s.first = false;

@@ -15,9 +15,9 @@
 // wave idles only at the very end of a launch -- episodes of the acrobot and the walker end at different steps.
 //
 // Between its turns a sub-batch's lane state (register trace, pending update, position of p) is PARKED in LDS
-// (180 B per lane, lane-contiguous 16-byte quads: conflict-free ds_read/write_b128), its per-replica scalars (RNG
+// (196 B per lane, lane-contiguous 16-byte quads: conflict-free ds_read/write_b128), its per-replica scalars (RNG
 // streams, counters, action) in a small structure-of-arrays; observation / reward / terminal / action travel between
-// the two lane roles through LDS as well.  B = 2: 23 KB of parked state per wave, four waves per CU fit.
+// the two lane roles through LDS as well.  B = 2: 25 KB of parked state per wave, four waves per CU fit.
 #pragma once
 
 namespace grlx {
@@ -31,8 +31,10 @@ struct WideLane {                 // table-role state of one lane for one sub-ba
   // actor-critic only (AC = true): position of the actor's projection of s, its shared flag, slots created in the actor's table
   uint32_t  ap_pos, inserted2;
   bool      ap_sh;
+  // the weights of p's slot(s) as looked up one pass ago (instead of loading them again): Q / critic table, actor table
+  double    wp_seen, wap_seen;
 };
-constexpr int kWideQuads = 11;    // 16-byte quads per parked lane
+constexpr int kWideQuads = 12;    // 16-byte quads per parked lane
 
 __device__ __forceinline__ uint4 pack2d(double a, double b)
 {
@@ -66,6 +68,7 @@ __device__ __forceinline__ void wide_park(const WideLane &c, uint4 *sh_ctx, uint
     sh_ctx[10 * 64 + lane] = make_uint4((uint32_t)uw, (uint32_t)(uw >> 32),
                                         (c.pd ? 1u : 0u) | (c.pd_sh ? 2u : 0u) | (c.p_sh ? 4u : 0u) | ((AC && c.ap_sh) ? 8u : 0u), c.status);
   }
+  sh_ctx[11 * 64 + lane] = pack2d(c.wp_seen, c.wap_seen);
   sh_ins[lane] = c.inserted;
   if (AC)
   {
@@ -99,6 +102,7 @@ __device__ __forceinline__ void wide_unpark(WideLane &c, const uint4 *sh_ctx, co
   c.pd_sh = (q.z & 2u) != 0u;
   c.p_sh = (q.z & 4u) != 0u;
   c.status = q.w;
+  unpack2d(sh_ctx[11 * 64 + lane], c.wp_seen, c.wap_seen);
   c.inserted = sh_ins[lane];
   c.ap_sh = AC && (q.z & 8u) != 0u;
   c.inserted2 = AC ? sh_ins[64 + lane] : 0u;
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     c.status = RS.status;
     c.inserted = 0;
     c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
+    c.wp_seen = 0; c.wap_seen = 0;
     wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
     WideRep s;
     s.G = RS.G; s.TL = RS.TL; s.S1 = RS.S1;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          if (update) wp = value_load(tab, c.p_pos);
+          if (update) wp = c.wp_seen;          // as looked up one pass ago; reconciled with the trace / eviction / shared slots below
           if (has_next) table_issue<NA>(tab, slot, lk, br);
         }
 
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             s.action = pick<double, NA>(acts, a_next);                         // discretizer_->at(index)
             c.p_pos = pick<uint32_t, NA>(pos, a_next);
             c.p_sh = pick<bool, NA>(sh, a_next);
+            c.wp_seen = pick<double, NA>(w, a_next);
           }
           if (!s.first && terminal) { s.running = false; s.ending = true; }
           s.first = false;

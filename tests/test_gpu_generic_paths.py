@@ -362,3 +362,19 @@ def test_repeated_policy_loads_do_not_accumulate_device_memory(grlx):
     r.run(3); r.sync()
     assert_bit_equal(r.weights(0, np.array([5, 77, 4242], np.uint32)) >= 0, [True] * 3)
     r.close()
+
+
+@pytest.mark.parametrize("pattern", ["0xffffffff", "0x7ff80000"])
+def test_results_do_not_depend_on_stale_register_content(grlx, monkeypatch, pattern):
+    """ROCm 7.2's register allocator placed a live-range-split copy of the tiling key in
+    front of a join block's exec restore in the 5-action kernel; the lanes masked off there got whatever the previous
+    wave had left in a scratch register, and returns differed from the oracle's from the first update on.  With
+    GRLX_POISON_REGISTERS every rollout launch is preceded by a kernel that fills all 512 vector registers per lane
+    (and the SGPRs) of every SIMD with the pattern, so a read of a never-written register is no longer a matter of
+    luck.  The build's assembly filter moves such copies behind the restore: the 5-action kernel, the generic
+    3-action one and the headline specialisation must equal the oracle under any pattern."""
+    monkeypatch.setenv("GRLX_POISON_REGISTERS", pattern)
+    over = dict(action_steps=5, test_interval=4, decay_rate=0.97, decay_min=0.2, randomization=1.0)
+    _run_both(grlx, [31, 32, 33], 15, over, agent=1, chunks=[7, 8])
+    _run_both(grlx, [41, 42, 43, 44, 45], 12, dict(test_interval=3), chunks=[12], force_generic=1)
+    _run_both(grlx, [51, 52, 53, 54], 12, {}, chunks=[5, 7])
