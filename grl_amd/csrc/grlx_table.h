@@ -225,7 +225,7 @@ __device__ __forceinline__ void table_lookup(const Table &t, const uint32_t (&sl
 
 // Serialised insert (one lane per 16-lane group at a time), re-reading the bucket: used for
 // the lanes the parallel path could not place (conflicts), and by the fine-grained operators.
-__device__ __forceinline__ void table_insert_serial(const Table &t, bool todo, uint32_t slot, uint32_t owner, double w0,
+__device__ __noinline__ void table_insert_serial(const Table &t, bool todo, uint32_t slot, uint32_t owner, double w0,
                                            Lookup &lk, double &val, uint32_t &status, uint32_t &inserted)
 {
   const int lane = threadIdx.x & 63;
