@@ -86,7 +86,7 @@ int make_tile_params(const grlx_tile_spec &ts, TileParams *tp)
   if (ts.dims < 1 || ts.dims > GRLX_MAX_DIMS) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution (dims %d)", ts.dims);
   if (ts.tilings < 1 || ts.tilings > 32) return fail(GRLX_ERR_INVALID, "projector/tile_coding:tilings (%d)", ts.tilings);
   if (ts.memory < 1 || ts.memory >= (1 << 26)) return fail(GRLX_ERR_INVALID, "projector/tile_coding:memory (1 .. 2^26-1 supported)");
-  if (ts.safe < 0 || ts.safe > 1) return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe (0 and 1 are built; 2 = claim always is not)");
+  if (ts.safe < 0 || ts.safe > 2) return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe must be 0, 1 or 2");
   memset(tp, 0, sizeof(*tp));
   tp->T = ts.tilings;
   tp->D = ts.dims;
@@ -231,14 +231,14 @@ int make_params(const grlx_config &c, DevParams *P)
     P->beta = c.beta;
   }
 
-  if (c.projector.safe == 1)
+  if (c.projector.safe >= 1)
   { // claim table of the tile coding: its own (plain) kernel
     if ((c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q) || (c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) ||
         c.action_steps != 3 || c.trace == GRLX_TRACE_ACCUMULATING)
-      return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe = 1 is built for predictor/critic/sarsa and predictor/critic/q on the pendulum and the "
+      return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe >= 1 is built for predictor/critic/sarsa and predictor/critic/q on the pendulum and the "
                                     "acrobot with 3 actions, replacing or no trace");
-    if (c.env == GRLX_ENV_ACROBOT && c.target_interval > 0) return fail(GRLX_ERR_INVALID, "safe = 1 together with a target network is built for the pendulum");
-    P->tile_safe = 1;
+    if (c.env == GRLX_ENV_ACROBOT && c.target_interval > 0) return fail(GRLX_ERR_INVALID, "safe >= 1 together with a target network is built for the pendulum");
+    P->tile_safe = c.projector.safe;         // 2: the policy's batch projections claim too
   }
   if ((ac || qv) && c.actor_projector.safe != 0) return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe on the second table");
   if (c.target_interval < 0 || !std::isfinite(c.target_tau)) return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:{interval,tau}");

@@ -107,7 +107,7 @@ struct DevParams {
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
   double   kappa;               // predictor/critic/advantage: advantage scaling factor
   double   beta;                // predictor/critic/qv: state-value learning rate
-  int32_t  tile_safe;           // projector/tile_coding:safe = 1: claim table (plain kernel)
+  int32_t  tile_safe;           // projector/tile_coding:safe: 1 = claim table, single projections claim; 2 = batch projections claim too (plain kernel)
   int32_t  target_interval;     // > 0: the Q table has a target network synchronised every so many update() calls
   double   target_tau;          // synchronisation strength (representation.h:284-296)
   double  *tvals;               // [replica][2^logC]: the target network's value per table position (all ones: not materialised)

@@ -290,11 +290,13 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       }
-      // -------- policy: Q(s', .) -- the batch projections of QPolicy::values (no claims under safe = 1)
+      // -------- policy: Q(s', .) -- the batch projections of QPolicy::values: no claims under safe = 1; under safe = 2 each
+      // variant claims like a single projection, one variant after the other (tile_coding.h:67-73)
+      const bool claim_batch = P.tile_safe > 1;
       if (SAFE)
       {
 #pragma unroll
-        for (int a = 0; a < NA; ++a) probe(running && has_next, hfull[a], false, slot[a], pos[a], w[a], sh[a], share_event);
+        for (int a = 0; a < NA; ++a) probe(running && has_next, hfull[a], claim_batch, slot[a], pos[a], w[a], sh[a], share_event);
       }
       else if (running && has_next)
         table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted, share_event);
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64) void rollout_tgt_kernel(DevParams P, int n_tria
           uint32_t s2 = 0, p2 = kInvalidPos;
           double w2 = 0;
           bool sh2 = false;
-          probe(act, hfull[a], false, s2, p2, w2, sh2, share_event);
+          probe(act, hfull[a], claim_batch, s2, p2, w2, sh2, share_event);
           tw[a] = target_value(act, p2, s2, sh2, w2);
         }
       }

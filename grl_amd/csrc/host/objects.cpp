@@ -357,7 +357,7 @@ struct TileCodingProjector : Projector {
       double w = wrapping[ii] * (tilings / resolution[ii]);
       if (std::fabs(w - std::round(w)) > 0.001) throw bad_param("projector/tile_coding:wrapping");
     }
-    if (safe != 0 && safe != 1) throw Exception(path() + ": safe >= 1: only safe = 1 (claim on write) is built; safe = 2 is outside the accelerated path");
+    if (safe < 0 || safe > 2) throw Exception(path() + ": safe must be 0, 1 or 2");
   }
 };
 GRLX_REGISTER(TileCodingProjector)

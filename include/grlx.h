@@ -67,7 +67,8 @@ typedef struct {
   int32_t dims;
   int32_t safe;                       /* collision detection (tile_coding.cpp:39): 0 = off; 1 = claim on write (single projections
                                          claim their slots with their hash sum, tile_coding.h:116-151) -- served by the plain kernel
-                                         for SARSA / Q-learning on the pendulum and the acrobot; 2 (claim always) is not built */
+                                         for SARSA / Q-learning on the pendulum and the acrobot; 2 = claim always: the policy's batch
+                                         projections (tile_coding.h:67-73) claim too, one variant after the other */
   double  resolution[GRLX_MAX_DIMS];
   double  wrapping[GRLX_MAX_DIMS];
 } grlx_tile_spec;

@@ -647,7 +647,7 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
   }
   if (spec->safe != 0)
   { /* TileCodingProjector::configure (tile_coding.cpp:50-55): indices_ = -1 everywhere */
-    if (spec->safe != 1 || (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q)) { free(e); return NULL; }
+    if ((spec->safe != 1 && spec->safe != 2) || (spec->agent != ORC_AGENT_SARSA && spec->agent != ORC_AGENT_Q)) { free(e); return NULL; }
     e->claim = (int32_t *)malloc((size_t)spec->projector.memory * sizeof(int32_t));
     if (!e->claim) { free(e); return NULL; }
     memset(e->claim, 0xFF, (size_t)spec->projector.memory * sizeof(int32_t));

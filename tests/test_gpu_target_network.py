@@ -101,15 +101,20 @@ def test_deployer_target_network(grlx, tmp_path):
 
 
 # ---------------------------------------------------------------- projector/tile_coding: safe = 1 ---
-@pytest.mark.parametrize("env,agent,memory,trace,target", [
-    ("pendulum", 0, 8388608, 1, 0),        # SARSA: p, project(obs, action) and the critique's projection all claim
-    ("pendulum", 1, 8388608, 1, 0),        # Q-learning: p and the critique claim, the max runs over unclaimed batch projections
-    ("pendulum", 0, 32768, 1, 0),          # a memory of the size of the visited set: slots are contested, projections walk on
-    ("pendulum", 1, 32768, 0, 0),
-    ("acrobot", 0, 65536, 1, 0),
-    ("pendulum", 0, 32768, 1, 400),        # claim table AND target network
+@pytest.mark.parametrize("env,agent,memory,trace,target,safe", [
+    ("pendulum", 0, 8388608, 1, 0, 1),     # SARSA: p, project(obs, action) and the critique's projection all claim
+    ("pendulum", 1, 8388608, 1, 0, 1),     # Q-learning: p and the critique claim, the max runs over unclaimed batch projections
+    ("pendulum", 0, 32768, 1, 0, 1),       # a memory of the size of the visited set: slots are contested, projections walk on
+    ("pendulum", 1, 32768, 0, 0, 1),
+    ("acrobot", 0, 65536, 1, 0, 1),
+    ("pendulum", 0, 32768, 1, 400, 1),     # claim table AND target network
+    ("pendulum", 0, 32768, 1, 0, 2),       # safe = 2 (claim always): the policy's batch projections claim too, variant after variant
+    ("pendulum", 1, 32768, 1, 0, 2),       # ... and so do Q-learning's second batch projections inside criticize
+    ("pendulum", 1, 8388608, 0, 0, 2),
+    ("acrobot", 1, 65536, 1, 0, 2),
+    ("pendulum", 1, 32768, 1, 300, 2),
 ])
-def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target):
+def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target, safe):
     """projector/tile_coding with safe = 1 (tile_coding.h:116-151): slots claimed by the hash sum of single projections,
     linear probing past slots claimed by another hash sum, claims of one projection made in tiling order.  Per-step records
     (the slot indices in them are the CLAIMED locations), rows, RNG, weights.  parity unpinned by reference tests."""
@@ -122,8 +127,8 @@ def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target):
         obj.trace = trace
         obj.projector.memory = memory
         obj.target_interval, obj.target_tau = target, 0.3
-    cfg.projector.safe = 1
-    spec.safe = 1
+    cfg.projector.safe = safe
+    spec.safe = safe
     r = grlx.Runner(cfg, seeds)
     r.run(7); r.run(9); r.run(8); r.sync()
     rng = np.random.default_rng(29)
@@ -164,7 +169,7 @@ def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target):
 
 
 def test_safe_and_project_operator(grlx):
-    """grlx_project is stateless: it refuses a spec with safe != 0; safe = 2 (claim always) is not built."""
+    """grlx_project is stateless: it refuses a spec with safe != 0; safe = 3 does not exist."""
     capi = grlx.capi
     spec = grlx.pendulum_sarsa_config(1).projector
     spec.safe = 1
@@ -172,7 +177,7 @@ def test_safe_and_project_operator(grlx):
         grlx.runner.project(spec, [[0.1, 0.2, 0.0]])
     assert ei.value.code == capi.ERR_INVALID
     cfg = grlx.pendulum_sarsa_config(1)
-    cfg.projector.safe = 2
+    cfg.projector.safe = 3
     with pytest.raises(capi.GrlxError) as ei:
         grlx.Runner(cfg, [1])
     assert ei.value.code == capi.ERR_INVALID

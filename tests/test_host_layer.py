@@ -46,7 +46,7 @@ def _variant(tmp_path, old, new):
     ("steps: [ 3 ]", "steps: [ 3, 3 ]", "discretizer/uniform:{min,max,steps}"),                          # uniform.cpp:66-67
     ("init_min: [ 0 ]", "init_min: [ 0, 1, 2 ]", "representation/parameterized/linear:init_min"),       # linear.cpp:62-66
     ("type: dynamics/pendulum", "type: dynamics/flyer2d", "unknown object type"),
-    ("safe: 0", "safe: 2", "safe >= 1"),
+    ("safe: 0", "safe: 3", "safe must be 0, 1 or 2"),
     ("      sampler:\n        type: sampler/greedy", "      sampler:\n        type: sampler/epsilon_greedy", "sampler/greedy for testing"),
     ("      sampler:\n        epsilon: 0.05\n        type: sampler/epsilon_greedy\n", "", "required parameter 'sampler'"),
 ])
