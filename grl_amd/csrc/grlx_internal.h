@@ -113,6 +113,8 @@ struct DevParams {
   double  *tvals;               // [replica][2^logC]: the target network's value per table position (all ones: not materialised)
   int32_t  tap_deferred;        // taps are recorded by the deferred-update (production) ordering instead of the in-place one
   int32_t  replicas_per_wave;   // 4 (one sub-batch) or 8 (two): chosen at create from the replica count and the SIMD count
+  int32_t  wave_limit;          // wide actor-critic kernel: waves launched at most (> 0); further replicas come from `queue`
+  uint32_t *queue;              // next unstarted replica (set by the launcher before every launch)
 };
 
 // ---------------------------------------------------------------------------

@@ -84,6 +84,8 @@ __global__ __launch_bounds__(64) void poison_registers_kernel(uint32_t pattern)
 #undef GRLX_D100
 #undef GRLX_D10
 
+__global__ void set_u32_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
 hipError_t launch_poison_registers(uint32_t pattern, hipStream_t stream)
 { // one wave fills a SIMD; several rounds over the chip's SIMDs so that none is missed
   hipLaunchKernelGGL(poison_registers_kernel, dim3(8192), dim3(64), 0, stream, pattern);
@@ -97,20 +99,28 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
   const bool taps = P.tap_replica >= 0 && P.tap_capacity > 0;          // recorded by the in-place instantiation
   if (variant) *variant = taps ? GRLX_KERNEL_IN_PLACE : GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
-  if (!taps && P.replicas_per_wave == 8)
-  { // two sub-batches per wave share one environment phase (grlx_rollout_ac_wide.h)
-    const int wwaves = (P.n_replicas + 7) / 8;
-    if (P.env == GRLX_ENV_CART_POLE && !P.no_specialisation && SpecCartPoleAc::matches(P))
-    {
-      if (variant) *variant = GRLX_KERNEL_SPECIALISED;
-      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_CART_POLE, 2, SpecCartPoleAc>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
-    }
-    else if (P.env == GRLX_ENV_CART_POLE)
-      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_CART_POLE, 2, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
-    else if (P.env == GRLX_ENV_PENDULUM)
-      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_PENDULUM, 2, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
-    else
+  if (!taps && P.replicas_per_wave >= 8)
+  { // two (four) sub-batches per wave share one environment phase (grlx_rollout_ac_wide.h); at most wave_limit waves, the
+    // replicas beyond their first load are handed out by a device-side counter as slots fall idle
+    const int R = P.replicas_per_wave;
+    const int all_waves = (P.n_replicas + R - 1) / R;
+    const int wwaves = all_waves < P.wave_limit ? all_waves : P.wave_limit;
+    hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, P.queue, (uint32_t)wwaves * (uint32_t)R);
+#define GRLX_LAUNCH_AC_WIDE(NB)                                                                                                  \
+    if (P.env == GRLX_ENV_CART_POLE && !P.no_specialisation && SpecCartPoleAc::matches(P))                                       \
+    {                                                                                                                            \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                                           \
+      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_CART_POLE, NB, SpecCartPoleAc>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+    }                                                                                                                            \
+    else if (P.env == GRLX_ENV_CART_POLE)                                                                                        \
+      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_CART_POLE, NB, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+    else if (P.env == GRLX_ENV_PENDULUM)                                                                                         \
+      hipLaunchKernelGGL((rollout_ac_wide_kernel<GRLX_ENV_PENDULUM, NB, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+    else                                                                                                                         \
       return hipErrorInvalidValue;
+    if (R == 16) { GRLX_LAUNCH_AC_WIDE(4) }
+    else { GRLX_LAUNCH_AC_WIDE(2) }
+#undef GRLX_LAUNCH_AC_WIDE
     return hipGetLastError();
   }
   switch (P.env)

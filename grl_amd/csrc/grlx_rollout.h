@@ -85,8 +85,14 @@ struct SpecNone {
 // TAP: per-step records of the tapped replica.  Normally the instantiation that updates in place; TAP with DEFER
 // records the PRODUCTION ordering step by step (grlx_config.tap_deferred), the trace length being the one the pending
 // update will leave.
+// GRLX_TWO_WAVES (experiment): limit the kernel to 256 registers so that two waves share a SIMD
+#ifdef GRLX_TWO_WAVES
+#define GRLX_ROLLOUT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define GRLX_ROLLOUT_OCCUPANCY
+#endif
 template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG, bool ADV = false, bool TAP = !DEFER>
-__global__ __launch_bounds__(64) void rollout_kernel(DevParams P, int n_trials)
+__global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevParams P, int n_trials)
 {
   static_assert(!(ADV && DEFER), "the advantage-learning instantiation updates in place");
   constexpr int NROWS = ADV ? 2 * NA : NA + 1;      // LDS rows of weights summed per pass

@@ -1,5 +1,9 @@
 // grlx_rollout_ac_wide.h -- actor-critic rollout with 8 replicas per wave: rollout_ac_kernel's table phase (grlx_rollout_ac.h)
 // under the wave layout and the per-replica trial sequencing of rollout_wide_kernel (grlx_rollout_wide.h).
+// Work queue: a wave starts with the replicas blockIdx*R .. +R-1 in its R slots; a slot whose replica has run its n_trials
+// writes it back and takes the next unstarted replica from the counter P.queue (set to gridDim*R by the launcher), until the
+// counter passes n_replicas.  Episodes of a learning batch are ragged, so this is what keeps the 8 slots of a wave busy;
+// every replica still runs its own trials in order with its own tables and streams: results do not depend on who runs it.
 // Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
 #pragma once
 
@@ -33,6 +37,9 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   __shared__ int      sh_term[R];
   __shared__ uint32_t sh_step[R];
   __shared__ uint32_t sh_est[R];
+  __shared__ uint32_t sh_rid[R];               // replica in slot q (kNoReplica: none)
+  __shared__ uint32_t sh_xwb[R];               // replica the slot has just retired: its environment state is still in the env lanes
+  constexpr uint32_t kNoReplica = 0xFFFFFFFFu;
 
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
@@ -41,12 +48,16 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
 
   // ---- environment role
   const int eq = lane % R;
-  const bool elive = wave0 + eq < P.n_replicas;
   double x[S];
 #pragma unroll
-  for (int i = 0; i < S; ++i) x[i] = P.states[elive ? wave0 + eq : 0].x[i];
+  for (int i = 0; i < S; ++i) x[i] = P.states[(wave0 + eq < P.n_replicas) ? wave0 + eq : 0].x[i];
   uint32_t estatus = 0;
-  if (lane < R) { sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0; }
+  if (lane < R)
+  {
+    sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0;
+    sh_rid[lane] = (wave0 + lane < P.n_replicas) ? (uint32_t)(wave0 + lane) : kNoReplica;
+    sh_xwb[lane] = kNoReplica;
+  }
 
   // ---- table role
   UpdateParams up;
@@ -60,16 +71,12 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   const double a_min = N.lin_actor.out_min, a_max = N.lin_actor.out_max;
   const bool a_limit = N.lin_actor.limit != 0;
 
-  for (int b = 0; b < B; ++b)
-  { // initial parked state: the critic's trace is restored (positions from HBM, weights from the current table)
-    const int q = 4 * b + g;
-    const bool live = wave0 + q < P.n_replicas;
-    const int r = live ? wave0 + q : 0;
+  // replica r into a slot: the critic's trace is restored (positions from HBM, weights from the current table)
+  auto slot_load = [&](int r, WideLane &c, WideRep &s) {
     const ReplicaState &RS = P.states[r];
     const Table tabC = table_of(P, 0, r);
-    WideLane c;
     trace_init(c.tr);
-    if (live && up.use_trace)
+    if (up.use_trace)
     {
       const uint32_t *ts = P.trace_state + ((size_t)r * 16 + (size_t)j) * kMaxTrace * 2;
       c.tr.len = RS.tr_len;
@@ -93,8 +100,6 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     c.inserted = 0;
     c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
     c.wp_seen = 0; c.wap_seen = 0;
-    wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
-    WideRep s;
     s.G = RS.G; s.TL = RS.TL;
     s.S1 = (uint64_t)__double_as_longlong(RS.ac_noise);
     s.eps_decay = RS.ac_decay;
@@ -105,7 +110,95 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     s.running = false; s.first = true; s.test = 0;
     s.ending = false;
     s.rows = RS.rows;
-    s.trials_left = live ? n_trials : 0;
+    s.trials_left = n_trials;
+  };
+  // ... and back: the critic's trace is persisted (its weights go to the table), the counters and streams to the replica
+  // (the environment state follows from the env lanes, see sh_xwb)
+  auto slot_store = [&](int r, int q, WideLane &c, WideRep &s) {
+    const Table tabC = table_of(P, 0, r);
+    trace_flush(c.tr, tabC, false);
+    if (up.use_trace)
+    {
+      uint32_t *ts = P.trace_state + ((size_t)r * 16 + (size_t)j) * kMaxTrace * 2;
+#pragma unroll
+      for (int e = 0; e < kMaxTrace; ++e)
+      {
+        ts[e * 2] = c.tr.pos[e];
+        ts[e * 2 + 1] = (trace_cnt(c.tr, e) & 0xFFFFu) | (((c.tr.wt >> e) & 1u) << 16);
+      }
+    }
+    uint32_t ic = c.inserted, ia = c.inserted2;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { ic += __shfl_xor(ic, off, 16); ia += __shfl_xor(ia, off, 16); }
+    uint32_t st = c.status | sh_est[q];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+    if (j == 0)
+    {
+      ReplicaState &RS = P.states[r];
+      RS.G = s.G;
+      RS.TL = s.TL;
+      RS.ac_decay = s.eps_decay;
+      RS.ac_noise = __longlong_as_double((long long)s.S1);
+      RS.tt = s.tt;
+      RS.ss = s.ss;
+      RS.test_steps = s.test_steps;
+      RS.n_slots[0] += ic;
+      RS.n_slots[1] += ia;
+      RS.rows = s.rows;
+      RS.tr_len = c.tr.len;
+      RS.tr_total = c.tr.total;
+      RS.status = st;
+    }
+  };
+  // a slot without a replica: nothing pending, nothing left to run
+  auto slot_empty = [&](WideLane &c, WideRep &s) {
+    trace_init(c.tr);
+    c.pd = c.pd_sh = c.p_sh = false;
+    c.pd_dW = c.pd_dT = c.pd_wp = 0;
+    c.pd_pos = c.p_pos = kInvalidPos;
+    c.status = 0;
+    c.inserted = 0;
+    c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
+    c.wp_seen = 0; c.wap_seen = 0;
+    s.G = 0; s.TL = 0; s.S1 = 0;
+    s.eps_decay = 0;
+    s.tt = 0; s.ss = 0;
+    s.test_steps = 0;
+    s.total_reward = 0; s.time = 0; s.action = 0;
+    s.action_index = 0;
+    s.running = false; s.first = true; s.test = 0;
+    s.ending = false;
+    s.rows = 0;
+    s.trials_left = 0;
+  };
+  // the env lanes of a retired slot still hold its last state (and status bits of its steps): to its replica, before the
+  // slot's next replica starts
+  auto env_write_back = [&]() {
+    const uint32_t wb = sh_xwb[eq];
+    if (rarely(__any(wb != kNoReplica)))
+    {
+      wave_sync();
+      if (wb != kNoReplica) estatus = 0u;               // the slot's next replica starts clean (its bits went out through sh_est)
+      if (wb != kNoReplica && lane < R)
+      {
+        ReplicaState &RS = P.states[wb];
+#pragma unroll
+        for (int i = 0; i < S; ++i) RS.x[i] = x[i];
+        sh_xwb[eq] = kNoReplica;
+      }
+      wave_sync();
+    }
+  };
+
+  for (int b = 0; b < B; ++b)
+  {
+    const int q = 4 * b + g;
+    WideLane c;
+    WideRep s;
+    if (wave0 + q < P.n_replicas) slot_load(wave0 + q, c, s);
+    else slot_empty(c, s);
+    wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
@@ -114,7 +207,8 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   {
     // ================= environment phase (see rollout_wide_kernel)
     {
-      const uint32_t todo = elive ? sh_step[eq] : 0u;
+      env_write_back();
+      const uint32_t todo = sh_step[eq];               // 0 for a slot without a replica
       if (rarely(__any(todo == 2u)))
       {
         if (todo == 2u)
@@ -138,6 +232,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           for (int i = 0; i < D; ++i) sh_obs[i * R + eq] = obs[i];
           sh_reward[eq] = reward;
           sh_term[eq] = terminal;
+          if (rarely(estatus != 0u)) sh_est[eq] = estatus;       // sticky status bits of this replica's steps (ST_DOMAIN)
         }
       }
       wave_sync();
@@ -148,15 +243,16 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     for (int b = 0; b < B; ++b)
     {
       const int q = 4 * b + g;
-      const bool live = wave0 + q < P.n_replicas;
-      const int r = live ? wave0 + q : 0;
+      const uint32_t rid = sh_rid[q];
+      const bool live = rid != kNoReplica;
+      const int r = live ? (int)rid : 0;
       const ReplicaState &RS = P.states[r];
       const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
       WideLane c;
       wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
       WideRep s;
       wide_rep_load<R>(s, sh_r64, sh_r32, q);
-      if (!__any(s.running || c.pd || s.trials_left > 0)) continue;
+      if (!__any(live)) continue;                     // (a live slot always has something to do: it retires the moment it has not)
       double ac_noise = __longlong_as_double((long long)s.S1), ac_decay = s.eps_decay;
 
       uint32_t slotA[1] = {0}, slotC[1] = {0};
@@ -348,9 +444,11 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
 
       // ---- between trials
       uint32_t step_next = s.running ? 1u : 0u;
-      const bool between = !s.running && !c.pd && s.trials_left > 0;
-      if (__any(between))
+      bool now_live = live;
+      const bool at_rest = live && !s.running && !c.pd;
+      if (__any(at_rest))
       {
+        bool between = at_rest && s.trials_left > 0;
         if (between && s.ending)
         { // end of a learning trial: make the table current; the entries stay -- the reference never clears the critic's trace
           if (!s.test) trace_flush(c.tr, tabC, false);
@@ -375,6 +473,22 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           s.tt++;
           s.trials_left--;
           s.ending = false;
+        }
+        if (at_rest && s.trials_left == 0)
+        { // this replica is done: back to HBM, and the next one from the queue (group-uniform: all 16 lanes are here)
+          slot_store(r, q, c, s);
+          uint32_t nr = 0u;
+          if (j == 0) nr = __hip_atomic_fetch_add(P.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          nr = __shfl(nr, 0, 16);
+          if (j == 0)
+          {
+            sh_xwb[q] = rid;
+            sh_est[q] = 0u;
+            sh_rid[q] = (nr < (uint32_t)P.n_replicas) ? nr : kNoReplica;
+          }
+          if (nr < (uint32_t)P.n_replicas) slot_load((int)nr, c, s);
+          else { slot_empty(c, s); now_live = false; }
+          between = now_live && s.trials_left > 0;
         }
         if (between && s.trials_left > 0)
         {
@@ -401,7 +515,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         sh_act[q] = s.action;
         sh_step[q] = step_next;
       }
-      more = more || s.running || c.pd || s.trials_left > 0;
+      more = more || now_live;
       s.S1 = (uint64_t)__double_as_longlong(ac_noise);
       s.eps_decay = ac_decay;
       wide_rep_store<R>(s, sh_r64, sh_r32, q);
@@ -411,60 +525,8 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     if (!__any(more)) break;
   }
 
-  // ---- write the replicas back; persist the critic's trace (weights are in the table already)
-  if (elive && lane < R)
-  {
-    ReplicaState &RS = P.states[wave0 + eq];
-#pragma unroll
-    for (int i = 0; i < S; ++i) RS.x[i] = x[i];
-    sh_est[eq] = estatus;
-  }
-  wave_sync();
-  for (int b = 0; b < B; ++b)
-  {
-    const int q = 4 * b + g;
-    const bool live = wave0 + q < P.n_replicas;
-    const int r = live ? wave0 + q : 0;
-    const Table tabC = table_of(P, 0, r);
-    WideLane c;
-    wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
-    WideRep s;
-    wide_rep_load<R>(s, sh_r64, sh_r32, q);
-    trace_flush(c.tr, tabC, false);
-    if (live && up.use_trace)
-    {
-      uint32_t *ts = P.trace_state + ((size_t)r * 16 + (size_t)j) * kMaxTrace * 2;
-#pragma unroll
-      for (int e = 0; e < kMaxTrace; ++e)
-      {
-        ts[e * 2] = c.tr.pos[e];
-        ts[e * 2 + 1] = (trace_cnt(c.tr, e) & 0xFFFFu) | (((c.tr.wt >> e) & 1u) << 16);
-      }
-    }
-    uint32_t ic = c.inserted, ia = c.inserted2;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) { ic += __shfl_xor(ic, off, 16); ia += __shfl_xor(ia, off, 16); }
-    uint32_t st = c.status | sh_est[q];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
-    if (live && j == 0)
-    {
-      ReplicaState &RS = P.states[r];
-      RS.G = s.G;
-      RS.TL = s.TL;
-      RS.ac_decay = s.eps_decay;
-      RS.ac_noise = __longlong_as_double((long long)s.S1);
-      RS.tt = s.tt;
-      RS.ss = s.ss;
-      RS.test_steps = s.test_steps;
-      RS.n_slots[0] += ic;
-      RS.n_slots[1] += ia;
-      RS.rows = s.rows;
-      RS.tr_len = c.tr.len;
-      RS.tr_total = c.tr.total;
-      RS.status = st;
-    }
-  }
+  // every slot has retired its last replica inside the loop; the env lanes still owe the states of the last ones
+  env_write_back();
 }
 
 } // namespace grlx

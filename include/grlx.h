@@ -129,7 +129,8 @@ typedef struct {
   double   beta;
   /* GPU-side layout (no reference counterpart): replicas carried by one wavefront.  0 = automatic: 4 (16 lanes per
    * replica, lane = tiling) while the batch has no more than 4 replicas per SIMD of the device, else 8 (two sub-batches
-   * of four share one environment phase; grlx_rollout_wide.h).  4 / 8 force the choice (tests); results are identical. */
+   * of four share one environment phase; grlx_rollout_wide.h).  4 / 8 force the choice (tests); the actor-critic kernel also
+   * takes 16 (four sub-batches; never chosen automatically: its LDS footprint halves the waves per CU).  Results are identical. */
   int32_t  replicas_per_wave;
   /* 1: the taps are recorded by the PRODUCTION ordering of the rollout kernel (TD update applied one pass later, under the
    * next step's table loads) instead of the in-place diagnostic ordering: per-step parity of the kernel that is benchmarked.
@@ -141,7 +142,11 @@ typedef struct {
    * target_interval LinearRepresentation::update calls (linear.cpp:267: one per write and one per trace entry).  Served by
    * its own plain kernel (pendulum / acrobot, 3 actions, replacing or no trace); 0 = none. */
   int32_t  target_interval;
-  int32_t  reserved1;
+  /* GPU-side layout (no reference counterpart), wide actor-critic kernel: at most this many wavefronts are launched; each
+   * carries replicas_per_wave replicas at a time and takes the next unstarted replica from a device-side counter whenever
+   * one of its slots has finished its trials (episodes of a learning batch are ragged: without the queue a wave idles until
+   * its slowest replica is done).  0 = automatic: one wave per SIMD of the device.  Results do not depend on it (tests). */
+  int32_t  wave_limit;
   double   target_tau;
 } grlx_config;
 

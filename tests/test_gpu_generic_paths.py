@@ -217,16 +217,21 @@ def test_wide_waves_are_chosen_for_batches_beyond_four_replicas_per_simd(grlx):
         grlx.Runner(grlx.pendulum_sarsa_config(8, replicas_per_wave=16), np.arange(8))
 
 
-@pytest.mark.parametrize("over", [dict(), dict(end_stop_penalty=1, ac_update_method=1, ac_step_limit=0.5)])
-def test_wide_waves_actor_critic_bit_exact(grlx, over):
+@pytest.mark.parametrize("over,n,wave_limit", [(dict(), 13, 0), (dict(end_stop_penalty=1, ac_update_method=1, ac_step_limit=0.5), 13, 0),
+                                               (dict(), 29, 1), (dict(end_stop_penalty=1), 29, 2), (dict(), 16, 1)])
+def test_wide_waves_actor_critic_bit_exact(grlx, over, n, wave_limit):
     """rollout_ac_wide_kernel: both actor update methods, the end-stop penalty (episodes of one wave end apart), the
-    critic's trace kept across episodes AND launches (three launches), a ragged batch, every replica checked."""
+    critic's trace kept across episodes AND launches (three launches), a ragged batch, every replica checked.
+    wave_limit 1 / 2: ONE (two) wave(s) for 29 replicas -- the first 8 (16) start in its slots, the others are taken from the
+    device-side queue as slots finish (grlx_rollout_ac_wide.h); 16 replicas on one wave: the queue runs dry with every slot
+    busy.  Who runs a replica must not matter."""
     from tests import configs
-    n, trials = 13, 24
+    trials = 24
     got = {}
-    for rpw in (8, 4):
+    for rpw in (16, 8, 4):
         cfg, spec = configs.cart_pole_ac(grlx, n, **over)
         cfg.replicas_per_wave = rpw
+        cfg.wave_limit = wave_limit
         cfg.max_rows = trials + 1
         r = grlx.Runner(cfg, np.arange(201, 201 + n))
         assert r.replicas_per_wave() == rpw
@@ -238,7 +243,7 @@ def test_wide_waves_actor_critic_bit_exact(grlx, over):
     for k in range(n):
         e = ob.Experiment(spec, seed=201 + k)
         rows, _ = e.run(trials)
-        for rpw in (8, 4):
+        for rpw in (16, 8, 4):
             (t, s, rew), rg, st, w0, w1 = got[rpw][k]
             assert list(s) == [x.steps for x in rows], f"rpw {rpw} replica {k}"
             assert_bit_equal(rew, [x.reward for x in rows], f"rpw {rpw}: returns of replica {k}")
