@@ -205,6 +205,12 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
 
   for (;;)
   {
+#ifdef GRLX_WIDE_STAMPS
+    const unsigned long long st0 = stamp();
+#define GRLX_AC_STAMP(k) { const unsigned long long t__ = stamp(); if (P.diag_out && lane == 0) P.diag_out[(size_t)blockIdx.x * 8 + (k)] += t__ - stl; stl = t__; }
+#else
+#define GRLX_AC_STAMP(k)
+#endif
     // ================= environment phase (see rollout_wide_kernel)
     {
       env_write_back();
@@ -238,6 +244,11 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       wave_sync();
     }
 
+#ifdef GRLX_WIDE_STAMPS
+    const unsigned long long st1 = stamp();
+    unsigned long long stl = st1;
+    if (P.diag_out && lane == 0) { P.diag_out[(size_t)blockIdx.x * 8 + 0] += st1 - st0; P.diag_out[(size_t)blockIdx.x * 8 + 2] += 1; }
+#endif
     // ================= table phase, one sub-batch after the other
     bool more = false;
     for (int b = 0; b < B; ++b)
@@ -246,7 +257,13 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       const uint32_t rid = sh_rid[q];
       const bool live = rid != kNoReplica;
       const int r = live ? (int)rid : 0;
-      const ReplicaState &RS = P.states[r];
+      const ReplicaState &RSg = P.states[r];
+      // the three fields the slot-creation path reads (start of the initialisation stream, loaded policy images): loaded here,
+      // with the buckets, instead of behind a miss -- early in learning nearly every pass of a sub-batch creates a slot
+      ReplicaState RS;
+      RS.TL0 = RSg.TL0;
+      RS.lazy_base[0] = RSg.lazy_base[0];
+      RS.lazy_base[1] = RSg.lazy_base[1];
       const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
       WideLane c;
       wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
       }
 
+      GRLX_AC_STAMP(3)
       // the PREVIOUS step's critic update, in the shadow of the loads just issued
       Evicted ev;
       ev.n = 0u; ev.pos = kInvalidPos; ev.val = 0;
@@ -309,6 +327,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         c.pd = false;
       }
 
+      GRLX_AC_STAMP(4)
       if (s.running)
       {
         uint32_t posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
@@ -345,6 +364,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         }
         if (need_critic) wC[0] = trace_forward(c.tr, posC[0], wC[0]);
         if (update) wpc = trace_forward(c.tr, c.p_pos, wpc);
+        GRLX_AC_STAMP(5)
         SHA(0, j, g) = wA[0];
         SHA(1, j, g) = wC[0];
         SHA(2, j, g) = wap;
@@ -441,6 +461,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         s.first = false;
       }
       if (ev.pos != kInvalidPos) value_store(tabC, ev.pos, ev.val);
+      GRLX_AC_STAMP(6)
 
       // ---- between trials
       uint32_t step_next = s.running ? 1u : 0u;
@@ -520,13 +541,19 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       s.eps_decay = ac_decay;
       wide_rep_store<R>(s, sh_r64, sh_r32, q);
       wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      GRLX_AC_STAMP(7)
     }
     wave_sync();
+#ifdef GRLX_WIDE_STAMPS
+    if (P.diag_out && lane == 0) P.diag_out[(size_t)blockIdx.x * 8 + 1] += stamp() - st1;
+#endif
     if (!__any(more)) break;
   }
 
   // every slot has retired its last replica inside the loop; the env lanes still owe the states of the last ones
   env_write_back();
 }
+
+#undef GRLX_AC_STAMP
 
 } // namespace grlx
