@@ -7,11 +7,19 @@ namespace grlx {
 // ------------------------------------------------- accumulating-trace rollout ---
 // trace/enumerated/accumulating (trace.h:238-263): no ssub, cut 1e-4 -- up to 19 entries in which a slot may
 // occur many times, every occurrence adding to the weight in the reference's order (entry-major, newest first;
-// tiling-minor).  Nothing is cached here: the trace holds table positions only and every update is a
-// read-modify-write of the table, entry after entry (same-address accesses of one wave complete in issue
-// order); slots shared between tilings are updated one lane at a time in tiling order.  SARSA, Q-learning and
-// Expected SARSA over one Q table; TD update in place.  A plain, correct path -- about 3x the time of the
-// replacing-trace kernel.
+// tiling-minor).  SARSA, Q-learning and Expected SARSA over one Q table; TD update in place.
+// The weights of the slots in the trace are CACHED (write-back), one value per entry in LDS (sh_tv, entry-major, lane-minor):
+//  * the value of a slot is authoritative at its HEAD -- its newest occurrence in this lane's trace (bit e of tnh = entry e
+//    has a newer occurrence); lookups and the weight of p are forwarded from the heads, the table is stale meanwhile;
+//  * one update walks the entries newest first; an entry continues from the result of the latest newer occurrence of its
+//    slot (or from p's freshly written value), and every result is handed back to the newer occurrences, so that after the
+//    walk all occurrences -- the head included -- hold the slot's final value: the additions of one step reach a slot one
+//    after the other in entry order, as in the reference;
+//  * a head that leaves the trace (dropped at the far end, trace cleared) is written to the table; the trace is flushed and
+//    cleared at the end of every learning trial (TDAgent::start would clear it anyway), so test trials and the host see
+//    the table current;
+//  * slots shared between tilings are not cached: read-modify-write of the table, one lane at a time in tiling order; a
+//    slot that becomes shared is written back first (on_share).
 constexpr int kAccTrace = 20;
 
 // f() in the flagged lanes of every 16-lane group, one lane of a group at a time, ascending
@@ -45,6 +53,7 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
   __shared__ uint32_t sh_mail[4];
   __shared__ double   sh_res[4 * 16];
   __shared__ uint64_t sh_jump[2048];
+  __shared__ double   sh_tv[kAccTrace * 64];         // cached weight per trace entry and lane
   jump_table_to_lds(sh_jump);
 
   const int lane = threadIdx.x & 63;
@@ -83,10 +92,13 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
   uint32_t tpos[kAccTrace];
 #pragma unroll
   for (int e = 0; e < kAccTrace; ++e) tpos[e] = kInvalidPos;
-  uint32_t tsh = 0;
+  uint32_t tsh = 0, tnh = 0;
   int tlen = 0;
   double ttotal = 1.;
   int tr_len_ref = 0;
+  constexpr uint32_t kAccMask = (1u << kAccTrace) - 1u;
+  // entries whose weight this lane caches: valid and not shared between tilings; heads: those without a newer occurrence
+  auto mine_mask = [&]() { return (tlen >= kAccTrace ? kAccMask : ((1u << tlen) - 1u)) & ~tsh; };
 
   auto add_to = [&](uint32_t pos, double d) {       // LinearRepresentation::update of one index (linear.cpp:198-216)
     const double v = value_load(tab, pos) + d;
@@ -109,11 +121,13 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
     int action_index = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0;
     bool p_sh = false;
+    double wp_seen = 0;                                     // weight of p's slot as looked up (and forwarded) one pass ago
     if (!test)
-    { // TDAgent::start -> predictor->finalize() -> trace_->clear() (td.cpp:54, sarsa.cpp:126-132)
+    { // TDAgent::start -> predictor->finalize() -> trace_->clear() (td.cpp:54, sarsa.cpp:126-132); it is empty already
+      // (flushed and cleared at the end of the previous learning trial)
 #pragma unroll
       for (int e = 0; e < kAccTrace; ++e) tpos[e] = kInvalidPos;
-      tsh = 0; tlen = 0; ttotal = 1.; tr_len_ref = 0;
+      tsh = 0; tnh = 0; tlen = 0; ttotal = 1.; tr_len_ref = 0;
     }
     bool first = true;
 
@@ -152,15 +166,44 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        bool shared_event = false;
         if (has_next)
           table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
-                        [&](uint32_t mp) { // a slot became shared: every entry that refers to it is updated serially from now on
+                        [&](uint32_t mp) { // a slot became shared: its cached value goes to the table (the finder reads it), and
+                          // every entry that refers to it is updated serially, on the table, from now on
                           if (p_pos == mp) p_sh = true;
+                          shared_event = true;
+                          const uint32_t heads = mine_mask() & ~tnh;
 #pragma unroll
-                          for (int e = 0; e < kAccTrace; ++e) tsh |= (tpos[e] == mp) ? (1u << e) : 0u;
+                          for (int e = 0; e < kAccTrace; ++e)
+                          {
+                            if (tpos[e] == mp && ((heads >> e) & 1u)) value_store(tab, mp, sh_tv[e * 64 + lane]);
+                            tsh |= (tpos[e] == mp) ? (1u << e) : 0u;
+                          }
                         });
-        double wp = 0;
-        if (update) wp = value_load(tab, p_pos);          // the table is always current here
+        // a slot this lane had cached and looked up in the same pass was written back AFTER its bucket was loaded
+        if (rarely(__any(shared_event)))
+        {
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            if (has_next && sh[a]) w[a] = value_load(tab, pos[a]);
+        }
+        // the cached weights of this lane's trace; what the table returned for a cached slot is stale: the head's value counts
+        double tv[kAccTrace];
+        const uint32_t mine = mine_mask(), heads = mine & ~tnh;
+#pragma unroll
+        for (int e = 0; e < kAccTrace; ++e) tv[e] = sh_tv[e * 64 + lane];
+        double wp = wp_seen;
+#pragma unroll
+        for (int e = kAccTrace - 1; e >= 0; --e)
+        {
+          const bool hd = ((heads >> e) & 1u) != 0u;
+#pragma unroll
+          for (int a = 0; a < NA; ++a) w[a] = (hd && tpos[e] == pos[a]) ? tv[e] : w[a];
+          wp = (hd && tpos[e] == p_pos) ? tv[e] : wp;
+        }
+        if (rarely(__any(update && p_sh)))
+          if (update && p_sh) wp = value_load(tab, p_pos);    // shared between tilings: the table is current
 #pragma unroll
         for (int a = 0; a < NA; ++a) SHW(a, j, g) = w[a];
         SHW(NA, j, g) = wp;
@@ -235,37 +278,47 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           delta = target - qsa;
           const double dW = P.alpha * (target - qsa);
           const double dT = P.alpha * delta;
-          // write(p, target, alpha): every index of p, in tiling order where tilings share the slot
-          if (!p_sh) add_to(p_pos, dW);
+          // write(p, target, alpha): every index of p, in tiling order where tilings share the slot.  p is about to enter the
+          // trace as its newest entry, so its new weight stays in the cache (unless the slot is shared between tilings)
+          const double newp = limit ? clampd(wp + dW, out_min, out_max) : wp + dW;
           serial_lanes(p_sh, [&]() { add_to(p_pos, dW); });
-          // update(trace, alpha*delta, e): newest entry first while its weight exceeds 0.001.  The slots this
-          // tiling owns alone are loaded together (one round trip); an entry whose slot occurred in a newer
-          // entry continues from that entry's result instead of its (stale) load, so every slot still
-          // receives its additions one after the other in entry order.  Shared slots: one lane at a time.
-          double cur[kAccTrace], de[kAccTrace];
-          bool mine[kAccTrace];
+          // update(trace, alpha*delta, e): newest entry first while its weight exceeds 0.001.  tv[e] becomes the value of the
+          // entry's slot after all additions processed so far: an entry starts from the latest newer occurrence of its slot
+          // (tv[k] of ANY newer occurrence k: they are kept equal), or from p's new weight, or -- a head -- from its cache
+          uint32_t dupp = 0, newer = 0;
           {
             double weight = 1.;
 #pragma unroll
             for (int e = 0; e < kAccTrace; ++e)
             {
+              const bool me = ((mine >> e) & 1u) != 0u;
               const bool go = e < tlen && weight > 0.001;
-              de[e] = weight * dT * ee;
-              mine[e] = go && ((tsh >> e) & 1u) == 0u;
-              cur[e] = mine[e] ? value_load(tab, tpos[e]) : 0.;
+              const double de = weight * dT * ee;
+              const bool isp = me && !p_sh && tpos[e] == p_pos;
+              dupp |= isp ? (1u << e) : 0u;
+              double base = isp ? newp : tv[e];
+              bool same[kAccTrace];
+              bool any = false;
+#pragma unroll
+              for (int k = 0; k < e; ++k)
+              {
+                same[k] = me && ((mine >> k) & 1u) != 0u && tpos[k] == tpos[e];
+                base = same[k] ? tv[k] : base;
+                any = any || same[k];
+              }
+              newer |= any ? (1u << e) : 0u;
+              const double v = base + de;
+              const double res = (go && me) ? (limit ? clampd(v, out_min, out_max) : v) : base;
+              tv[e] = res;
+#pragma unroll
+              for (int k = 0; k < e; ++k) tv[k] = same[k] ? res : tv[k];
               weight *= ee;
             }
           }
+          // p's weight after the walk: that of its oldest occurrence in the trace, if it has one
+          double p_fin = newp;
 #pragma unroll
-          for (int e = 0; e < kAccTrace; ++e)
-          {
-            double base = cur[e];
-#pragma unroll
-            for (int k = 0; k < e; ++k) base = (mine[k] && tpos[k] == tpos[e]) ? cur[k] : base;   // the latest newer occurrence wins
-            const double v = base + de[e];
-            cur[e] = limit ? clampd(v, out_min, out_max) : v;
-            if (mine[e]) value_store(tab, tpos[e], cur[e]);
-          }
+          for (int e = 0; e < kAccTrace; ++e) p_fin = ((dupp >> e) & 1u) ? tv[e] : p_fin;
           {
             double weight = 1.;
 #pragma unroll
@@ -273,31 +326,51 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
             {
               const bool go = e < tlen && weight > 0.001;
               const bool shared = ((tsh >> e) & 1u) != 0u;
-              const double d = de[e];
+              const double d = weight * dT * ee;
               const uint32_t at = tpos[e];
               if (rarely(__any(go && shared)))
                 serial_lanes(go && shared, [&]() { add_to(at, d); });
               weight *= ee;
             }
           }
-          // trace_->add(p, e) (trace.h:245-262)
-          if (ee < cut) { tlen = 0; ttotal = 1.; tsh = 0; }
-          if (tlen >= kAccTrace) status |= ST_TRACE_OVERFLOW;       // cannot happen: validated at create
-#pragma unroll
-          for (int e = kAccTrace - 1; e > 0; --e) tpos[e] = tpos[e - 1];
-          tsh = (tsh << 1) & ((1u << kAccTrace) - 1u);
-          tpos[0] = p_pos;
-          if (p_sh) tsh |= 1u;
-          tlen = (tlen < kAccTrace) ? tlen + 1 : kAccTrace;
+          // trace_->add(p, e) (trace.h:245-262): the entries move one place down, p becomes entry 0; heads that fall off the
+          // far end (or all of them, when the decay is below the cut) are written back
+          const int old_len = (ee < cut) ? 0 : tlen;                 // entries that survive the `ee < cut` reset
+          if (ee < cut) ttotal = 1.;
+          if (old_len >= kAccTrace) status |= ST_TRACE_OVERFLOW;       // cannot happen: validated at create
+          int new_len = (old_len < kAccTrace) ? old_len + 1 : kAccTrace;
           ttotal *= ee;
-          while (ttotal < cut && tlen > 1)
+          while (ttotal < cut && new_len > 1)
           {
             ttotal /= ee;
-            tlen--;
+            new_len--;
+          }
+          {
+            const uint32_t nonhead = tnh | dupp;
+#pragma unroll
+            for (int e = 0; e < kAccTrace; ++e)
+            { // old entry e moves to e + 1: it stays if e + 1 < new_len and the trace was not reset
+              const bool dropped = e < tlen && !(e < old_len && e + 1 < new_len);
+              const bool wb = dropped && ((mine >> e) & 1u) != 0u && ((nonhead >> e) & 1u) == 0u;
+              if (rarely(__any(wb)))
+                if (wb) value_store(tab, tpos[e], tv[e]);
+            }
+            if (ee < cut) { tsh = 0; tnh = 0; }
+            else tnh = ((nonhead) << 1) & kAccMask;
           }
 #pragma unroll
+          for (int e = kAccTrace - 1; e > 0; --e) tpos[e] = tpos[e - 1];
+          tsh = (tsh << 1) & kAccMask;
+          tpos[0] = p_pos;
+          if (p_sh) tsh |= 1u;
+          tlen = new_len;
+#pragma unroll
           for (int e = 0; e < kAccTrace; ++e)
-            if (e >= tlen) { tpos[e] = kInvalidPos; tsh &= ~(1u << e); }
+            if (e >= tlen) { tpos[e] = kInvalidPos; tsh &= ~(1u << e); tnh &= ~(1u << e); }
+          // the cache in its new order
+          sh_tv[lane] = p_fin;
+#pragma unroll
+          for (int e = 0; e + 1 < kAccTrace; ++e) sh_tv[(e + 1) * 64 + lane] = tv[e];
           tr_len_ref = tlen;
         }
 
@@ -342,10 +415,23 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           p_pos = pick<uint32_t, NA>(pos, a_next);
           p_slot = pick<uint32_t, NA>(slot, a_next);
           p_sh = pick<bool, NA>(sh, a_next);
+          wp_seen = pick<double, NA>(w, a_next);
         }
         if (!first && terminal) running = false;
         first = false;
       }
+    }
+
+    if (!test)
+    { // end of a learning trial: the cached weights go to the table, the trace is emptied (the next TDAgent::start would)
+      const uint32_t heads = mine_mask() & ~tnh;
+#pragma unroll
+      for (int e = 0; e < kAccTrace; ++e)
+      {
+        if ((heads >> e) & 1u) value_store(tab, tpos[e], sh_tv[e * 64 + lane]);
+        tpos[e] = kInvalidPos;
+      }
+      tsh = 0; tnh = 0; tlen = 0; ttotal = 1.;
     }
 
     if (live && (ti >= 0 ? test : 1))
