@@ -45,7 +45,7 @@ class Config(C.Structure):
                 ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
                 ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("tap_deferred", C.c_int32),
-                ("target_interval", C.c_int32), ("wave_limit", C.c_int32), ("target_tau", C.c_double)]
+                ("target_interval", C.c_int32), ("wave_limit", C.c_int32), ("table_log2_max", C.c_int32), ("target_tau", C.c_double)]
 
 
 class FqiConfig(C.Structure):
@@ -93,6 +93,8 @@ _SIGS = {
     "grlx_get_rng": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint64)]),
     "grlx_get_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double)]),
     "grlx_table_load": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_uint32)]),
+    "grlx_table_capacity": (C.c_int, [C.c_void_p, _P(C.c_uint32)]),
+    "grlx_grow_tables": (C.c_int, [C.c_void_p, C.c_uint32]),
     "grlx_get_target_weights": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double), _P(C.c_uint32)]),
     "grlx_export_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_load_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_uint64]),

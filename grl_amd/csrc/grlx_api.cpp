@@ -293,6 +293,8 @@ struct grlx_ctx {
   uint32_t     *tap_count = nullptr;
   uint64_t     *scratch = nullptr;        // 8 x u64
   uint32_t     *queue = nullptr;          // work queue of the wide actor-critic kernel: next unstarted replica
+  uint32_t     *max_load = nullptr;       // fullest table of the context after the last grlx_run (max_load_kernel)
+  uint32_t     logC_max = 26;             // growth bound of the sparse tables
   unsigned long long *diag = nullptr;
   uint32_t     *trace_state = nullptr;
   double       *tvals = nullptr;          // target network values per table position (target_interval > 0)
@@ -480,6 +482,9 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   const int N = cfg->n_replicas;
   uint32_t logC = cfg->table_log2_capacity ? (uint32_t)cfg->table_log2_capacity : 17u;
   if (logC < 8 || logC > 26) { delete ctx; return fail(GRLX_ERR_INVALID, "table_log2_capacity must be in 8..26"); }
+  if (cfg->table_log2_max != 0 && (cfg->table_log2_max < (int)logC || cfg->table_log2_max > 26))
+  { delete ctx; return fail(GRLX_ERR_INVALID, "table_log2_max must be 0 or in table_log2_capacity..26"); }
+  ctx->logC_max = cfg->table_log2_max ? (uint32_t)cfg->table_log2_max : 26u;
   P.n_replicas = N;
   P.logC = logC;
   P.max_rows = cfg->max_rows;
@@ -531,6 +536,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMemset(ctx->row_time, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->queue, sizeof(uint32_t)));
+  CTX_TRY(hipMalloc((void **)&ctx->max_load, sizeof(uint32_t)));
+  CTX_TRY(hipMemset(ctx->max_load, 0, sizeof(uint32_t)));
   CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));
   CTX_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
   if (cfg->agent == GRLX_AGENT_AC)
@@ -612,6 +619,7 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->tap_count);
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->queue);
+  (void)hipFree(ctx->max_load);
   (void)hipFree(ctx->diag);
   (void)hipFree(ctx->trace_state);
   (void)hipFree(ctx->tvals);
@@ -647,10 +655,78 @@ int grlx_read_diag(grlx_ctx *ctx, uint64_t *out, int cap_waves, int *n_waves)
   return GRLX_OK;
 }
 
+// Re-hash every table of the context into tables of 2^new_logC entries per replica.  Positions are internal to the tables,
+// to the persisted actor-critic trace and to the target values (both translated); nothing else refers to them.
+static int grow_tables(grlx_ctx *ctx, uint32_t new_logC)
+{
+  if (new_logC <= ctx->P.logC) return GRLX_OK;
+  if (new_logC > 26) return fail(GRLX_ERR_INVALID, "tables cannot grow beyond 2^26 entries");
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t N = (size_t)ctx->P.n_replicas, n_tables = (size_t)ctx->n_tables;
+  Entry *nt = nullptr;
+  uint32_t *remap = nullptr;
+  double *ntv = nullptr;
+  const size_t new_bytes = (N * n_tables * sizeof(Entry)) << new_logC;
+  auto oom = [&]() {
+    (void)hipGetLastError();
+    if (nt) (void)hipFree(nt);
+    if (remap) (void)hipFree(remap);
+    if (ntv) (void)hipFree(ntv);
+    return fail(GRLX_ERR_OOM, "no device memory to grow the sparse tables to 2^%u entries per replica (%.1f GiB)", new_logC, (double)new_bytes / 1073741824.);
+  };
+  if (hipMalloc((void **)&nt, new_bytes) != hipSuccess) return oom();
+  HIP_TRY(hipMemset(nt, 0, new_bytes));
+  if (ctx->trace_state || ctx->tvals)
+    if (hipMalloc((void **)&remap, (N * sizeof(uint32_t)) << ctx->P.logC) != hipSuccess) return oom();
+  if (ctx->tvals)
+  {
+    if (hipMalloc((void **)&ntv, (N * sizeof(double)) << new_logC) != hipSuccess) return oom();
+    HIP_TRY(hipMemset(ntv, 0xFF, (N * sizeof(double)) << new_logC));
+  }
+  HIP_TRY(launch_rehash(ctx->P, ctx->n_tables, nt, new_logC, remap, nullptr));
+  if (remap) HIP_TRY(launch_remap_positions(ctx->P, remap, new_logC, ntv, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(ctx->tables);
+  if (ctx->tvals) (void)hipFree(ctx->tvals);
+  if (remap) (void)hipFree(remap);
+  ctx->tables = nt;
+  ctx->tvals = ntv;
+  ctx->P.tables = nt;
+  ctx->P.tvals = ntv;
+  ctx->P.logC = new_logC;
+  return GRLX_OK;
+}
+
+int grlx_table_capacity(grlx_ctx *ctx, uint32_t *log2_entries)
+{
+  if (!ctx || !log2_entries) return fail(GRLX_ERR_INVALID, "bad argument");
+  *log2_entries = ctx->P.logC;
+  return GRLX_OK;
+}
+
+int grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2)
+{
+  if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
+  DRAIN(ctx);
+  return grow_tables(ctx, new_log2);
+}
+
 int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n_trials == 0) return GRLX_OK;
+  if (!ctx->run_pending && ctx->P.logC < ctx->logC_max)
+  { // nothing in flight: how full did the last run leave the fullest table?  Beyond a quarter, grow to an eighth.
+    uint32_t used = 0;
+    HIP_TRY(hipMemcpy(&used, ctx->max_load, sizeof(used), hipMemcpyDeviceToHost));
+    if ((uint64_t)used * 4u > (1ull << ctx->P.logC))
+    {
+      uint32_t want = ctx->P.logC;
+      while ((uint64_t)used * 8u > (1ull << want) && want < ctx->logC_max) ++want;
+      const int rc = grow_tables(ctx, want);
+      if (rc != GRLX_OK) return rc;
+    }
+  }
   // One launch per <= kTrialsPerLaunch trials: replica state (and the actor-critic trace) persists in
   // HBM between launches, so results do not depend on the chunking (tested), and no single kernel
   // runs for minutes (compass walker: up to 1000 steps per episode).
@@ -676,6 +752,7 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
     else
       HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
   }
+  HIP_TRY(launch_max_load(ctx->P, ctx->n_tables, ctx->max_load, (hipStream_t)stream));
   ctx->trials_run += n_trials;
   return GRLX_OK;
 }

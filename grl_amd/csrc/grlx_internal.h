@@ -142,5 +142,11 @@ hipError_t launch_math(int op, const double *x, const double *y, int n, double *
 hipError_t launch_rand48_at(uint64_t x0, const uint64_t *skip, int n, double *out, hipStream_t stream);
 hipError_t launch_curve_stats(const DevParams &P, int first, int count, double *out_dev, hipStream_t stream);
 hipError_t launch_step_counts(const DevParams &P, uint64_t *out_dev /*[3]: learn, test, status-or*/, hipStream_t stream);
+// sparse-table growth (grlx_api.cpp: grow_tables).  max over replicas and tables of the occupied slots; every entry of the
+// old tables re-inserted into tables of 2^new_logC entries per replica (remap_dev, optional: [replica][2^old logC] new position of
+// every old position of table 0); the positions persisted outside the tables translated (actor-critic trace, target values)
+hipError_t launch_max_load(const DevParams &P, int n_tables, uint32_t *out_dev, hipStream_t stream);
+hipError_t launch_rehash(const DevParams &P, int n_tables, Entry *new_tables, uint32_t new_logC, uint32_t *remap_dev, hipStream_t stream);
+hipError_t launch_remap_positions(const DevParams &P, const uint32_t *remap_dev, uint32_t new_logC, double *new_tvals, hipStream_t stream);
 
 } // namespace grlx

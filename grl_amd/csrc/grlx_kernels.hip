@@ -587,4 +587,100 @@ hipError_t launch_step_counts(const DevParams &P, uint64_t *out_dev, hipStream_t
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------ table growth ---
+__global__ __launch_bounds__(256) void max_load_kernel(DevParams P, int n_tables, uint32_t *out)
+{
+  __shared__ uint32_t m[256];
+  uint32_t v = 0;
+  for (int r = threadIdx.x; r < P.n_replicas; r += 256)
+    for (int t = 0; t < n_tables; ++t) v = max(v, P.states[r].n_slots[t]);
+  m[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1)
+  {
+    if ((int)threadIdx.x < off) m[threadIdx.x] = max(m[threadIdx.x], m[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = m[0];
+}
+
+hipError_t launch_max_load(const DevParams &P, int n_tables, uint32_t *out_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(max_load_kernel, dim3(1), dim3(256), 0, stream, P, n_tables, out_dev);
+  return hipGetLastError();
+}
+
+// One wave per (table, replica): the 64 lanes walk the old buckets and claim ways of the new table with a compare-and-swap
+// on the key word (the new table is at most a quarter full, probes are short).  Key word (slot, creating tiling, shared bit),
+// claim word and value move unchanged; only the position changes.
+__global__ __launch_bounds__(64) void rehash_kernel(DevParams P, int n_tables, Entry *new_tables, uint32_t new_logC, uint32_t *remap)
+{
+  const int r = blockIdx.x % P.n_replicas, table = blockIdx.x / P.n_replicas;
+  if (table >= n_tables) return;
+  const Table ot = table_of(P, table, r);
+  Table nt;
+  nt.base = reinterpret_cast<Bucket *>(new_tables + (((size_t)table * (size_t)P.n_replicas + (size_t)r) << new_logC));
+  nt.bmask = (1u << (new_logC - 2)) - 1u;
+  nt.shift = 32u - (new_logC - 2);
+  uint32_t *map = (remap && table == 0) ? remap + ((size_t)r << P.logC) : nullptr;
+  const uint32_t n_buckets = 1u << (P.logC - 2);
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += 64)
+  {
+    const Bucket ob = ot.base[b];
+    for (int way = 0; way < 4; ++way)
+    {
+      const uint32_t kw = ob.key[way];
+      if (map) map[b * 4 + way] = kInvalidPos;
+      if ((kw & kKeyMask) == 0u) continue;
+      uint32_t nb = table_home(nt, (kw & kKeyMask) - 1u);
+      uint32_t at = kInvalidPos;
+      for (int it = 0; it < kMaxProbe && at == kInvalidPos; ++it)
+      {
+        for (int w = 0; w < 4; ++w)
+          if (atomicCAS(&nt.base[nb].key[w], 0u, kw) == 0u) { at = (nb << 2) | (uint32_t)w; break; }
+        if (at == kInvalidPos) nb = (nb + 1u) & nt.bmask;
+      }
+      if (at == kInvalidPos) { P.states[r].status |= ST_TABLE_FULL; continue; }
+      nt.base[at >> 2].aux[at & 3u] = ob.aux[way];
+      nt.base[at >> 2].val[at & 3u] = ob.val[way];
+      if (map) map[b * 4 + way] = at;
+    }
+  }
+}
+
+hipError_t launch_rehash(const DevParams &P, int n_tables, Entry *new_tables, uint32_t new_logC, uint32_t *remap_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(rehash_kernel, dim3(P.n_replicas * n_tables), dim3(64), 0, stream, P, n_tables, new_tables, new_logC, remap_dev);
+  return hipGetLastError();
+}
+
+// positions kept outside the tables: the actor-critic's persisted critic trace and the target network's values
+__global__ __launch_bounds__(64) void remap_positions_kernel(DevParams P, const uint32_t *remap, uint32_t new_logC, double *new_tvals)
+{
+  const int r = blockIdx.x;
+  const uint32_t *map = remap + ((size_t)r << P.logC);
+  if (P.trace_state)
+  {
+    uint32_t *ts = P.trace_state + (size_t)r * 16 * kMaxTrace * 2;
+    for (int k = threadIdx.x; k < 16 * kMaxTrace; k += 64)
+    {
+      const uint32_t pos = ts[k * 2];
+      if (pos != kInvalidPos) ts[k * 2] = map[pos & ((1u << P.logC) - 1u)];
+    }
+  }
+  if (P.tvals && new_tvals)
+  {
+    const double *otv = P.tvals + ((size_t)r << P.logC);
+    double *ntv = new_tvals + ((size_t)r << new_logC);
+    for (uint32_t p = threadIdx.x; p < (1u << P.logC); p += 64)
+      if (map[p] != kInvalidPos) ntv[map[p]] = otv[p];
+  }
+}
+
+hipError_t launch_remap_positions(const DevParams &P, const uint32_t *remap_dev, uint32_t new_logC, double *new_tvals, hipStream_t stream)
+{
+  hipLaunchKernelGGL(remap_positions_kernel, dim3(P.n_replicas), dim3(64), 0, stream, P, remap_dev, new_logC, new_tvals);
+  return hipGetLastError();
+}
+
 } // namespace grlx

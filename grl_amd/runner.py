@@ -192,6 +192,15 @@ class Runner:
         capi.check(self.lib.grlx_table_load(self._ctx, table, replica, C.byref(n)))
         return n.value
 
+    def table_capacity(self) -> int:
+        """log2 of the entries per replica and table (the sparse tables grow between launches)."""
+        n = C.c_uint32(0)
+        capi.check(self.lib.grlx_table_capacity(self._ctx, C.byref(n)))
+        return int(n.value)
+
+    def grow_tables(self, new_log2: int):
+        capi.check(self.lib.grlx_grow_tables(self._ctx, new_log2))
+
     def taps(self):
         cap = max(int(self.cfg.tap_capacity), 1)
         buf = (capi.Tap * cap)()

@@ -147,6 +147,12 @@ typedef struct {
    * one of its slots has finished its trials (episodes of a learning batch are ragged: without the queue a wave idles until
    * its slowest replica is done).  0 = automatic: one wave per SIMD of the device.  Results do not depend on it (tests). */
   int32_t  wave_limit;
+  /* Sparse weight tables: table_log2_capacity (above) is the INITIAL size, 2^k entries per replica and table.  Between
+   * launches -- at the start of a grlx_run whose predecessor has been waited for (grlx_sync or any read-back) -- the fullest
+   * table of the context is looked at, and beyond a quarter of the capacity all tables are re-hashed into larger ones
+   * (results do not depend on it: positions are internal).  table_log2_max bounds the growth: 0 = up to 2^26; a value equal
+   * to the initial size = fixed tables, overflow is then the sticky error GRLX_ERR_TABLE_FULL, as within one launch. */
+  int32_t  table_log2_max;
   double   target_tau;
 } grlx_config;
 
@@ -238,6 +244,10 @@ int  grlx_get_rng(grlx_ctx *ctx, int replica, uint64_t out[4] /* G, TL, S1, S2 *
  * representation.h:201-263): current weights of the given reference slots. */
 int  grlx_get_weights(grlx_ctx *ctx, int table, int replica, const uint32_t *slots, int n, double *out);
 int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_used);
+/* Current table size (log2 of the entries per replica and table), and explicit growth to 2^new_log2 (waits for the context's
+ * work first; no-op if the tables are at least that large). */
+int  grlx_table_capacity(grlx_ctx *ctx, uint32_t *log2_entries);
+int  grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2);
 /* Replaces reading target()->params() (representation.h:266-282): the target network's current value of the given
  * reference slots of the Q table, and the number of synchronisations so far; contexts with target_interval > 0 only. */
 int  grlx_get_target_weights(grlx_ctx *ctx, int replica, const uint32_t *slots, int n, double *out, uint32_t *n_syncs);

@@ -383,3 +383,65 @@ def test_results_do_not_depend_on_stale_register_content(grlx, monkeypatch, patt
     _run_both(grlx, [31, 32, 33], 15, over, agent=1, chunks=[7, 8])
     _run_both(grlx, [41, 42, 43, 44, 45], 12, dict(test_interval=3), chunks=[12], force_generic=1)
     _run_both(grlx, [51, 52, 53, 54], 12, {}, chunks=[5, 7])
+
+
+# ------------------------------------------------ sparse tables that grow between launches ---
+@pytest.mark.parametrize("kind", ["pendulum_sarsa", "pendulum_wide", "cart_pole_ac", "cart_pole_ac_wide", "target_network", "accumulating"])
+def test_tables_grow_between_launches(grlx, kind):
+    """grlx_config.table_log2_capacity is the INITIAL size: started at 2^13 entries per replica, with a grlx_sync between
+    launches the tables are re-hashed into larger ones whenever the fullest passes a quarter of its capacity
+    (grlx_api.cpp grow_tables, rehash_kernel).  Positions are internal -- to the tables, to the actor-critic's persisted
+    critic trace and to the target network's values, which are translated -- so rows, RNG positions, environment state and
+    weights must equal the oracle's as with large tables, for every kernel family that keeps positions."""
+    from tests import configs
+    n, chunks = 6, [1, 1, 2, 3, 5, 10]
+    over = {}
+    if kind.startswith("pendulum") or kind in ("target_network", "accumulating"):
+        if kind == "target_network":
+            over = dict(target_interval=150, target_tau=0.3)
+        if kind == "accumulating":
+            over = dict(trace=2)
+        cfg, spec = configs.pendulum(grlx, n, table_log2_capacity=13, **over)
+        for k, v in over.items():
+            setattr(spec, k, v)
+        n_tables = 1
+    else:
+        cfg, spec = configs.cart_pole_ac(grlx, n, table_log2_capacity=13)
+        n_tables = 2
+    cfg.replicas_per_wave = 8 if kind.endswith("wide") else 4
+    trials = sum(chunks)
+    cfg.max_rows = trials + 1
+    seeds = np.arange(301, 301 + n)
+    r = grlx.Runner(cfg, seeds)
+    caps = [r.table_capacity()]
+    for c in chunks:
+        r.run(c); r.sync()                                      # the sync is what lets the next run look at the load
+        caps.append(r.table_capacity())
+    assert caps[0] == 13 and caps[-1] >= 15 and caps == sorted(caps), caps        # it grew (the cart-pole tables more than once)
+    rng = np.random.default_rng(3)
+    slots = rng.integers(0, 8388608, 1200).astype(np.uint32)
+    for k in range(n):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+        for t_ in range(n_tables):
+            assert_bit_equal(r.weights(k, slots, t_), e.weights(slots, t_), f"table {t_} of replica {k}")
+        if kind == "target_network":
+            tw, syncs = r.target_weights(k, slots)
+            assert syncs == e.L.orc_target_syncs(e.h) and syncs > 0
+            assert_bit_equal(tw, e.weights(slots, table=2), f"target table of replica {k}")
+        assert r.table_load(k) * 4 <= (1 << caps[-1]) * 2        # never far beyond the growth threshold
+        e.close()
+    # a bounded context keeps its size and reports the overflow as before
+    cfg2, _ = configs.pendulum(grlx, 2, table_log2_capacity=9, table_log2_max=9)
+    r2 = grlx.Runner(cfg2, [1, 2])
+    with pytest.raises(grlx.capi.GrlxError) as ei:
+        for c in range(6):
+            r2.run(3); r2.sync()
+    assert ei.value.code == grlx.capi.ERR_TABLE_FULL and r2.table_capacity() == 9
+    r2.close()
+    r.close()
