@@ -35,7 +35,7 @@ int main(int argc, char **argv)
 {
   if (argc != 5)
   {
-    std::cerr << "usage: " << argv[0] << " project|envstep <yaml> <object path> <input file>" << std::endl;
+    std::cerr << "usage: " << argv[0] << " project|envstep|represent <yaml> <object path> <input file>" << std::endl;
     return 1;
   }
   try
@@ -90,6 +90,33 @@ int main(int argc, char **argv)
         for (int k = 0; k < S; ++k) printf("%.17g ", state[(size_t)i * S + k]);
         for (int k = 0; k < D; ++k) printf("%.17g ", obs[(size_t)i * D + k]);
         printf("%.17g %d\n", reward[i], terminal[i]);
+      }
+    }
+    else if (std::string(argv[1]) == "represent")
+    { // rows: <op> <argument> <16 slot indices>; op 0 = read (argument ignored), 1 = write (argument = target, alpha 0.2),
+      // 2 = update (argument = delta); applied in order on a representation seeded with 1; prints what each read returns
+      Representation *rp = dynamic_cast<Representation *>(node->ptr());
+      if (!rp) throw Exception(std::string(argv[3]) + ": not a representation");
+      rp->reset(1);
+      for (int i = 0; i < n; ++i)
+      {
+        if (rows[i].size() != 18) throw Exception("input row must hold op, argument and 16 slot indices");
+        uint32_t idx[16];
+        for (int k = 0; k < 16; ++k) idx[k] = (uint32_t)rows[i][2 + k];
+        const int op = (int)rows[i][0];
+        const double arg = rows[i][1];
+        if (op == 0)
+        {
+          double out = 0;
+          rp->read(idx, 1, &out);
+          printf("%.17g\n", out);
+        }
+        else if (op == 1)
+          rp->write(idx, 1, &arg, 0.2);
+        else if (op == 2)
+          rp->update(idx, 1, &arg);
+        else
+          throw Exception("unknown representation op");
       }
     }
     else

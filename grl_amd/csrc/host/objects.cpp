@@ -363,11 +363,49 @@ struct TileCodingProjector : Projector {
 GRLX_REGISTER(TileCodingProjector)
 
 // representation/parameterized/linear (linear.cpp:34-101)
-struct LinearRepresentation : Configurable {
+struct LinearRepresentation : Representation {
   GRLX_TYPEINFO("representation/parameterized/linear")
   VecD init_min, init_max, output_min, output_max;
   int memory = 8 * 1024 * 1024, outputs = 1, limit = 1, interval = 0;
   double tau = 1;
+  // the stand-alone use of the object (Representation interface): a private one-replica context holds the parameters
+  grlx_ctx *own = nullptr;
+  ~LinearRepresentation() override { if (own) grlx_destroy(own); }
+  void reset(int64_t seed) override
+  {
+    if (outputs != 1) throw Exception(path() + ": the GPU operators serve representations with one output");
+    if (own) { grlx_destroy(own); own = nullptr; }
+    grlx_config c;
+    grlx_config_pendulum_sarsa(&c);
+    c.n_replicas = 1;
+    c.projector.memory = memory;
+    c.representation.init_min = init_min[0];
+    c.representation.init_max = init_max[0];
+    c.representation.output_min = output_min[0];
+    c.representation.output_max = output_max[0];
+    c.representation.limit = limit;
+    if (grlx_create(&c, &seed, &own) != GRLX_OK) { own = nullptr; throw Exception(path() + ": " + grlx_last_error()); }
+  }
+  grlx_ctx *context()
+  {
+    if (!own) reset(1);
+    return own;
+  }
+  void read(const uint32_t *idx, int n, double *out) override
+  {
+    const std::vector<int32_t> rep((size_t)n, 0);
+    if (grlx_read(context(), 0, rep.data(), idx, n, out) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
+  }
+  void write(const uint32_t *idx, int n, const double *target, double alpha) override
+  {
+    const std::vector<int32_t> rep((size_t)n, 0);
+    if (grlx_write(context(), 0, rep.data(), idx, n, target, alpha) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
+  }
+  void update(const uint32_t *idx, int n, const double *delta) override
+  {
+    const std::vector<int32_t> rep((size_t)n, 0);
+    if (grlx_update(context(), 0, rep.data(), idx, n, delta) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
+  }
   void request(const std::string &, ConfigurationRequest *config) override
   {
     config->push_back(CRP("init_min", "Lower initial value limit", VecD{0.}));

@@ -29,6 +29,18 @@ struct Projector : Configurable {
   virtual void project(const double *in, int n, uint32_t *out) const = 0;
 };
 
+// Representation::read / write / update (representation.h:60-83 -> LinearRepresentation, linear.cpp:136-216) for rows of
+// projections idx[n][16] (reference slot indices, as Projector::project returns them), applied in row order.  The parameter
+// vector lives on the GPU: the object owns a one-replica context whose table it is -- drawn from srand48(seed) the way
+// LinearRepresentation::configure draws it as the first user of a fresh process -- and forwards to grlx_read / grlx_write /
+// grlx_update (HIP kernel table_op_kernel).  target[n] / delta[n]: one output per row (outputs = 1).
+struct Representation : Configurable {
+  virtual void reset(int64_t seed) = 0;
+  virtual void read(const uint32_t *idx, int n, double *out) = 0;
+  virtual void write(const uint32_t *idx, int n, const double *target, double alpha) = 0;
+  virtual void update(const uint32_t *idx, int n, const double *delta) = 0;
+};
+
 // Experiment::run (experiment.h:44) -> learning curve of replica 0
 struct OnlineLearningExperiment : Configurable {
   virtual std::vector<double> run(const RunOptions &opt) = 0;

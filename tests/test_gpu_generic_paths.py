@@ -255,8 +255,9 @@ def test_wide_waves_actor_critic_bit_exact(grlx, over, n, wave_limit):
 
 
 def test_host_layer_plugin_interfaces(grlx, tmp_path):
-    """The C++ host layer's Projector::project and Environment::step (grl_amd/csrc/host/objects.h), instantiated from the
-    reference's own yaml and driven through grl_amd/bin/grlx_ops: indices and transitions equal the oracle's bit for bit."""
+    """The C++ host layer's Projector::project, Environment::step and Representation::read/write/update
+    (grl_amd/csrc/host/objects.h), instantiated from the reference's own yaml and driven through grl_amd/bin/grlx_ops:
+    indices, transitions and representation outputs equal the oracle's bit for bit."""
     import subprocess
     from grl_amd import _build
     from tests import configs
@@ -288,6 +289,47 @@ def test_host_layer_plugin_interfaces(grlx, tmp_path):
         assert_bit_equal(out[:, S:S + D], nobs, yaml_name + ": observation")
         assert_bit_equal(out[:, S + D], nrew, yaml_name + ": reward")
         assert list(out[:, S + D + 1].astype(int)) == list(nterm)
+    # Representation::read / write / update (representation.h:60-83): a sequence of operations on the yaml's
+    # representation/parameterized/linear object (seed 1), against a dense restatement of linear.cpp:136-216 on the oracle's
+    # initial parameter vector -- lazily initialised slots, duplicate indices inside a projection
+    yaml = os.path.join(root, "tests", "golden", "pendulum-sarsa-tc.yaml")
+    e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=1)
+    dense = {}
+
+    def w(slot):
+        if slot not in dense:
+            dense[slot] = float(e.weights([slot])[0])
+        return dense[slot]
+
+    lines, want = [], []
+    for it in range(60):
+        idx = rng.integers(0, 300, 16)
+        if it % 4 == 0:
+            idx[5] = idx[2]
+        op = it % 3
+        arg = float(rng.uniform(-5, 5))
+        lines.append(" ".join([str(op), repr(arg)] + [str(int(v)) for v in idx]))
+        if op == 0:
+            s = 0.0
+            for v in idx:
+                s += w(int(v))
+            want.append(s / 16)
+        elif op == 1:
+            s = 0.0
+            for v in idx:
+                s += w(int(v))
+            d = 0.2 * (arg - s / 16)
+            for v in idx:
+                dense[int(v)] = w(int(v)) + d
+        else:
+            for v in idx:
+                dense[int(v)] = w(int(v)) + arg
+    e.close()
+    f.write_text("\n".join(lines) + "\n")
+    res = subprocess.run([_build.GRLX_OPS, "represent", yaml, "experiment/agent/policy/representation", str(f)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = [float(v) for v in res.stdout.split()]
+    assert_bit_equal(got, want, "Representation::read after writes and updates")
 
 
 @pytest.mark.parametrize("env,agent,memory", [("pendulum", 0, 8388608), ("pendulum", 1, 8388608), ("pendulum", 3, 8388608),
