@@ -285,8 +285,15 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           // update(trace, alpha*delta, e): newest entry first while its weight exceeds 0.001.  tv[e] becomes the value of the
           // entry's slot after all additions processed so far: an entry starts from the latest newer occurrence of its slot
           // (tv[k] of ANY newer occurrence k: they are kept equal), or from p's new weight, or -- a head -- from its cache
-          uint32_t dupp = 0, newer = 0;
+          uint32_t dupp = 0;
           {
+            // positions of the cached entries; an entry this lane does not cache gets a value no other entry has, so that one
+            // compare decides "same slot, both cached" (the compare is made twice per pair rather than kept: 190 lane masks
+            // do not fit the scalar registers)
+            uint32_t tq[kAccTrace];
+#pragma unroll
+            for (int e = 0; e < kAccTrace; ++e) tq[e] = ((mine >> e) & 1u) ? tpos[e] : (kInvalidPos - 1u - (uint32_t)e);
+            const uint32_t pq = p_sh ? kInvalidPos : p_pos;
             double weight = 1.;
 #pragma unroll
             for (int e = 0; e < kAccTrace; ++e)
@@ -294,24 +301,16 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
               const bool me = ((mine >> e) & 1u) != 0u;
               const bool go = e < tlen && weight > 0.001;
               const double de = weight * dT * ee;
-              const bool isp = me && !p_sh && tpos[e] == p_pos;
+              const bool isp = tq[e] == pq;
               dupp |= isp ? (1u << e) : 0u;
               double base = isp ? newp : tv[e];
-              bool same[kAccTrace];
-              bool any = false;
 #pragma unroll
-              for (int k = 0; k < e; ++k)
-              {
-                same[k] = me && ((mine >> k) & 1u) != 0u && tpos[k] == tpos[e];
-                base = same[k] ? tv[k] : base;
-                any = any || same[k];
-              }
-              newer |= any ? (1u << e) : 0u;
+              for (int k = 0; k < e; ++k) base = (tq[k] == tq[e]) ? tv[k] : base;
               const double v = base + de;
               const double res = (go && me) ? (limit ? clampd(v, out_min, out_max) : v) : base;
               tv[e] = res;
 #pragma unroll
-              for (int k = 0; k < e; ++k) tv[k] = same[k] ? res : tv[k];
+              for (int k = 0; k < e; ++k) tv[k] = (tq[k] == tq[e]) ? res : tv[k];
               weight *= ee;
             }
           }
