@@ -61,10 +61,10 @@ SECONDARY = [
          kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>", want_kernel=2),
     dict(key="acrobot_q", replicas=8192, trials=32, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
          workload="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 32 trials per replica per step",
-         kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, generic, deferred update>", want_kernel=1),
+         kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ, deferred update>", want_kernel=2),
     dict(key="compass_walker_q", replicas=8192, trials=32, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
          workload="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 32 trials per replica per step",
-         kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, generic, deferred update>", want_kernel=1),
+         kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, SpecWalkerQ, deferred update>", want_kernel=2),
 ]
 
 

@@ -221,6 +221,16 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
     }
     GRLX_LAUNCH_WIDE_SPEC(GRLX_AGENT_SARSA)
     GRLX_LAUNCH_WIDE_SPEC(GRLX_AGENT_Q)
+#define GRLX_LAUNCH_WIDE_SPECQ(SPECQ)                                                                                 \
+    if (!P.no_specialisation && SPECQ::matches(P))                                                                  \
+    {                                                                                                               \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                              \
+      hipLaunchKernelGGL((rollout_wide_kernel<SPECQ::kEnv, 3, 2, SPECQ>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                     \
+    }
+    GRLX_LAUNCH_WIDE_SPECQ(SpecWalkerQ)
+    GRLX_LAUNCH_WIDE_SPECQ(SpecAcrobotQ)
+#undef GRLX_LAUNCH_WIDE_SPECQ
     GRLX_LAUNCH_WIDE(GRLX_ENV_PENDULUM, 3)
     GRLX_LAUNCH_WIDE(GRLX_ENV_PENDULUM, 5)
     GRLX_LAUNCH_WIDE(GRLX_ENV_ACROBOT, 3)
@@ -243,6 +253,16 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
     GRLX_LAUNCH_SPEC(GRLX_AGENT_Q)
     GRLX_LAUNCH_SPEC(GRLX_AGENT_EXPECTED_SARSA)
 #undef GRLX_LAUNCH_SPEC
+#define GRLX_LAUNCH_SPECQ(SPECQ)                                                                                       \
+    if (SPECQ::matches(P))                                                                                             \
+    {                                                                                                                  \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                                 \
+      hipLaunchKernelGGL((rollout_kernel<SPECQ::kEnv, 3, false, SPECQ>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                        \
+    }
+    GRLX_LAUNCH_SPECQ(SpecWalkerQ)
+    GRLX_LAUNCH_SPECQ(SpecAcrobotQ)
+#undef GRLX_LAUNCH_SPECQ
   }
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 3)
   GRLX_LAUNCH(GRLX_ENV_PENDULUM, 5)

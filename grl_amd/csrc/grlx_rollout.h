@@ -74,6 +74,107 @@ struct SpecPendulumTcA {
   __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_pendulum_tc; }
 };
 using SpecPendulumTc = SpecPendulumTcA<GRLX_AGENT_SARSA>;
+
+// Every numeric field of the parameter block (what a kernel reads through SPEC::numeric) equal, bit for bit.  Pointers,
+// sizes, taps and layout choices stay run-time values of P.
+inline bool spec_numeric_equal(const DevParams &a, const DevParams &b)
+{
+  auto tile_eq = [](const TileParams &x, const TileParams &y) {
+    bool ok = x.T == y.T && x.D == y.D && x.memory == y.memory;
+    for (int i = 0; i < GRLX_MAX_DIMS; ++i) ok = ok && x.scaling[i] == y.scaling[i] && x.wrap[i] == y.wrap[i];
+    return ok;
+  };
+  auto lin_eq = [](const LinearParams &x, const LinearParams &y) {
+    return x.init_min == y.init_min && x.init_range == y.init_range && x.out_min == y.out_min && x.out_max == y.out_max &&
+           x.limit == y.limit && x.draws_before == y.draws_before;
+  };
+  bool ok = a.test_interval == b.test_interval && a.env == b.env && a.agent == b.agent && a.trace_kind == b.trace_kind &&
+            a.integration_steps == b.integration_steps && a.h == b.h && a.timeout == b.timeout && a.randomization == b.randomization &&
+            a.A == b.A && tile_eq(a.tile, b.tile) && lin_eq(a.lin, b.lin) && a.epsilon == b.epsilon && a.decay_rate == b.decay_rate &&
+            a.decay_min == b.decay_min && a.alpha == b.alpha && a.gamma == b.gamma && a.gl == b.gl &&
+            tile_eq(a.tile_actor, b.tile_actor) && lin_eq(a.lin_actor, b.lin_actor) && a.actor_alpha == b.actor_alpha &&
+            a.sigma == b.sigma && a.theta == b.theta && a.ac_decay_rate == b.ac_decay_rate && a.ac_decay_min == b.ac_decay_min &&
+            a.ac_step_limit == b.ac_step_limit && a.ac_update_method == b.ac_update_method && a.action_min == b.action_min &&
+            a.action_max == b.action_max && a.end_stop_penalty == b.end_stop_penalty && a.action_penalty == b.action_penalty &&
+            a.control_step == b.control_step && a.slope_angle == b.slope_angle &&
+            a.initial_state_variation == b.initial_state_variation && a.negative_reward == b.negative_reward &&
+            a.walker_dt == b.walker_dt && a.kappa == b.kappa && a.beta == b.beta && a.tile_safe == b.tile_safe &&
+            a.target_interval == b.target_interval && a.target_tau == b.target_tau;
+  for (int i = 0; i < kMaxActions; ++i) ok = ok && a.actions[i] == b.actions[i];
+  return ok;
+}
+
+// The agent block of the reference's Q-learning yamls (cfg/pendulum/q_tc.yaml, cfg/compass_walker/qlearning_walk.yaml):
+// epsilon-greedy 0.05, alpha 0.2, gamma 0.97, lambda 0.65, replacing trace, test_interval 10, weights U(0, 1), no output limits
+constexpr void spec_q_agent_block(DevParams &P)
+{
+  P.agent = GRLX_AGENT_Q;
+  P.trace_kind = GRLX_TRACE_REPLACING;
+  P.test_interval = 10;
+  P.randomization = 0;
+  P.A = 3;
+  P.tile.T = 16; P.tile.memory = 8388608;
+  P.lin.init_min = 0; P.lin.init_range = 1;
+  P.lin.out_min = -1.7976931348623157e308; P.lin.out_max = 1.7976931348623157e308;
+  P.lin.limit = 1; P.lin.draws_before = 0;
+  P.epsilon = 0.05; P.decay_rate = 1; P.decay_min = 0;
+  P.alpha = 0.2; P.gamma = 0.97; P.gl = 0.97 * 0.65;
+  // fields these kernels do not read, at the values grlx_config_pendulum_sarsa leaves them (the comparison covers every field)
+  P.end_stop_penalty = 1;
+  P.slope_angle = 0.004; P.initial_state_variation = 0.2; P.negative_reward = -100.0;
+}
+// cfg/compass_walker/qlearning_walk.yaml (BASELINE config 4): every derived value by the expression of make_params (grlx_api.cpp)
+constexpr DevParams make_spec_walker_q()
+{
+  DevParams P{};
+  spec_q_agent_block(P);
+  P.env = GRLX_ENV_COMPASS_WALKER;
+  P.integration_steps = 20;
+  P.control_step = 0.2;
+  P.h = 0.2 / (double)(size_t)20;
+  P.timeout = 100.0;
+  P.slope_angle = 0.004; P.initial_state_variation = 0.2; P.negative_reward = -100.0;
+  P.walker_dt = 1.0E-6 * (double)(uint64_t)200000 / 20;          // floor((0.2 + 0.5E-6) * 1E6) = 200000 whole microseconds
+  P.action_min = -1.2; P.action_max = 1.2;
+  P.actions[0] = -1.2 + (2.4 / 2.) * 0; P.actions[1] = -1.2 + (2.4 / 2.) * 1; P.actions[2] = -1.2 + (2.4 / 2.) * 2;
+  P.tile.D = 6;
+  P.tile.scaling[0] = 16 / 0.0838; P.tile.scaling[1] = 16 / 0.1047; P.tile.scaling[2] = 16 / 0.1111;
+  P.tile.scaling[3] = 16 / 0.2222; P.tile.scaling[4] = 16 / 10.; P.tile.scaling[5] = 16 / 1.2;
+  return P;
+}
+// the acrobot of SURVEY 8d config 4 (the reference ships no TD yaml for it): dynamics/acrobot + task/acrobot/balancing under the
+// same agent block, 3 torques over [-1, 1], control step 0.05 s, tile resolution [0.05, 0.05, 0.2, 0.4 | 1.0]
+constexpr DevParams make_spec_acrobot_q()
+{
+  DevParams P{};
+  spec_q_agent_block(P);
+  P.env = GRLX_ENV_ACROBOT;
+  P.integration_steps = 5;
+  P.control_step = 0.05;
+  P.h = 0.05 / (double)(size_t)5;
+  P.timeout = 20.0;
+  P.walker_dt = 1.0E-6 * (double)(uint64_t)50000 / 5;
+  P.action_min = -1.0; P.action_max = 1.0;
+  P.actions[0] = -1.0 + (2.0 / 2.) * 0; P.actions[1] = -1.0 + (2.0 / 2.) * 1; P.actions[2] = -1.0 + (2.0 / 2.) * 2;
+  P.tile.D = 5;
+  P.tile.scaling[0] = 16 / 0.05; P.tile.scaling[1] = 16 / 0.05; P.tile.scaling[2] = 16 / 0.2; P.tile.scaling[3] = 16 / 0.4;
+  P.tile.scaling[4] = 16 / 1.0;
+  return P;
+}
+__device__ const DevParams d_spec_walker_q = make_spec_walker_q();
+__device__ const DevParams d_spec_acrobot_q = make_spec_acrobot_q();
+struct SpecWalkerQ {
+  static constexpr int kEnv = GRLX_ENV_COMPASS_WALKER;
+  __device__ static __forceinline__ int agent(const DevParams &) { return GRLX_AGENT_Q; }
+  static bool matches(const DevParams &P) { constexpr DevParams C = make_spec_walker_q(); return spec_numeric_equal(P, C); }
+  __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_walker_q; }
+};
+struct SpecAcrobotQ {
+  static constexpr int kEnv = GRLX_ENV_ACROBOT;
+  __device__ static __forceinline__ int agent(const DevParams &) { return GRLX_AGENT_Q; }
+  static bool matches(const DevParams &P) { constexpr DevParams C = make_spec_acrobot_q(); return spec_numeric_equal(P, C); }
+  __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_acrobot_q; }
+};
 struct SpecNone {
   __device__ static __forceinline__ const DevParams &numeric(const DevParams &P) { return P; }
   __device__ static __forceinline__ int agent(const DevParams &P) { return P.agent; }

@@ -181,14 +181,23 @@ def _wide_vs_oracle(grlx, make, n, trials, sample, chunks, **over):
         e.close()
 
 
-@pytest.mark.parametrize("name,n,trials,agent", [("pendulum", 21, 33, 0), ("pendulum", 13, 22, 1), ("pendulum", 9, 22, 3),
-                                                 ("acrobot", 19, 44, 1), ("acrobot", 10, 33, 0), ("compass_walker", 11, 22, 1)])
-def test_wide_waves_bit_exact(grlx, name, n, trials, agent):
+@pytest.mark.parametrize("name,n,trials,agent,generic", [("pendulum", 21, 33, 0, 0), ("pendulum", 13, 22, 1, 0), ("pendulum", 9, 22, 3, 0),
+                                                         ("acrobot", 19, 44, 1, 0), ("acrobot", 10, 33, 0, 0), ("compass_walker", 11, 22, 1, 0),
+                                                         ("acrobot", 19, 44, 1, 1), ("compass_walker", 11, 22, 1, 1)])
+def test_wide_waves_bit_exact(grlx, name, n, trials, agent, generic):
     """Ragged batches (n mod 8 != 0: a half-empty sub-batch, a dead 16-lane group), every replica checked; episodes of
-    the acrobot and the walker end at different steps inside one wave (absorbing states), so sub-batches finish apart."""
+    the acrobot and the walker end at different steps inside one wave (absorbing states), so sub-batches finish apart.
+    Q-learning on the acrobot and on the walker with these parameters runs compile-time specialised instantiations
+    (SpecAcrobotQ, SpecWalkerQ; both layouts); generic = 1 forces the run-time-parameter kernels on the same experiment."""
     from tests import configs
     make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot, "compass_walker": configs.compass_walker}[name]
-    _wide_vs_oracle(grlx, lambda g, k, **o: make(g, k, agent=agent, **o), n, trials, list(range(n)), [trials // 3, trials - trials // 3])
+    if name != "pendulum" and agent == 1:
+        cfg, _ = make(grlx, n, agent=agent, force_generic=generic)
+        r = grlx.Runner(cfg, np.arange(n)); r.run(1); r.sync()
+        assert r.last_kernel() == (1 if generic else 2)
+        r.close()
+    _wide_vs_oracle(grlx, lambda g, k, **o: make(g, k, agent=agent, force_generic=generic, **o), n, trials, list(range(n)),
+                    [trials // 3, trials - trials // 3])
 
 
 def test_wide_waves_generic_parameters_and_tiny_memory(grlx):

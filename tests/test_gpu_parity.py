@@ -1132,7 +1132,8 @@ def test_kernel_selection(grlx):
              (grlx.pendulum_sarsa_config(4, force_generic=1), 1), (grlx.pendulum_sarsa_config(4, alpha=0.25), 1),
              (grlx.pendulum_sarsa_config(4, tap_replica=0, tap_capacity=10), 3),
              (configs.cart_pole_ac(grlx, 4)[0], 2), (configs.cart_pole_ac(grlx, 4, sigma=4.0)[0], 1),
-             (configs.cart_pole_ac(grlx, 4, force_generic=1)[0], 1), (configs.acrobot(grlx, 4)[0], 1)]
+             (configs.cart_pole_ac(grlx, 4, force_generic=1)[0], 1), (configs.acrobot(grlx, 4)[0], 2), (configs.acrobot(grlx, 4, agent=0)[0], 1),
+             (configs.acrobot(grlx, 4, alpha=0.25)[0], 1), (configs.compass_walker(grlx, 4)[0], 2), (configs.compass_walker(grlx, 4, gamma=0.96)[0], 1)]
     for cfg, want in cases:
         r = grlx.Runner(cfg, [1, 2, 3, 4])
         assert r.last_kernel() == 0
