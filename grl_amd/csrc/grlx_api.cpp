@@ -663,36 +663,29 @@ static int grow_tables(grlx_ctx *ctx, uint32_t new_logC)
   if (new_logC > 26) return fail(GRLX_ERR_INVALID, "tables cannot grow beyond 2^26 entries");
   HIP_TRY(hipDeviceSynchronize());
   const size_t N = (size_t)ctx->P.n_replicas, n_tables = (size_t)ctx->n_tables;
-  Entry *nt = nullptr;
-  uint32_t *remap = nullptr;
-  double *ntv = nullptr;
   const size_t new_bytes = (N * n_tables * sizeof(Entry)) << new_logC;
-  auto oom = [&]() {
-    (void)hipGetLastError();
-    if (nt) (void)hipFree(nt);
-    if (remap) (void)hipFree(remap);
-    if (ntv) (void)hipFree(ntv);
-    return fail(GRLX_ERR_OOM, "no device memory to grow the sparse tables to 2^%u entries per replica (%.1f GiB)", new_logC, (double)new_bytes / 1073741824.);
-  };
-  if (hipMalloc((void **)&nt, new_bytes) != hipSuccess) return oom();
-  HIP_TRY(hipMemset(nt, 0, new_bytes));
-  if (ctx->trace_state || ctx->tvals)
-    if (hipMalloc((void **)&remap, (N * sizeof(uint32_t)) << ctx->P.logC) != hipSuccess) return oom();
-  if (ctx->tvals)
+  DevBuf nt, remap, ntv;                     // freed on every early return; ownership moves to the context at the end
+  if (nt.alloc(new_bytes) != hipSuccess ||
+      ((ctx->trace_state || ctx->tvals) && remap.alloc((N * sizeof(uint32_t)) << ctx->P.logC) != hipSuccess) ||
+      (ctx->tvals && ntv.alloc((N * sizeof(double)) << new_logC) != hipSuccess))
   {
-    if (hipMalloc((void **)&ntv, (N * sizeof(double)) << new_logC) != hipSuccess) return oom();
-    HIP_TRY(hipMemset(ntv, 0xFF, (N * sizeof(double)) << new_logC));
+    (void)hipGetLastError();
+    return fail(GRLX_ERR_OOM, "no device memory to grow the sparse tables to 2^%u entries per replica (%.1f GiB)", new_logC,
+                (double)new_bytes / 1073741824.);
   }
-  HIP_TRY(launch_rehash(ctx->P, ctx->n_tables, nt, new_logC, remap, nullptr));
-  if (remap) HIP_TRY(launch_remap_positions(ctx->P, remap, new_logC, ntv, nullptr));
+  HIP_TRY(hipMemset(nt.p, 0, new_bytes));
+  if (ntv.p) HIP_TRY(hipMemset(ntv.p, 0xFF, (N * sizeof(double)) << new_logC));
+  HIP_TRY(launch_rehash(ctx->P, ctx->n_tables, (Entry *)nt.p, new_logC, (uint32_t *)remap.p, nullptr));
+  if (remap.p) HIP_TRY(launch_remap_positions(ctx->P, (const uint32_t *)remap.p, new_logC, (double *)ntv.p, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   (void)hipFree(ctx->tables);
   if (ctx->tvals) (void)hipFree(ctx->tvals);
-  if (remap) (void)hipFree(remap);
-  ctx->tables = nt;
-  ctx->tvals = ntv;
-  ctx->P.tables = nt;
-  ctx->P.tvals = ntv;
+  ctx->tables = (Entry *)nt.p;
+  ctx->tvals = (double *)ntv.p;
+  nt.p = nullptr;
+  ntv.p = nullptr;
+  ctx->P.tables = ctx->tables;
+  ctx->P.tvals = ctx->tvals;
   ctx->P.logC = new_logC;
   return GRLX_OK;
 }
