@@ -496,3 +496,46 @@ def test_tables_grow_between_launches(grlx, kind):
     assert ei.value.code == grlx.capi.ERR_TABLE_FULL and r2.table_capacity() == 9
     r2.close()
     r.close()
+
+
+@pytest.mark.parametrize("family", ["acrobot_wide", "walker_wide", "cart_pole_ac_wide", "accumulating", "target_network", "qv", "advantage"])
+def test_other_kernel_families_under_poisoned_registers(grlx, monkeypatch, family):
+    """The same diagnostic (GRLX_POISON_REGISTERS) on one small case of every other kernel family, so
+    that a register-allocation accident in any of them shows up in the default suite and not only in the full poisoned run."""
+    from tests import configs
+    monkeypatch.setenv("GRLX_POISON_REGISTERS", "0x7ff80000")
+    n, trials = 9, 12
+    over, rpw, tables = {}, 4, 1
+    if family == "acrobot_wide":
+        make, rpw = configs.acrobot, 8
+    elif family == "walker_wide":
+        make, rpw, trials = configs.compass_walker, 8, 8
+    elif family == "cart_pole_ac_wide":
+        make, rpw, tables = configs.cart_pole_ac, 8, 2
+    elif family == "qv":
+        make, tables = configs.pendulum_qv, 2
+    else:
+        make = configs.pendulum
+        over = {"accumulating": dict(trace=2), "target_network": dict(target_interval=200, target_tau=0.5),
+                "advantage": dict(agent=grlx.capi.AGENT_ADVANTAGE, kappa=0.2)}[family]
+    cfg, spec = make(grlx, n, **{k: v for k, v in over.items() if k in ("agent", "kappa")})
+    for k, v in over.items():
+        if k != "agent":
+            setattr(cfg, k, v); setattr(spec, k, v)
+    cfg.replicas_per_wave = rpw
+    cfg.max_rows = trials + 1
+    seeds = np.arange(501, 501 + n)
+    r = grlx.Runner(cfg, seeds)
+    r.run(trials // 2); r.run(trials - trials // 2); r.sync()
+    rng = np.random.default_rng(13)
+    slots = rng.integers(0, 8388608, 800).astype(np.uint32)
+    for k in (0, 3, 8):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows, _ = e.run(trials)
+        assert_bit_equal(r.rows(k)[2], [x.reward for x in rows], f"{family}: returns of replica {k}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        assert_bit_equal(r.env_state(k), e.state(), f"{family}: env state of replica {k}")
+        for t in range(tables):
+            assert_bit_equal(r.weights(k, slots, t), e.weights(slots, t), f"{family}: table {t} of replica {k}")
+        e.close()
+    r.close()
