@@ -231,6 +231,11 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
   uint32_t status = RS.status, rows = RS.rows, inserted = 0;
 
   const Table tab = table_of(P, 0, r);
+  // the two fields the slot-creation path reads (start of the initialisation stream, loaded policy image): kept in registers
+  // instead of loaded behind a miss -- in the first few hundred trials most passes of a wave create a slot somewhere
+  ReplicaState RSc;
+  RSc.TL0 = RS.TL0;
+  RSc.lazy_base[0] = RS.lazy_base[0];
   UpdateParams up;
   up.out_min = N.lin.out_min;
   up.out_max = N.lin.out_max;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
         if (has_next)
         {
           bool shared_event = false;
-          table_get_finish<NA>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+          table_get_finish<NA>(tab, N.lin, RSc, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
                                [&](uint32_t mp) {
                                  // a weight evicted a moment ago and not stored yet: store it now, the finder reads it
                                  if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tab, mp, ev.val);
