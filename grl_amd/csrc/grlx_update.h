@@ -370,41 +370,56 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
       sh_mb[g * (NP * 16) + a * 16 + j] = lk[a].miss ? lk[a].bucket : 0xFFFFFFFFu;
       sh_ms[g * (NP * 16) + a * 16 + j] = slot[a];
       claims[a] = (uint32_t)((__ballot(lk[a].miss) >> (16 * g)) & 0xFFFFull);
-      w0[a] = 0;
       slow[a] = false;
-      if (lk[a].miss)
-      { // a loaded policy image replaces the drawn initial value (read here, on the rare path, so
-        // that the hot path carries no pointer for it)
-        const double *img = rs.lazy_base[table];
-        if constexpr (LDSJ)
-          w0[a] = img ? img[slot[a]] : lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
-        else
-          w0[a] = img ? img[slot[a]] : lazy_weight(rs.TL0, lp, slot[a]);
+    }
+    // the initial weights of all NP slots in straight-line code, needed or not: their jump-ahead chains (four dependent table
+    // reads each) then overlap instead of running one after the other under NP branches.  A loaded policy image replaces the draw.
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+    {
+      if constexpr (LDSJ)
+        w0[a] = lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
+      else
+        w0[a] = lazy_weight(rs.TL0, lp, slot[a]);
+    }
+    {
+      const double *img = rs.lazy_base[table];
+      if (rarely(img != nullptr))
+      {
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+          if (lk[a].miss) w0[a] = img[slot[a]];
       }
     }
     wave_sync();
+    // one walk over the claims of my group serves all my NP lookups: an earlier claimant of the same bucket with another
+    // slot moves me one empty way on, the same slot claimed twice goes to the serialised path
+    uint32_t rank[NP];
+    bool dup[NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a) { rank[a] = 0u; dup[a] = false; }
+#pragma unroll
+    for (int a2 = 0; a2 < NP; ++a2)
+      for (uint32_t mm = claims[a2]; mm != 0u; mm &= mm - 1u)
+      { // only the (index, tiling) pairs that actually claim something
+        const int k = a2 * 16 + __builtin_ctz(mm);
+        const uint32_t ob = sh_mb[g * (NP * 16) + k], os = sh_ms[g * (NP * 16) + k];
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+        {
+          const int me = a * 16 + j;
+          const bool same_bucket = lk[a].miss && ob == lk[a].bucket && k != me;
+          dup[a] = dup[a] || (same_bucket && os == slot[a]);
+          rank[a] += (same_bucket && os != slot[a] && k < me) ? 1u : 0u;
+        }
+      }
 #pragma unroll
     for (int a = 0; a < NP; ++a)
       if (lk[a].miss)
       {
-        const int me = a * 16 + j;
-        uint32_t rank = 0;
-        bool dup = false;
-#pragma unroll
-        for (int a2 = 0; a2 < NP; ++a2)
-          for (uint32_t mm = claims[a2]; mm != 0u; mm &= mm - 1u)
-          { // only the (index, tiling) pairs that actually claim something
-            const int k = a2 * 16 + __builtin_ctz(mm);
-            const uint32_t ob = sh_mb[g * (NP * 16) + k], os = sh_ms[g * (NP * 16) + k];
-            if (ob == lk[a].bucket && k != me)
-            {
-              if (os == slot[a]) dup = true;
-              else if (k < me) rank++;
-            }
-          }
         uint32_t e = lk[a].empty;
-        for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;      // drop the ways taken by earlier claimants
-        if (dup || e == 0u)
+        for (uint32_t c = 0; c < rank[a]; ++c) e &= e - 1u;   // drop the ways taken by earlier claimants
+        if (dup[a] || e == 0u)
           slow[a] = true;
         else
         {
@@ -416,6 +431,10 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
         }
       }
     wave_sync();
+    bool anyslow = false;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) anyslow = anyslow || slow[a];
+    if (rarely(__any(anyslow)))
 #pragma unroll
     for (int a = 0; a < NP; ++a)
       if (rarely(__any(slow[a])))

@@ -10,7 +10,7 @@ import grl_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 11
 logc = int(sys.argv[3]) if len(sys.argv) > 3 else 17
-cfg = grl_amd.pendulum_sarsa_config(n, max_rows=64, table_log2_capacity=logc)
+cfg = grl_amd.pendulum_sarsa_config(n, max_rows=512, table_log2_capacity=logc)
 r = grl_amd.Runner(cfg, np.arange(1, n + 1))
 warm = int(sys.argv[4]) if len(sys.argv) > 4 else 33
 r.run(warm); r.sync()                     # warm tables
