@@ -23,6 +23,7 @@ __device__ __forceinline__ double lane_fetch(double v, int src) { return __shfl(
 // dynamics/pendulum + task/pendulum/swingup (pendulum.cpp:40-145)
 template <> struct Env<GRLX_ENV_PENDULUM> {
   static constexpr int S = 3, D = 2;
+  static constexpr bool kAbsorbing = false;      // can observe() report an absorbing state (terminal = 2)?
   // pendulum.cpp:40-49, 55-68; the constants are held in registers by the caller (rk4_step)
   struct Consts { SinConsts k; double invJ, mgl, b, kkr, kr; };
   template <bool PIN> __device__ static __forceinline__ Consts consts()
@@ -78,6 +79,7 @@ template <> struct Env<GRLX_ENV_PENDULUM> {
 // thetad1, thetad2, time].  No reference test pins it: parity is against the oracle only.
 template <> struct Env<GRLX_ENV_ACROBOT> {
   static constexpr int S = 5, D = 4;
+  static constexpr bool kAbsorbing = true;      // can observe() report an absorbing state (terminal = 2)?
   using Consts = SinConsts;                     // held in registers across the integration loop
   template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
   // Equations of motion of dynamics/acrobot (acrobot.cpp:48-79).  Unit link masses, lengths and inertias fold the
@@ -179,6 +181,7 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
 // state = [x, theta, xd, thetad, time].  parity unpinned by reference tests.
 template <> struct Env<GRLX_ENV_CART_POLE> {
   static constexpr int S = 5, D = 4;
+  static constexpr bool kAbsorbing = true;      // can observe() report an absorbing state (terminal = 2)?
   using Consts = SinConsts;                     // held in registers across the integration loop
   template <bool PIN> __device__ static __forceinline__ Consts consts() { return sin_consts<PIN>(); }
   __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd)
@@ -280,6 +283,7 @@ template <> struct Env<GRLX_ENV_CART_POLE_BALANCING> : Env<GRLX_ENV_CART_POLE> {
 // state vector (compass_walker.h:40-42).  parity unpinned by reference tests.
 template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
   static constexpr int S = 11, D = 5;
+  static constexpr bool kAbsorbing = true;      // can observe() report an absorbing state (terminal = 2)?
   static constexpr bool kCustomModel = true;
   enum { SLA = 0, HA, SLAR, HAR, CHANGED, SFX, LASTHIPX, HIPVEL, STEPDIST, TIME, TIMEOUT };
   struct St { double sla, slar, ha, har, sfx; };

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
         }
-        has_next = first || terminal != 2;
+        has_next = first || !Env<ENV>::kAbsorbing || terminal != 2;      // (a compile-time `true` for the pendulum)
         update = !first && !test;                                          // a TD update follows
         DIAG_STAMP(1)
 
