@@ -22,6 +22,26 @@ namespace grlx {
 //    slot that becomes shared is written back first (on_share).
 constexpr int kAccTrace = 20;
 
+constexpr DevParams make_spec_pendulum_acc(int agent)
+{
+  DevParams P = make_spec_pendulum_tc();
+  P.trace_kind = GRLX_TRACE_ACCUMULATING;
+  P.agent = agent;
+  P.end_stop_penalty = 1;                              // fields this kernel does not read, as grlx_config_pendulum_sarsa leaves them
+  P.slope_angle = 0.004; P.initial_state_variation = 0.2; P.negative_reward = -100.0;
+  P.control_step = 0.03;
+  P.walker_dt = 1.0E-6 * (double)(uint64_t)30000 / 5;
+  P.action_min = -3; P.action_max = 3;
+  return P;
+}
+__device__ const DevParams d_spec_pendulum_acc = make_spec_pendulum_acc(GRLX_AGENT_SARSA);     // the agent is a template constant
+template <int AGENT>
+struct SpecPendulumAcc {
+  __device__ static __forceinline__ int agent(const DevParams &) { return AGENT; }
+  static bool matches(const DevParams &P) { constexpr DevParams C = make_spec_pendulum_acc(AGENT); return spec_numeric_equal(P, C); }
+  __device__ static __forceinline__ const DevParams &numeric(const DevParams &) { return d_spec_pendulum_acc; }
+};
+
 // f() in the flagged lanes of every 16-lane group, one lane of a group at a time, ascending
 template <typename F>
 __device__ __forceinline__ void serial_lanes(bool flag, F f)
@@ -43,9 +63,12 @@ __device__ __forceinline__ void serial_lanes(bool flag, F f)
   }
 }
 
-template <int ENV, int NA>
+// SPEC: SpecNone, or the compile-time parameter block of the reference's cfg/pendulum/{sarsa,q}_tc.yaml family with the
+// accumulating trace (SpecPendulumAcc; see SpecPendulumTcA in grlx_rollout.h)
+template <int ENV, int NA, typename SPEC = SpecNone>
 __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_trials)
 {
+  const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
   __shared__ double   sh_w[(NA + 1) * 16 * 4];
   __shared__ uint32_t sh_mb[4 * NA * 16];
@@ -75,17 +98,17 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
   uint32_t status = RS.status, rows = RS.rows, inserted = 0;
 
   const Table tab = table_of(P, 0, r);
-  const double out_min = P.lin.out_min, out_max = P.lin.out_max;
-  const bool limit = P.lin.limit != 0;
-  const double ee = P.gl, cut = 0.0001;
+  const double out_min = N.lin.out_min, out_max = N.lin.out_max;
+  const bool limit = N.lin.limit != 0;
+  const double ee = N.gl, cut = 0.0001;
 
   double acts[NA];
 #pragma unroll
-  for (int a = 0; a < NA; ++a) acts[a] = P.actions[a];
+  for (int a = 0; a < NA; ++a) acts[a] = N.actions[a];
   uint32_t key_act[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
-    key_act[a] = in_reg(murmur_key(tile_coord<T>(P.tile, D, tile_quant(P.tile, D, P.actions[a]), j)));
+    key_act[a] = in_reg(murmur_key(tile_coord<T>(N.tile, D, tile_quant(N.tile, D, N.actions[a]), j)));
   const uint32_t key_j = in_reg(murmur_key(j));
 
   // the trace of this lane's tiling: positions newest first, bit e of tsh = entry e is a slot shared between tilings
@@ -107,15 +130,15 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
 
   for (int trial = 0; trial < n_trials; ++trial, ++tt)
   {
-    const int ti = P.test_interval;
+    const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
     double obs[D], reward = 0, total_reward = 0;
     int terminal = 0;
     bool running = live;
     if (live)
     {
-      Env<ENV>::start(P, test, TL, G, x);
-      Env<ENV>::observe(P, x, obs);
+      Env<ENV>::start(N, test, TL, G, x);
+      Env<ENV>::observe(N, x, obs);
     }
     double time = 0, action = 0;
     int action_index = 0;
@@ -138,7 +161,7 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
       {
         if (!first)
         {
-          env_step<ENV>(P, x, action, obs, reward, terminal, status);
+          env_step<ENV>(N, x, action, obs, reward, terminal, status);
           total_reward += reward;
           time += 1;
         }
@@ -155,20 +178,20 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           uint32_t hpre = 449u ^ (uint32_t)(D + 2);
 #pragma unroll
           for (int i = 0; i < D; ++i)
-            hpre = murmur_mix(hpre, tile_coord<T>(P.tile, i, tile_quant(P.tile, i, obs[i]), j));
+            hpre = murmur_mix(hpre, tile_coord<T>(N.tile, i, tile_quant(N.tile, i, obs[i]), j));
           const uint32_t hpm = hpre * 0x5bd1e995u;
 #pragma unroll
           for (int a = 0; a < NA; ++a)
           {
             uint32_t h = murmur_absorb(hpm ^ key_act[a], key_j);
-            const uint32_t hm = murmur_final(h), mem = (uint32_t)P.tile.memory;
+            const uint32_t hm = murmur_final(h), mem = (uint32_t)N.tile.memory;
             slot[a] = ((mem & (mem - 1u)) == 0u) ? (hm & (mem - 1u)) : (hm % mem);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         bool shared_event = false;
         if (has_next)
-          table_get<NA>(tab, P.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
+          table_get<NA>(tab, N.lin, RS, 0, slot, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, inserted,
                         [&](uint32_t mp) { // a slot became shared: its cached value goes to the table (the finder reads it), and
                           // every entry that refers to it is updated serially, on the table, from now on
                           if (p_pos == mp) p_sh = true;
@@ -231,10 +254,10 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
             a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
           else
           {
-            if (time == 0.) eps_decay = fmax(eps_decay * P.decay_rate, P.decay_min);
+            if (time == 0.) eps_decay = fmax(eps_decay * N.decay_rate, N.decay_min);
             S1 = lcg_next(S1);
             const double rnd = lcg_double(S1);
-            if (rnd < eps_decay * P.epsilon)
+            if (rnd < eps_decay * N.epsilon)
             {
               G = lcg_next(G);
               a_next = (int)(lcg_long(G) % (uint32_t)NA);
@@ -251,11 +274,11 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
           double target = reward;
           if (has_next)
           {
-            if (P.agent == GRLX_AGENT_SARSA)
-              target += P.gamma * pick<double, NA>(q, a_next);
-            else if (P.agent == GRLX_AGENT_EXPECTED_SARSA)
+            if (SPEC::agent(P) == GRLX_AGENT_SARSA)
+              target += N.gamma * pick<double, NA>(q, a_next);
+            else if (SPEC::agent(P) == GRLX_AGENT_EXPECTED_SARSA)
             {
-              const double de = eps_decay * P.epsilon;
+              const double de = eps_decay * N.epsilon;
               double v = 0;
 #pragma unroll
               for (int kk = 0; kk < NA; ++kk)
@@ -265,19 +288,19 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
                 d += de / NA;
                 v += q[kk] * d;
               }
-              target += P.gamma * v;
+              target += N.gamma * v;
             }
             else
             {
               double v = -__builtin_inf();
 #pragma unroll
               for (int kk = 0; kk < NA; ++kk) v = fmax(v, q[kk]);
-              target += P.gamma * v;
+              target += N.gamma * v;
             }
           }
           delta = target - qsa;
-          const double dW = P.alpha * (target - qsa);
-          const double dT = P.alpha * delta;
+          const double dW = N.alpha * (target - qsa);
+          const double dT = N.alpha * delta;
           // write(p, target, alpha): every index of p, in tiling order where tilings share the slot.  p is about to enter the
           // trace as its newest entry, so its new weight stays in the cache (unless the slot is shared between tilings)
           const double newp = limit ? clampd(wp + dW, out_min, out_max) : wp + dW;
@@ -479,6 +502,19 @@ hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stre
 {
   if (variant) *variant = GRLX_KERNEL_IN_PLACE;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (!P.no_specialisation && !(P.tap_replica >= 0 && P.tap_capacity > 0))
+  {
+#define GRLX_LAUNCH_ACC_SPEC(AGENT)                                                                                              \
+    if (SpecPendulumAcc<AGENT>::matches(P))                                                                                      \
+    {                                                                                                                            \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                                           \
+      hipLaunchKernelGGL((rollout_acc_kernel<GRLX_ENV_PENDULUM, 3, SpecPendulumAcc<AGENT>>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                                  \
+    }
+    GRLX_LAUNCH_ACC_SPEC(GRLX_AGENT_SARSA)
+    GRLX_LAUNCH_ACC_SPEC(GRLX_AGENT_Q)
+#undef GRLX_LAUNCH_ACC_SPEC
+  }
   if (P.env == GRLX_ENV_PENDULUM && P.A == 3)
     hipLaunchKernelGGL((rollout_acc_kernel<GRLX_ENV_PENDULUM, 3>), dim3(waves), dim3(64), 0, stream, P, n_trials);
   else if (P.env == GRLX_ENV_ACROBOT && P.A == 3)

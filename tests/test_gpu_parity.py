@@ -396,6 +396,28 @@ def test_accumulating_trace_bit_exact(grlx, agent):
     r.close()
 
 
+@pytest.mark.parametrize("agent", [0, 1])
+def test_specialised_accumulating_trace_equals_generic_and_oracle(grlx, agent):
+    """cfg/pendulum/{sarsa,q}_tc.yaml with trace/enumerated/accumulating runs the compile-time instantiation
+    (SpecPendulumAcc); force_generic the run-time-parameter one: rows, RNG, weights of both equal the oracle's."""
+    seeds, trials = [71, 72, 73, 74, 75, 76], 23
+    rng = np.random.default_rng(4)
+    slots = rng.integers(0, 8388608, 1500).astype(np.uint32)
+    for force, want in ((0, 2), (1, 3)):
+        cfg = grlx.pendulum_sarsa_config(len(seeds), agent=agent, trace=2, force_generic=force)
+        r = grlx.Runner(cfg, seeds)
+        r.run(12); r.run(11); r.sync()
+        assert r.last_kernel() == want
+        for k, seed in enumerate(seeds):
+            e = ob.Experiment(ob.pendulum_sarsa_spec(agent=agent, trace=2), seed=seed)
+            rows, _ = e.run(trials)
+            assert_bit_equal(r.rows(k)[2], [x.reward for x in rows], f"returns of seed {seed} (force_generic {force})")
+            assert list(r.rng(k))[:3] == list(e.rng())[:3]
+            assert_bit_equal(r.weights(k, slots), e.weights(slots), f"weights of seed {seed} (force_generic {force})")
+            e.close()
+        r.close()
+
+
 def test_deployer_accumulating_trace(grlx, tmp_path):
     """grlxd on the golden yaml with trace/enumerated/accumulating instead of the replacing trace: rows = oracle's."""
     import subprocess
