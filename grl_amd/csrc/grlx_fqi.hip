@@ -283,20 +283,33 @@ __global__ __launch_bounds__(64) void fqi_grad_kernel(FqiParams F)
   }
 }
 
-// one epoch, part 2: level 3 of the tree (chunk sums strided over 64 lanes, wave reduction) and the RPROP step of
-// ANNRepresentation::finalize (ann.cpp:186-192, 199); one wave per parameter
-__global__ __launch_bounds__(64) void fqi_step_kernel(FqiParams F)
+// one epoch, part 2: level 3 of the tree and the RPROP step of ANNRepresentation::finalize (ann.cpp:186-192, 199).
+// Level 3 as specified (oracle/fqi.c): 64 partial sums per parameter, the L-th over the chunks L, L+64, ... in this order, then
+// the tree v[L] += v[L + off], off = 32 .. 1.  One block = 16 parameters x the 64 partial sums: the 16 threads of a row read 16
+// consecutive parameters of one chunk (the chunk sums are stored [chunk][parameter]), so a row is one 128-byte request instead
+// of the 64 separate lines that one wave per parameter used to touch per load (36 -> 9 us per epoch at 16 x 200 000 samples).
+constexpr int kStepCols = 16;
+__global__ __launch_bounds__(kStepCols * 64) void fqi_step_kernel(FqiParams F)
 {
-  const int r = blockIdx.y, k = blockIdx.x, lane = threadIdx.x;
+  __shared__ double sh[64][kStepCols + 1];
+  const int r = blockIdx.y, kx = threadIdx.x, L = threadIdx.y;
+  const int k = blockIdx.x * kStepCols + kx;
   FqiRep &rep = F.rep[r];
-  if (rep.done) return;
+  if (rep.done) return;                                                      // uniform over the block
   const int64_t chunks = (rep.n + 63) / 64;
   const double *part = F.partial + (size_t)r * (size_t)F.chunks_cap * (size_t)(F.P + 1);
   double v = 0.;
-  for (int64_t c = lane; c < chunks; c += 64) v += part[(size_t)c * (size_t)(F.P + 1) + (size_t)k];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += shfl_down_f64(v, off);
-  if (lane != 0) return;
+  if (k <= F.P)
+    for (int64_t c = L; c < chunks; c += 64) v += part[(size_t)c * (size_t)(F.P + 1) + (size_t)k];
+  sh[L][kx] = v;
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    if (L < off) sh[L][kx] += sh[L + off][kx];
+    __syncthreads();
+  }
+  if (L != 0 || k > F.P) return;
+  v = sh[0][kx];
   if (k == F.P) { rep.last_error = v / (double)rep.n; return; }
   double *net = F.net + (size_t)r * 4 * F.P;
   const double Delta = 0. + v;                                               // Delta was zero before this epoch (ann.cpp:199)
@@ -548,6 +561,8 @@ int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
   const FqiParams &F = ctx->F;
   const int n_after = (ctx->batches_run + 1) * F.batch_size;
   const int chunks = (n_after + 255) / 256, gchunks = (n_after + 63) / 64;
+  // (the epochs of one iteration captured into a HIP graph and replayed were measured: no gain -- 337 us per epoch either way at
+  // 16 x 200 000 samples, of which the two kernels account for 241; the rest is dispatch and drain of two dependent launches)
   hipLaunchKernelGGL(fqi_generate_kernel, dim3((F.batch_size + 255) / 256, F.R), dim3(256), 0, stream, F);
   hipLaunchKernelGGL(fqi_batch_begin_kernel, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
   for (int ii = 0; ii < ctx->cfg.iterations; ++ii)
@@ -557,7 +572,7 @@ int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
     for (int e = 0; e < ctx->cfg.epochs; ++e)
     {
       hipLaunchKernelGGL(fqi_grad_kernel<20>, dim3(gchunks, F.R), dim3(64), 0, stream, F);
-      hipLaunchKernelGGL(fqi_step_kernel, dim3(F.P + 1, F.R), dim3(64), 0, stream, F);
+      hipLaunchKernelGGL(fqi_step_kernel, dim3((F.P + 1 + kStepCols - 1) / kStepCols, F.R), dim3(kStepCols, 64), 0, stream, F);
     }
   }
   hipLaunchKernelGGL(fqi_test_kernel<20>, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
