@@ -87,6 +87,61 @@ __device__ __forceinline__ uint64_t lcg_jump_lds(const uint64_t *sh_jump, uint64
   return x;
 }
 
+// The wide kernels have no 16 KB of LDS to spare (their parked state already takes 24 KB of the 40 KB a wave may use with four
+// waves per CU): a table of 6-bit windows is 6 KB -- six multiply-adds instead of four, all reads from LDS instead of eight from
+// device memory.  The maps are powers of one affine map, so any window width gives the same x.
+struct JumpTable6 { uint64_t a[6][64], c[6][64]; };
+constexpr JumpTable6 make_jump_table6()
+{
+  JumpTable6 t{};
+  uint64_t sa = kLcgA, sc = kLcgC;                 // map of 64^w draws
+  for (int w = 0; w < 6; ++w)
+  {
+    uint64_t a = 1, c = 0;
+    for (int b = 0; b < 64; ++b)
+    {
+      t.a[w][b] = a;
+      t.c[w][b] = c;
+      c = (sa * c + sc) & kMask48;
+      a = (sa * a) & kMask48;
+    }
+    sa = a;
+    sc = c;
+  }
+  return t;
+}
+__device__ const JumpTable6 d_jump6 = make_jump_table6();
+constexpr int kJump6Words = 2 * 6 * 64;
+
+__device__ __forceinline__ void jump_table6_to_lds(uint64_t *sh_jump6)
+{
+  const uint64_t *src = reinterpret_cast<const uint64_t *>(&d_jump6);
+  for (int i = threadIdx.x; i < kJump6Words; i += blockDim.x) sh_jump6[i] = src[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ uint64_t lcg_jump_lds6(const uint64_t *sh_jump6, uint64_t x, uint64_t n)
+{
+  uint64_t a[6], c[6];
+#pragma unroll
+  for (int w = 0; w < 6; ++w)
+  {
+    const uint32_t b = (uint32_t)(n >> (6 * w)) & 63u;
+    a[w] = sh_jump6[w * 64 + b];
+    c[w] = sh_jump6[6 * 64 + w * 64 + b];
+  }
+#pragma unroll
+  for (int w = 0; w < 6; ++w) x = (a[w] * x + c[w]) & kMask48;
+  if (n >> 36) x = lcg_step_pow2(x, (n >> 36) << 36);
+  return x;
+}
+
+__device__ __forceinline__ double lazy_weight_lds6(const uint64_t *sh_jump6, uint64_t tl0, const LinearParams &lp, uint32_t slot)
+{
+  uint64_t x = lcg_next(lcg_jump_lds6(sh_jump6, tl0, lp.draws_before + (uint64_t)slot));
+  return lp.init_min + lcg_double(x) * lp.init_range;
+}
+
 // value the reference's dense initialisation gives `slot` (linear.cpp:117-120:
 // params_[ii] = rand->getUniform(init_min, init_max) in index order)
 __device__ inline double lazy_weight(uint64_t tl0, const LinearParams &lp, uint32_t slot)

@@ -37,10 +37,12 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   __shared__ int      sh_term[R];
   __shared__ uint32_t sh_step[R];
   __shared__ uint32_t sh_est[R];
+  __shared__ uint64_t sh_jump6[kJump6Words];   // LCG jump table, 6-bit windows (lazy weight initialisation)
   __shared__ uint32_t sh_rid[R];               // replica in slot q (kNoReplica: none)
   __shared__ uint32_t sh_xwb[R];               // replica the slot has just retired: its environment state is still in the env lanes
   constexpr uint32_t kNoReplica = 0xFFFFFFFFu;
 
+  jump_table6_to_lds(sh_jump6);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   const unsigned long long gmask = 0xFFFFull << (16 * g);
@@ -335,13 +337,13 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         bool shA[1] = {false}, shC[1] = {false};
         if (has_next)
         {
-          table_get_finish<1, false>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+          table_get_finish<1, 2>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump6,
                                      c.status, c.inserted2, [&](uint32_t mp) { if (c.ap_pos == mp) c.ap_sh = true; });
         }
         if (need_critic)
         {
           bool shared_event = false;
-          table_get_finish<1, false>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+          table_get_finish<1, 2>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump6,
                                      c.status, c.inserted,
                                      [&](uint32_t mp) {
                                        if (ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   __shared__ uint32_t sh_mb[4 * NA * 16];
   __shared__ uint32_t sh_ms[4 * NA * 16];
   __shared__ uint32_t sh_mail[4];
+  __shared__ uint64_t sh_jump6[kJump6Words];        // LCG jump table, 6-bit windows (lazy weight initialisation)
   __shared__ double   sh_res[4 * 16];
   __shared__ uint4    sh_ctx[B * kWideQuads * 64];      // parked lane state
   __shared__ uint32_t sh_ins[B * 64];
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   __shared__ uint32_t sh_step[R];                       // 1: the replica takes an environment step in the next pass
   __shared__ uint32_t sh_est[R];                        // status bits raised by the environment role
 
+  jump_table6_to_lds(sh_jump6);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   const unsigned long long gmask = 0xFFFFull << (16 * g);
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
           if (has_next)
           {
             bool shared_event = false;
-            table_get_finish<NA, false>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, (const uint64_t *)nullptr,
+            table_get_finish<NA, 2>(tab, N.lin, RS, 0, slot, lk, br, pos, w, sh, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump6,
                                  c.status, c.inserted,
                                  [&](uint32_t mp) {
                                    if (ev.pos != kInvalidPos && ev.pos == mp) value_store(tab, mp, ev.val);

@@ -341,9 +341,9 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
 // resolves new cross-tiling sharing events.  sh[i]: the slot is shared between tilings.
 // on_share(mp): called in every lane of the group for each slot position that just became shared.
 // table_get_finish: the part after the loads of table_issue (lk, br).
-// LDSJ: the LCG jump table is staged in LDS (sh_jump); false: read from device memory (the wide kernels, whose LDS
-// holds parked state instead; sh_jump is ignored)
-template <int NP, bool LDSJ = true, typename OnShare>
+// LDSJ: where the LCG jump table is read from: 1 = the byte-window table staged in LDS (sh_jump, 16 KB), 0 = device memory
+// (sh_jump ignored), 2 = the 6-bit-window table staged in LDS (sh_jump, 6 KB: the wide kernels, whose LDS holds parked state)
+template <int NP, int LDSJ = 1, typename OnShare>
 __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearParams &lp, const ReplicaState &rs, int table, const uint32_t (&slot)[NP],
                                                  Lookup (&lk)[NP], const BucketRegs (&br)[NP],
                                                  uint32_t (&pos)[NP], double (&w)[NP], bool (&sh)[NP], int g, int j, unsigned long long gmask,
@@ -377,8 +377,10 @@ __device__ __forceinline__ void table_get_finish(const Table &tab, const LinearP
 #pragma unroll
     for (int a = 0; a < NP; ++a)
     {
-      if constexpr (LDSJ)
+      if constexpr (LDSJ == 1)
         w0[a] = lazy_weight_lds(sh_jump, rs.TL0, lp, slot[a]);
+      else if constexpr (LDSJ == 2)
+        w0[a] = lazy_weight_lds6(sh_jump, rs.TL0, lp, slot[a]);
       else
         w0[a] = lazy_weight(rs.TL0, lp, slot[a]);
     }
