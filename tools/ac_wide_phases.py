@@ -17,7 +17,7 @@ waves = min((n + 7) // 8, 1024)
 d = r.read_diag().astype(np.float64)[:waves]
 steps = (l1 - l0) + (t1s - t0s)
 passes = d[:, 2].sum()
-names = {0: "environment", 1: "table phase (all sub-batches)", 3: "  unpark + hash + issue loads", 4: "  deferred critic update", 5: "  wait + actor finish", 6: "  critic finish", 7: "  reconcile + forward"}
+names = {0: "environment", 1: "table phase (all sub-batches)", 3: "  unpark + hash + issue loads", 4: "  deferred critic update", 5: "  finish lookups, reconcile", 6: "  sums, policy, actor update", 7: "  between trials + park"}
 ins = sum(r.table_load(k) for k in range(0, n, 257)) / len(range(0, n, 257))
 print("mean critic-table slots of sampled replicas after", 2 * trials, "trials:", ins)
 print(f"{n} replicas: {steps/dt/1e6:.1f} M env-steps/s (stamped build); passes per wave {passes/len(d):.0f}; replica-steps per wave-pass {steps/passes:.2f}")
