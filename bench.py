@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the fused HIP rollout path (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): pendulum swing-up SARSA(lambda) tile coding,
+Headline workload (BASELINE.json configs[1]): pendulum swing-up SARSA(lambda) tile coding,
 4096 independent-seed replicas per GPU (replica r seeded srand48(1+r), weights
 U(0,1) from the replica's own LCG stream -- synthetic inputs only).  One "step" is
 one launch of the hot path: every replica advances by 11 trials (10 learning
 episodes + 1 greedy test episode = 1100 env-steps).  Replica state, weight tables
 and RNG streams are resident in HBM before the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  Replicas shard across ranks with no data-path
-collective (weak scaling: 4096 replicas per GPU); the only collective is the final
-RCCL all-reduce of the learning-curve statistics [rows][3], inside the timed region.
+Prints ONE JSON line on rank 0.  EVERY workload (= every configuration of BASELINE.json) runs on any number of
+ranks: replicas shard across ranks with no data-path collective (weak scaling, a fixed number of replicas per GPU,
+grl_amd.parallel.partition); the only collective of a workload is the final RCCL all-reduce of its learning-curve
+statistics [rows][3], inside the timed region.
+
+  --workload pendulum_sarsa (default)   the headline line; the other workloads follow under "secondary", each sharded
+                                        and timed the same way on the same ranks (--no-secondary / --no-fqi skip them)
+  --workload cart_pole_ac               BASELINE configs[2]: 16384 replicas per GPU
+  --workload acrobot_walker             BASELINE configs[3]: 8192 rollouts per GPU = 4096 acrobot + 4096 compass walker,
+                                        both halves on every rank, two contexts on two HIP streams
+  --workload acrobot_q | compass_walker_q   one half of configs[3] alone, 8192 replicas per GPU
+  --workload pendulum_fqi_ann           BASELINE configs[4]: replicas only (16 independent-seed batch experiments per GPU)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,45 +38,47 @@ if ROOT not in sys.path:
 REPLICAS_PER_GPU = 4096
 TRIALS_PER_STEP = 11                      # test_interval 10 => 10 learning + 1 test episode
 STEPS_PER_EPISODE = 100                   # control step 0.03 s, timeout 2.99 s
-LEARN_STEPS_PER_STEP = 10 * STEPS_PER_EPISODE
-TEST_STEPS_PER_STEP = 1 * STEPS_PER_EPISODE
-# Algorithmic bytes (SURVEY.md section 8d / BASELINE.md section 5, restated in DESIGN.md):
-BYTES_PER_LEARN_STEP = 2228               # 768 B of weight reads + 16 B x 91.2 read-modify-writes
-BYTES_PER_TEST_STEP = 384                 # A*T 8-byte reads
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+F64_PEAK_TFLOPS = 78.6                    # MI355X f64 vector = matrix rate: half the 157.3 TF f32 vector peak of MI355X_MICROARCH.md
 
+# Algorithmic bytes per env-step: 8 B per weight the algorithm reads + 16 B per read-modify-write.
+#   headline: the declared figure of SURVEY.md 8(d) / BASELINE.md 5 (2228 B per learning step = 768 B of reads + 16 B x 91.2
+#   read-modify-writes, the 20000-trial mean; 384 B per test step);
+#   every other graph: counted by the oracle on the trials this file times (tools/algorithmic_bytes.py, mean of seeds 1-4,
+#   libm arithmetic; the headline's own count in that regime is listed for comparison -- early learning updates longer traces).
+#   The default run recounts them live in its cpu_baseline leg (same oracle run) and reports which figure it used.
+ALGORITHMIC_BYTES = {
+    "pendulum_sarsa": dict(learn=2228.0, test=384.0, reads_per_test=48, oracle_bench_regime=2629.8),
+    "cart_pole_ac": dict(learn=3226.3, test=128.0, reads_per_test=16),
+    "acrobot_q": dict(learn=2113.3, test=384.0, reads_per_test=48),
+    "compass_walker_q": dict(learn=3434.8, test=384.0, reads_per_test=48),
+}
 
-def measured_pmc(key: str, n_replicas: int, trials_per_launch: int):
-    """What the PMC passes committed under profiles/ measured for this workload (rocprofv3 cannot run inside
-    this process): HBM-side bytes per launch and the issue share of the wave cycles.  Only valid for the
-    configuration it was measured on, else (None, None).  Written by tools/pmc_to_json.py."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f)["workloads"][key]
-        if t.get("replicas") == n_replicas and t.get("trials_per_launch") == trials_per_launch:
-            return float(t["hbm_bytes_per_launch"]), t.get("issue")
-    except (OSError, ValueError, KeyError, TypeError):
-        pass
-    return None, None
+# experiment graph -> how one GPU runs it
+GRAPHS = {
+    "pendulum_sarsa": dict(trials=TRIALS_PER_STEP, want_kernel=2, pmc_key="pendulum_sarsa",
+                           kernel="rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update>",
+                           text="pendulum swing-up SARSA(lambda) hashed tile coding (cfg/pendulum/sarsa_tc.yaml semantics)"),
+    "cart_pole_ac": dict(trials=11, want_kernel=2, pmc_key="cart_pole_ac",
+                         kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>",
+                         text="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml)"),
+    "acrobot_q": dict(trials=32, want_kernel=2, pmc_key="acrobot_q",
+                      kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ, deferred update>",
+                      text="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml)"),
+    "compass_walker_q": dict(trials=32, want_kernel=2, pmc_key="compass_walker_q",
+                             kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, SpecWalkerQ, deferred update>",
+                             text="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml)"),
+}
 
-
-# ---- the other single-GPU configurations of BASELINE.json (configs[2], per-GPU share of configs[3]) ------------
-# Reported under "secondary" of the same JSON line, N = 1 only.  Algorithmic bytes per step: the figure of
-# SURVEY.md 8(d) for the Q agents (3 actions, 16 tilings: 768 B of reads + 16 B x 91.2 read-modify-writes = 2228 B per
-# learning step, 384 B per test step); actor-critic (DESIGN.md 4.1b): 512 B of reads + 16 B x (16 + 16 + 75) = 2224 B
-# per learning step, 128 B per test step.
-SECONDARY = [
-    dict(key="cart_pole_ac", replicas=16384, trials=11, steps=5, warmup=1, bytes_learn=2224, bytes_test=128,
-         workload="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml), 16384 replicas, 11 trials (2200 env-steps) per replica per step",
-         kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>", want_kernel=2),
-    dict(key="acrobot_q", replicas=8192, trials=32, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
-         workload="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 32 trials per replica per step",
-         kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ, deferred update>", want_kernel=2),
-    dict(key="compass_walker_q", replicas=8192, trials=32, steps=5, warmup=1, bytes_learn=2228, bytes_test=384,
-         workload="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml), 8192 replicas (per-GPU share of BASELINE configs[3]), 32 trials per replica per step",
-         kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, SpecWalkerQ, deferred update>", want_kernel=2),
-]
-
+# workload -> replicas per GPU, default launches, which graph's kernel the roofline object describes
+WORKLOADS = {
+    "pendulum_sarsa": dict(replicas=REPLICAS_PER_GPU, steps=20, warmup=3, dominant="pendulum_sarsa", baseline_config=1),
+    "cart_pole_ac": dict(replicas=16384, steps=5, warmup=1, dominant="cart_pole_ac", baseline_config=2),
+    "acrobot_q": dict(replicas=8192, steps=5, warmup=1, dominant="acrobot_q", baseline_config=3),
+    "compass_walker_q": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
+    "acrobot_walker": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
+}
+SECONDARY_ORDER = ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker"]
 
 # The batch path (BASELINE.json configs[4], per-GPU share): tests/pendulum-fqi-ann.yaml scaled to 100,000 transitions per
 # batch, 16 independent-seed replicas per GPU.  A step = one batch (100,000 new transitions, FQIPredictor::rebuild over the
@@ -76,79 +88,86 @@ SECONDARY = [
 # + 4*20 (logistic) + 3*20 (hidden deltas) + (3+1)*20 + 20 (gradient products) + 2 = 444.
 FQI = dict(key="pendulum_fqi_ann", replicas=16, batch_size=100000, iterations=10, epochs=500, flops_per_sample_epoch=444,
            workload="pendulum fitted Q-iteration, 3-20-1 logistic network trained by RPROP (tests/pendulum-fqi-ann.yaml scaled: 100000 transitions per batch, "
-                    "10 iterations x 500 epochs), 16 independent-seed replicas; step = the second batch (rebuild over 200000 stored transitions)",
-           kernel="fqi_grad_kernel<20> (+ fqi_step_kernel, fqi_targets_kernel<20>)")
-F64_PEAK_TFLOPS = 78.6                    # MI355X f64 vector = matrix rate: half the 157.3 TF f32 vector peak of MI355X_MICROARCH.md
+                    "10 iterations x 500 epochs), 16 independent-seed replicas per GPU; step = the second batch (rebuild over 200000 stored transitions)",
+           kernel="fqi_epoch_kernel<20> (+ fqi_targets_kernel<20>)")
 
 
-def run_fqi(torch, no_cpu_baseline, replicas=None, batch_size=None, epochs=None):
-    import numpy as np
+def csrc_hash() -> str:
+    """Identifies the device code a profile was taken on: sha256 over the sources of libgrlx.so."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "grl_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        p = os.path.join(d, name)
+        if os.path.isfile(p) and name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            with open(p, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_pmc(key: str, n_replicas: int, trials_per_launch: int):
+    """What the PMC passes committed under profiles/ measured for this workload (rocprofv3 cannot run inside this process):
+    HBM-side bytes per launch and the issue share of the wave cycles.  Valid only for the configuration AND the device code
+    it was measured on: a profile taken on other kernel sources is refused.  Returns (traffic, issue, traffic_source)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            doc = json.load(f)
+        t = doc["workloads"][key]
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, None, "none: profiles/pmc_traffic.json has no entry for " + key
+    tag = f"profiles/{t.get('source', '?')}_pmc_raw.txt via profiles/pmc_traffic.json, csrc {doc.get('csrc_sha256', 'unrecorded')}"
+    if doc.get("csrc_sha256") != csrc_hash():
+        return None, None, f"stale, refused ({tag}; this build is csrc {csrc_hash()}): rerun tools/profile_passes.sh"
+    if t.get("replicas") != n_replicas or t.get("trials_per_launch") != trials_per_launch:
+        return None, None, f"other configuration, refused ({tag}: {t.get('replicas')} replicas x {t.get('trials_per_launch')} trials)"
+    return float(t["hbm_bytes_per_launch"]), t.get("issue"), tag
+
+
+def graph_config(graph, n, max_rows, table_log2=None, replicas_per_wave=0):
     import grl_amd
-    w = FQI
-    R = replicas or w["replicas"]
-    n = batch_size or w["batch_size"]
-    ep = epochs or w["epochs"]
-    cfg = grl_amd.pendulum_fqi_config(R, batch_size=n, iterations=w["iterations"], epochs=ep, max_batches=2)
-    r = grl_amd.FqiRunner(cfg, np.arange(1, R + 1))
-    stream = torch.cuda.current_stream()
-    r.run_batch(stream.cuda_stream)
-    r.sync(stream.cuda_stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record(stream)
-    r.run_batch(stream.cuda_stream)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    r.sync(stream.cuda_stream)
-    its = [r.info(k)["iterations"] for k in range(R)]
-    returns = [float(r.rows(k, 2)[2][1]) for k in range(R)]
-    r.close()
-    sample_epochs = sum(its) * ep * 2 * n
-    flops = sample_epochs * w["flops_per_sample_epoch"]
-    ms = e0.elapsed_time(e1)
-    out = {"workload": w["workload"].replace("100000 transitions", f"{n} transitions").replace("200000 stored", f"{2 * n} stored").replace("16 independent", f"{R} independent").replace("500 epochs", f"{ep} epochs"),
-           "value": sample_epochs / elapsed, "unit": "sample-epochs/s", "steps": 1, "warmup": 1, "ms_per_step": 1e3 * elapsed,
-           "replicas": R, "transitions_stored": 2 * n, "iterations_run": its, "epochs": ep, "dtype": "f64", "data": "synthetic",
-           "mean_test_return": sum(returns) / len(returns), "parity": "unpinned by the reference (oracle/fqi.c D1-D4); HIP == oracle bit for bit",
-           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS, "traffic": None, "kernel": w["kernel"], "kernel_ms_total": ms,
-                        "algorithmic_flops_per_step": flops,
-                        "note": "f64 VALU (no MFMA: K = 3 and K = 20 contractions, DESIGN.md 4.3); the chain of 10000 tiny launches per rebuild is latency-bound"}}
-    if not no_cpu_baseline:
-        from tests import oracle_binding as ob
-        e = ob.FqiExperiment(ob.pendulum_fqi_spec(math=ob.MATH_LIBM, sum_order=ob.SUM_SEQUENTIAL, batch_size=4000, iterations=4, epochs=100), seed=1)
-        t0 = time.perf_counter()
-        e.run_batch()
-        dt = time.perf_counter() - t0
-        se = e.info()["iterations"] * 100 * 4000
-        e.close()
-        out["cpu_baseline"] = {"value": se / dt, "unit": "sample-epochs/s", "cores": 1, "kind": "port",
-                               "sample": f"oracle/fqi.c (libm, the reference's sample-order gradient sum), 1 replica, 4000 transitions x {se // 4000} epochs in {dt:.1f} s"}
-    return out
+    make = {"pendulum_sarsa": grl_amd.pendulum_sarsa_config, "cart_pole_ac": grl_amd.cart_pole_ac_config,
+            "acrobot_q": grl_amd.acrobot_q_config, "compass_walker_q": grl_amd.compass_walker_q_config}[graph]
+    cfg = make(n)
+    cfg.max_rows = max_rows
+    if table_log2:
+        cfg.table_log2_capacity = table_log2
+    if replicas_per_wave:
+        cfg.replicas_per_wave = replicas_per_wave
+    return cfg
 
 
-def secondary_config(key, n):
-    import grl_amd
-    if key == "cart_pole_ac":
-        return grl_amd.cart_pole_ac_config(n)
-    if key == "acrobot_q":
-        return grl_amd.acrobot_q_config(n)
-    if key == "compass_walker_q":
-        return grl_amd.compass_walker_q_config(n)
-    raise KeyError(key)
+def oracle_spec(graph):
+    from tests import configs
+    make = {"pendulum_sarsa": configs.pendulum, "cart_pole_ac": configs.cart_pole_ac, "acrobot_q": configs.acrobot,
+            "compass_walker_q": configs.compass_walker}[graph]
+    return make(None, 1)[1]
 
 
-def secondary_cpu_baseline(key, budget_s=4.0):
-    """The oracle on ONE host core on the same experiment graph (libm arithmetic = the reference's own)."""
-    from tests import configs, oracle_binding as ob
-    make = {"cart_pole_ac": configs.cart_pole_ac, "acrobot_q": configs.acrobot, "compass_walker_q": configs.compass_walker}[key]
-    _, spec = make(None, 1)
+_ORACLE_RUNS = {}
+
+
+def oracle_cpu_baseline(graph, budget_s, trials_in_regime):
+    key = (graph, budget_s, trials_in_regime)
+    if key not in _ORACLE_RUNS:
+        _ORACLE_RUNS[key] = _oracle_cpu_baseline(graph, budget_s, trials_in_regime)
+    return _ORACLE_RUNS[key]
+
+
+def _oracle_cpu_baseline(graph, budget_s, trials_in_regime):
+    """The oracle (validated against the reference's golden files) on ONE host core, libm arithmetic = the reference's own:
+    replica seed 1 for about `budget_s` seconds.  Also counts the algorithmic bytes per step on the first
+    `trials_in_regime` trials (the ones bench.py times on the GPU)."""
+    from tests import oracle_binding as ob
+    spec = oracle_spec(graph)
     spec.math = ob.MATH_LIBM
     e = ob.Experiment(spec, seed=1)
-    trials = 0
+    rpt = ALGORITHMIC_BYTES[graph]["reads_per_test"]
     t0 = time.perf_counter()
+    e.run(trials_in_regime)
+    st = e.stats()
+    counted = dict(learn=(8.0 * (st.weight_reads - st.test_steps * rpt) + 16.0 * st.weight_rmws) / max(st.learn_steps, 1), test=8.0 * rpt,
+                   source=f"oracle, seed 1, trials 1-{trials_in_regime} ({int(st.learn_steps)} learning steps)")
+    trials = trials_in_regime
     while time.perf_counter() - t0 < budget_s:
         e.run(22)
         trials += 22
@@ -157,225 +176,304 @@ def secondary_cpu_baseline(key, budget_s=4.0):
     steps = int(st.learn_steps + st.test_steps)
     e.close()
     return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (C restatement of grl's scalar path, libm arithmetic), 1 replica seed 1, {trials} trials = {steps} env-steps in {dt:.1f} s, weight init excluded"}
+            "sample": f"oracle (C restatement of grl's scalar path, libm arithmetic), 1 replica seed 1, {trials} trials = {steps} env-steps in {dt:.1f} s, weight init excluded"}, counted
 
 
-def run_secondary(w, torch, no_cpu_baseline, replicas=None):
-    """One secondary workload on the current GPU: `warmup` untimed launches, then `steps` timed launches of
-    `trials` trials of every replica (HIP events per launch on the launch stream, wall clock around the lot).
-    Episode lengths vary (absorbing states), so env-steps are counted by the device, not assumed."""
-    import numpy as np
-    import grl_amd
-    n = replicas or w["replicas"]
-    cfg = secondary_config(w["key"], n)
-    cfg.max_rows = (w["steps"] + w["warmup"]) * w["trials"] + 1
-    runner = grl_amd.Runner(cfg, np.arange(1, n + 1))
-    stream = torch.cuda.current_stream()
-    sptr = stream.cuda_stream
-    for _ in range(w["warmup"]):
-        runner.run(w["trials"], sptr)
-    runner.sync(sptr)
-    l0, t0s = runner.step_counts()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(w["steps"])]
-    torch.cuda.synchronize()
+def all_cores_baseline(steps_per_s):
+    """The same oracle on all host cores this job may use, one replica per core (the reference's experiment/multi:
+    one thread per clone); spawned processes, they never touch the GPU."""
+    import subprocess
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    if cores <= 1:
+        return None
+    trials = max(110, int(steps_per_s * 6.0 / STEPS_PER_EPISODE))          # about 6 s per core
+    code = "import sys; from tests import oracle_binding as ob; s, t = ob.timed_run((int(sys.argv[1]), int(sys.argv[2]))); print(s, t)"
     t0 = time.perf_counter()
-    for k in range(w["steps"]):
-        ev[k][0].record(stream)
-        runner.run(w["trials"], sptr)
-        ev[k][1].record(stream)
-    torch.cuda.synchronize()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(seed), str(trials)], cwd=ROOT, stdout=subprocess.PIPE, text=True)
+             for seed in range(1, cores + 1)]
+    res = []
+    for pr in procs:
+        line = pr.communicate(timeout=300)[0].split()
+        if pr.returncode == 0 and len(line) == 2:
+            res.append((int(line[0]), float(line[1])))
+    wall = time.perf_counter() - t0
+    if len(res) != cores:
+        return None
+    busy = max(r[1] for r in res)
+    return {"value": sum(r[0] for r in res) / busy, "unit": "env-steps/s", "cores": cores,
+            "sample": f"{cores} processes x {trials} trials, slowest {busy:.1f} s (wall {wall:.1f} s incl. start-up and weight init)"}
+
+
+class Dist:
+    """The job as torch.distributed.run launched it (world 1: no process group)."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+            raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {self.world}")
+
+    def barrier(self, torch):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+
+def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log2=None, cpu_baseline=True, full_cpu_baseline=False):
+    """One workload on all ranks: `warmup` untimed launches, then EXACTLY `steps` timed launches of every context this rank
+    owns, bracketed by barrier + synchronize, with the workload's one collective (all-reduce of the curve statistics) inside
+    the timed region; MAX of the elapsed time over ranks.  HIP events per launch on the stream each kernel is launched on.
+    Episode lengths vary (absorbing states), so env-steps are counted by the device and summed over ranks afterwards."""
+    import grl_amd
+    from grl_amd import parallel
+    w = WORKLOADS[name]
+    n_rank = replicas or w["replicas"]
+    parts = parallel.partition(name, D.rank, D.world, n_rank)
+    main_stream = torch.cuda.current_stream()
+    ctx = []
+    for k, (graph, seeds) in enumerate(parts):
+        g = GRAPHS[graph]
+        rows_total = ((steps + warmup) * g["trials"]) // TRIALS_PER_STEP          # test_interval 10: one row per 11 trials
+        # two contexts share the GPU: 8 replicas per wave each (2 x 512 waves = one wave per SIMD, both kernels resident at once)
+        cfg = graph_config(graph, len(seeds), rows_total + 1, table_log2, 8 if len(parts) > 1 and len(seeds) >= 8 else 0)
+        stream = main_stream if len(parts) == 1 else torch.cuda.Stream()
+        ctx.append(dict(graph=graph, g=g, seeds=seeds, runner=grl_amd.Runner(cfg, seeds), stream=stream, rows=rows_total,
+                        ev=[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]))
+    rows_max = max(c["rows"] for c in ctx)
+    curve = torch.zeros((len(ctx), rows_max, 3), dtype=torch.float64, device="cuda")
+
+    for c in ctx:
+        for _ in range(warmup):
+            c["runner"].run(c["g"]["trials"], c["stream"].cuda_stream)
+    for c in ctx:
+        c["runner"].sync(c["stream"].cuda_stream)
+        c["count0"] = c["runner"].step_counts()
+    # warm the collective too (same shape and dtype as the timed one): communicator set-up and the first
+    # launch of the RCCL kernel belong to start-up, not to the job
+    parallel.reduce_curve(torch.zeros_like(curve), D.world)
+
+    D.barrier(torch)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        for c in ctx:
+            c["ev"][k][0].record(c["stream"])
+            c["runner"].run(c["g"]["trials"], c["stream"].cuda_stream)
+            c["ev"][k][1].record(c["stream"])
+    # the job's only collective: learning-curve statistics over all replicas of all GPUs
+    for i, c in enumerate(ctx):
+        c["runner"].curve_stats(curve[i].data_ptr(), 0, c["rows"], c["stream"].cuda_stream)
+        if c["stream"] is not main_stream:
+            main_stream.wait_stream(c["stream"])
+    parallel.reduce_curve(curve, D.world)
+    D.barrier(torch)
     elapsed = time.perf_counter() - t0
-    runner.sync(sptr)                                          # raises on table overflow etc.
-    l1, t1s = runner.step_counts()
-    variant = runner.last_kernel()
-    rpw = runner.replicas_per_wave()
-    runner.close()
-    learn, test = l1 - l0, t1s - t0s
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    avg_ms = sum(kernel_ms) / len(kernel_ms)
-    alg_bytes = (learn * w["bytes_learn"] + test * w["bytes_test"]) / w["steps"]
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    traffic, issue = measured_pmc(w["key"], n, w["trials"])
-    out = {"workload": w["workload"], "value": (learn + test) / elapsed, "unit": "env-steps/s", "steps": w["steps"], "warmup": w["warmup"],
-           "ms_per_step": 1e3 * elapsed / w["steps"], "replicas": n, "trials_per_step": w["trials"],
-           "env_steps_per_step": (learn + test) / w["steps"], "learn_steps": learn, "test_steps": test, "dtype": "f64", "data": "synthetic",
-           "last_kernel": variant, "kernel_is_expected_instantiation": variant == w["want_kernel"], "replicas_per_wave": rpw,
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "issue": issue, "kernel": w["kernel"], "kernel_ms_avg": avg_ms,
-                        "algorithmic_bytes_per_launch": alg_bytes}}
-    if not no_cpu_baseline:
-        out["cpu_baseline"] = secondary_cpu_baseline(w["key"])
+    elapsed = parallel.max_over_ranks(elapsed, D.world, device="cuda")
+
+    learn = test = 0
+    per_graph = []
+    for c in ctx:
+        if c["runner"].last_kernel() != c["g"]["want_kernel"]:
+            raise SystemExit(f"bench.py: {c['graph']} did not run its specialised kernel (grlx_last_kernel = {c['runner'].last_kernel()})")
+        c["runner"].sync(c["stream"].cuda_stream)               # raises on table overflow etc.
+        l1, t1 = c["runner"].step_counts()
+        c["learn"], c["test"] = l1 - c["count0"][0], t1 - c["count0"][1]
+        learn += c["learn"]
+        test += c["test"]
+        c["kernel_ms"] = [a.elapsed_time(b) for a, b in c["ev"]]
+        c["rpw"] = c["runner"].replicas_per_wave()
+    all_learn, all_test = parallel.sum_over_ranks([learn, test], D.world, device="cuda")
+    curve_host = curve.cpu().numpy()
+    for c in ctx:
+        c["runner"].close()                                     # frees this workload's tables before the next one allocates
+    if D.rank != 0:
+        return None
+
+    out = {"workload": name, "value": (all_learn + all_test) / elapsed, "unit": "env-steps/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * elapsed / steps, "scaling": "weak", "dtype": "f64", "data": "synthetic",
+           "replicas_per_gpu": n_rank, "parallelism": f"replicas x{D.world}" + (" (both halves on every rank, two streams)" if len(ctx) > 1 else ""),
+           "env_steps_per_step": (all_learn + all_test) / steps, "learn_steps": int(all_learn), "test_steps": int(all_test),
+           "baseline_config": f"BASELINE.json configs[{w['baseline_config']}]"}
+    text = []
+    for i, c in enumerate(ctx):
+        g = c["g"]
+        n = len(c["seeds"])
+        text.append(f"{g['text']}, {n} independent-seed replicas per GPU, {g['trials']} trials per replica per step")
+        bytes_ = dict(ALGORITHMIC_BYTES[c["graph"]], source="committed figure (bench.py ALGORITHMIC_BYTES; tools/algorithmic_bytes.py)")
+        cpu = None
+        if cpu_baseline:
+            cpu, counted = oracle_cpu_baseline(c["graph"], 12.0 if (full_cpu_baseline and i == 0) else 4.0, (steps + warmup) * g["trials"])
+            if c["graph"] != "pendulum_sarsa":                  # the headline keeps SURVEY's declared 2228 B
+                bytes_.update(counted)
+            else:
+                bytes_["oracle_this_run"] = counted["learn"]
+            if full_cpu_baseline and i == 0:
+                ac = all_cores_baseline(cpu["value"])
+                if ac:
+                    cpu["all_cores"] = ac
+        avg_ms = sum(c["kernel_ms"]) / len(c["kernel_ms"])
+        alg = (c["learn"] * bytes_["learn"] + c["test"] * bytes_["test"]) / steps
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic, issue, src = measured_pmc(g["pmc_key"], n, g["trials"]) if len(ctx) == 1 else (None, None, "none: concurrent contexts are not profiled separately")
+        mean_curve = curve_host[i, :c["rows"], 0] / curve_host[i, :c["rows"], 2].clip(min=1)
+        c["report"] = {"graph": c["graph"], "replicas": n, "trials_per_step": g["trials"], "replicas_per_wave": c["rpw"],
+                       "env_steps_per_step_this_rank": (c["learn"] + c["test"]) / steps,
+                       "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
+                       "curve_replicas": float(curve_host[i, 0, 2]),
+                       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                    "traffic": traffic, "traffic_source": src, "issue": issue, "kernel": g["kernel"], "kernel_ms_avg": avg_ms,
+                                    "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_learn_step": bytes_["learn"],
+                                    "algorithmic_bytes_per_test_step": bytes_["test"], "algorithmic_bytes_source": bytes_["source"]}}
+        if "oracle_this_run" in bytes_:
+            c["report"]["roofline"]["oracle_bytes_per_learn_step_on_these_trials"] = bytes_["oracle_this_run"]
+        if cpu:
+            c["report"]["cpu_baseline"] = cpu
+    out["config"] = {"workload": "; ".join(text), "replicas_per_gpu": n_rank, "parallelism": out["parallelism"]}
+    dom = [c for c in ctx if c["graph"] == w["dominant"]][0]
+    out["roofline"] = dom["report"]["roofline"]
+    if "cpu_baseline" in dom["report"]:
+        out["cpu_baseline"] = dom["report"]["cpu_baseline"]
+    out["mean_test_return_first_last"] = dom["report"]["mean_test_return_first_last"]
+    out["curve_replicas"] = dom["report"]["curve_replicas"]
+    out["replicas_per_wave"] = dom["report"]["replicas_per_wave"]
+    if len(ctx) > 1:
+        out["parts"] = [c["report"] for c in ctx]
     return out
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """The oracle (validated against the reference's golden curve) on ONE host core:
-    replica seed 1, the same trial mix, for about `budget_s` seconds of CPU work."""
-    from tests import oracle_binding as ob
-    e = ob.Experiment(ob.pendulum_sarsa_spec(math=ob.MATH_LIBM), seed=1)      # libm = the reference's own arithmetic
-    chunk = 110 * 5
-    steps = 0
+def run_fqi(D, torch, cpu_baseline=True, replicas=None, batch_size=None, epochs=None):
+    """The batch path on all ranks: replicas only -- rank g runs the independent-seed experiments
+    g*R .. (g+1)*R - 1; the one collective is the all-reduce of the per-batch test-return statistics [batches][3]."""
+    import numpy as np
+    import grl_amd
+    from grl_amd import parallel
+    w = FQI
+    R = replicas or w["replicas"]
+    n = batch_size or w["batch_size"]
+    ep = epochs or w["epochs"]
+    (_, seeds), = parallel.partition(w["key"], D.rank, D.world, R)
+    cfg = grl_amd.pendulum_fqi_config(R, batch_size=n, iterations=w["iterations"], epochs=ep, max_batches=2)
+    r = grl_amd.FqiRunner(cfg, seeds)
+    stream = torch.cuda.current_stream()
+    r.run_batch(stream.cuda_stream)
+    r.sync(stream.cuda_stream)
+    stats = torch.zeros((2, 3), dtype=torch.float64, device="cuda")
+    parallel.reduce_curve(torch.zeros_like(stats), D.world)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    D.barrier(torch)
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        e.run(chunk)
-        steps += chunk * STEPS_PER_EPISODE
-    dt = time.perf_counter() - t0
-    out = {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": f"oracle (C restatement of grl's scalar path, libm arithmetic), 1 replica seed 1, "
-                     f"{steps // STEPS_PER_EPISODE} trials = {steps} env-steps in {dt:.1f} s, weight init excluded"}
-    # the same code on all host cores this job may use, one replica per core (the reference's
-    # experiment/multi: one thread per clone); spawned processes, they never touch the GPU
-    cores = min(len(os.sched_getaffinity(0)), 16)
-    if cores > 1:
-        import subprocess
-        trials = max(110, int(steps / dt * 6.0 / STEPS_PER_EPISODE))          # about 6 s per core
-        code = "import sys; from tests import oracle_binding as ob; s, t = ob.timed_run((int(sys.argv[1]), int(sys.argv[2]))); print(s, t)"
-        root = os.path.dirname(os.path.abspath(__file__))
+    e0.record(stream)
+    r.run_batch(stream.cuda_stream)
+    e1.record(stream)
+    r.sync(stream.cuda_stream)
+    returns = np.array([r.rows(k, 2)[2] for k in range(R)])                 # [replica][batch]
+    stats.copy_(torch.tensor(np.stack([returns.sum(0), (returns ** 2).sum(0), np.full(2, float(R))], axis=1)))
+    parallel.reduce_curve(stats, D.world)
+    D.barrier(torch)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, D.world, device="cuda")
+    its = [r.info(k)["iterations"] for k in range(R)]
+    r.close()
+    sample_epochs_rank = sum(its) * ep * 2 * n
+    sample_epochs, = parallel.sum_over_ranks([sample_epochs_rank], D.world, device="cuda")
+    if D.rank != 0:
+        return None
+    flops = sample_epochs_rank * w["flops_per_sample_epoch"]
+    ms = e0.elapsed_time(e1)
+    s = stats.cpu().numpy()
+    traffic, issue, src = measured_pmc(w["key"], R, 2 * n)
+    out = {"workload": w["key"], "value": sample_epochs / elapsed, "unit": "sample-epochs/s", "n_gpus": D.world, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * elapsed,
+           "scaling": "weak", "dtype": "f64", "data": "synthetic", "replicas_per_gpu": R, "parallelism": f"replicas only x{D.world} (no data-path collective)",
+           "baseline_config": "BASELINE.json configs[4]",
+           "config": {"workload": w["workload"].replace("100000 transitions", f"{n} transitions").replace("200000 stored", f"{2 * n} stored").replace("16 independent", f"{R} independent").replace("500 epochs", f"{ep} epochs"),
+                      "replicas_per_gpu": R, "transitions_stored": 2 * n, "epochs": ep},
+           "iterations_run": its, "mean_test_return": float(s[1, 0] / s[1, 2]), "curve_replicas": float(s[1, 2]),
+           "parity": "unpinned by the reference (oracle/fqi.c D1-D4); HIP == oracle bit for bit",
+           "roofline": {"bound": "valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "issue": issue,
+                        "kernel": w["kernel"], "kernel_ms_total": ms, "algorithmic_flops_per_step": flops,
+                        "note": "f64 vector ALU, no MFMA is issued (K = 3 and K = 20 contractions with N = 1 and the logistic dominate, DESIGN.md 4.3); "
+                                "peak = the f64 vector rate"}}
+    if cpu_baseline:
+        from tests import oracle_binding as ob
+        e = ob.FqiExperiment(ob.pendulum_fqi_spec(math=ob.MATH_LIBM, sum_order=ob.SUM_SEQUENTIAL, batch_size=4000, iterations=4, epochs=100), seed=1)
         t0 = time.perf_counter()
-        procs = [subprocess.Popen([sys.executable, "-c", code, str(seed), str(trials)], cwd=root, stdout=subprocess.PIPE, text=True)
-                 for seed in range(1, cores + 1)]
-        res = []
-        for pr in procs:
-            line = pr.communicate(timeout=300)[0].split()
-            if pr.returncode == 0 and len(line) == 2:
-                res.append((int(line[0]), float(line[1])))
-        wall = time.perf_counter() - t0
-        if len(res) == cores:
-            busy = max(r[1] for r in res)
-            out["all_cores"] = {"value": sum(r[0] for r in res) / busy, "unit": "env-steps/s", "cores": cores,
-                                "sample": f"{cores} processes x {trials} trials, slowest {busy:.1f} s (wall {wall:.1f} s incl. start-up and weight init)"}
+        e.run_batch()
+        dt = time.perf_counter() - t0
+        se = e.info()["iterations"] * 100 * 4000
+        e.close()
+        out["cpu_baseline"] = {"value": se / dt, "unit": "sample-epochs/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/fqi.c (libm, the reference's sample-order gradient sum), 1 replica, 4000 transitions x {se // 4000} epochs in {dt:.1f} s "
+                                         f"-- a SMALLER regime than the GPU's ({2 * n} transitions x {ep} epochs x {R} replicas): the unit is the same, the store fits the host's cache"}
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=REPLICAS_PER_GPU, help="replicas per GPU")
+    ap.add_argument("--steps", type=int, default=None, help="timed launches of the chosen workload (default 20 for the headline)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="pendulum_sarsa", choices=sorted(WORKLOADS) + [FQI["key"]])
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU of the chosen workload (default: BASELINE.json's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations (cart-pole AC, acrobot, walker)")
-    ap.add_argument("--no-fqi", action="store_true", help="skip the batch-path entry (its rebuild is ~20000 launches: keeps profiler output small)")
-    ap.add_argument("--only", default="", help="profiling: run only this secondary workload (cart_pole_ac | acrobot_q | compass_walker_q) and print its entry")
-    ap.add_argument("--secondary-replicas", type=int, default=0, help="tests: override the replica count of the secondary workloads")
-    ap.add_argument("--table-log2", type=int, default=17)
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the other BASELINE.json configurations")
+    ap.add_argument("--no-fqi", action="store_true", help="skip the batch-path entry among the secondaries")
+    ap.add_argument("--only", default="", help="synonym of --workload (kept for the profiling scripts)")
+    ap.add_argument("--secondary-replicas", type=int, default=0, help="tests: replicas per GPU of the secondary workloads")
+    ap.add_argument("--fqi-replicas", type=int, default=0, help="tests: replicas per GPU of the batch path")
+    ap.add_argument("--fqi-batch-size", type=int, default=0, help="tests: transitions per batch of the batch path")
+    ap.add_argument("--fqi-epochs", type=int, default=0)
+    ap.add_argument("--table-log2", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
+    if args.only:
+        args.workload = args.only
+        args.no_secondary = True
+    D = Dist(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-
-    import numpy as np
     import torch
     import torch.distributed as dist
-    import grl_amd
     from grl_amd import parallel
 
-    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-    if args.only == FQI["key"]:
-        print(json.dumps(run_fqi(torch, args.no_cpu_baseline, args.secondary_replicas or None)))
-        return
-    if args.only:
-        w = [x for x in SECONDARY if x["key"] == args.only]
-        if not w:
-            raise SystemExit("--only: unknown workload " + args.only)
-        print(json.dumps(run_secondary(w[0], torch, args.no_cpu_baseline, args.secondary_replicas or None)))
-        return
+    torch.cuda.set_device(D.local_rank % max(torch.cuda.device_count(), 1))
     parallel.init_distributed(args.backend)
+    cpu = not args.no_cpu_baseline and D.world == 1              # cpu_baseline: rank 0 at N = 1 only
 
-    n = args.replicas
-    total_steps = args.steps + args.warmup
-    rows_total = total_steps                                   # one test row per step
-    cfg = grl_amd.pendulum_sarsa_config(n, table_log2_capacity=args.table_log2, max_rows=rows_total + 1)
-    seeds = parallel.replica_seeds(rank, world, n)             # contiguous partition of replica ids
-    runner = grl_amd.Runner(cfg, seeds)
-    stream = torch.cuda.current_stream()
-    sptr = stream.cuda_stream
-    curve = torch.zeros((rows_total, 3), dtype=torch.float64, device="cuda")
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        runner.run(TRIALS_PER_STEP, sptr)
-    runner.sync(sptr)
-    # warm the collective too (same shape and dtype as the timed one): communicator set-up and the first
-    # launch of the RCCL kernel belong to start-up, not to the job
-    parallel.reduce_curve(torch.zeros_like(curve), world)
-
-    # per-launch kernel time: HIP events on the stream the kernel is launched on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(stream)
-        runner.run(TRIALS_PER_STEP, sptr)
-        ev[k][1].record(stream)
-    # the job's only collective: learning-curve statistics over all replicas of all GPUs
-    runner.curve_stats(curve.data_ptr(), 0, rows_total, sptr)
-    parallel.reduce_curve(curve, world)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # the measured launches must have been the production instantiation of this configuration
-    if runner.last_kernel() != 2:
-        raise SystemExit("bench.py: the headline configuration did not run its specialised kernel (grlx_last_kernel = %d)" % runner.last_kernel())
-    runner.sync(sptr)                                          # raises on table overflow etc.
-
-    elapsed = parallel.max_over_ranks(elapsed, world, device="cuda")
-
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    env_steps_per_step = n * (LEARN_STEPS_PER_STEP + TEST_STEPS_PER_STEP)
-    total_env_steps = env_steps_per_step * args.steps * world
-    learn, test = runner.step_counts()
-    assert learn == n * LEARN_STEPS_PER_STEP * total_steps and test == n * TEST_STEPS_PER_STEP * total_steps, (learn, test)
-
-    if rank == 0:
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        alg_bytes = n * (LEARN_STEPS_PER_STEP * BYTES_PER_LEARN_STEP + TEST_STEPS_PER_STEP * BYTES_PER_TEST_STEP)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        mean_curve = (curve[:, 0] / curve[:, 2]).cpu().numpy()
-        traffic, issue = measured_pmc("pendulum_sarsa", n, TRIALS_PER_STEP)
-        out = {
-            "metric": "env-steps/sec (batched rollouts), pendulum SARSA-tc",
-            "value": total_env_steps / elapsed,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "pendulum swing-up SARSA(lambda) hashed tile coding (cfg/pendulum/sarsa_tc.yaml semantics), "
-                                   f"{n} independent-seed replicas per GPU, 11 trials (1100 env-steps) per replica per step",
-                       "replicas_per_gpu": n, "trials_per_step": TRIALS_PER_STEP, "env_steps_per_step": env_steps_per_step * world,
-                       "tilings": 16, "memory": 8388608, "parallelism": f"replicas x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "issue": issue,
-                         "kernel": "rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update>", "kernel_ms_avg": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
-        }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-    runner.close()                                             # frees this workload's tables before the next one allocates
-    if rank == 0:
-        if world == 1 and not args.no_secondary:
-            # the other single-GPU configurations BASELINE.json names, each timed the same way on this GPU
-            out["secondary"] = [run_secondary(w, torch, args.no_cpu_baseline, args.secondary_replicas or None) for w in SECONDARY]
-            if not args.no_fqi:
-                out["secondary"].append(run_fqi(torch, args.no_cpu_baseline))
-        print(json.dumps(out))
-    if world > 1:
+    if args.workload == FQI["key"]:
+        out = run_fqi(D, torch, cpu, args.replicas or args.fqi_replicas or None, args.fqi_batch_size or None, args.fqi_epochs or None)
+        head = FQI["key"]
+    else:
+        w = WORKLOADS[args.workload]
+        steps = args.steps if args.steps is not None else w["steps"]
+        warmup = args.warmup if args.warmup is not None else w["warmup"]
+        out = run_rollout_workload(args.workload, D, torch, steps, warmup, args.replicas or None, args.table_log2 or None, cpu,
+                                   full_cpu_baseline=args.workload == "pendulum_sarsa")
+        head = args.workload
+    if D.rank == 0:
+        metric = {"pendulum_sarsa": "env-steps/sec (batched rollouts), pendulum SARSA-tc", FQI["key"]: "sample-epochs/sec (batch path), pendulum FQI-ANN"}
+        line = {"metric": metric.get(head, "env-steps/sec (batched rollouts), " + head), "value": out["value"], "unit": out["unit"], "n_gpus": D.world,
+                "steps": out["steps"], "warmup": out["warmup"], "ms_per_step": out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+        line.update({k: v for k, v in out.items() if k not in line})
+        if head == "pendulum_sarsa":
+            n = out["replicas_per_gpu"]
+            line["config"].update({"trials_per_step": TRIALS_PER_STEP, "env_steps_per_step": int(out["env_steps_per_step"]), "tilings": 16, "memory": 8388608})
+            assert out["learn_steps"] == n * 10 * STEPS_PER_EPISODE * out["steps"] * D.world, out["learn_steps"]
+    if args.workload == "pendulum_sarsa" and not args.no_secondary:
+        # the other configurations BASELINE.json names, each sharded over the same ranks and timed the same way
+        sec = []
+        for name in SECONDARY_ORDER:
+            w = WORKLOADS[name]
+            sec.append(run_rollout_workload(name, D, torch, w["steps"], w["warmup"], args.secondary_replicas or None, None, cpu))
+        if not args.no_fqi:
+            sec.append(run_fqi(D, torch, cpu, args.fqi_replicas or None, args.fqi_batch_size or None, args.fqi_epochs or None))
+        if D.rank == 0:
+            line["secondary"] = sec
+    if D.rank == 0:
+        print(json.dumps(line))
+    if D.world > 1:
         dist.destroy_process_group()
 
 

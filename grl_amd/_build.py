@@ -17,11 +17,14 @@ HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_
            "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h",
            os.path.join("..", "..", "include", "grlx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
-# The device code is not taken from hipcc as is: it is compiled to assembly, passed through _exec_prologue.fix (a
-# work-around for a register-allocation bug of this compiler, see that file and DESIGN.md section 4.1f), assembled,
-# linked and bundled with the same tools and options the hipcc driver uses (`hipcc -###`), and handed to the host
-# compilation of the same source with -fcuda-include-gpubinary.
-PIPELINE = "device-asm+exec-prologue-fix/1"
+TAG_DEFINE = "-DGRLX_BUILD_PIPELINE="
+# The device code is not taken from hipcc as is: it is compiled to assembly together with the compiler's machine code
+# after register allocation, passed through _exec_prologue (a work-around for a register-allocation bug of this
+# compiler, see that file and DESIGN.md section 4.1f: the misplaced copies are FOUND in the machine code and MOVED in the
+# assembly; anything it cannot handle stops the build), assembled, linked and bundled with the same tools and options
+# the hipcc driver uses (`hipcc -###`), and handed to the host compilation of the same source with
+# -fcuda-include-gpubinary.  The library carries the tag (grlx_build_pipeline()); capi.load() refuses one without it.
+PIPELINE = "device-asm+mir-exec-prologue-fix/2"
 
 FLAGS_FILE = LIB + ".flags"      # the flags the library was built with: a change of flags makes it stale
 
@@ -41,6 +44,8 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "_exec_prologue.py")]
+    if not os.path.exists(LIB + ".asmfix"):
+        return True
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -64,14 +69,24 @@ def _build_hip_object(hipcc, src, tmp, flags, verbose, report):
     """One .hip source -> host object carrying the filtered device code."""
     from . import _exec_prologue
     stem = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0])
-    _run([hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", stem + ".s"], verbose)
+    cmd = [hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", stem + ".s", "-mllvm", "-print-after=stack-slot-coloring"]
+    if verbose:
+        print(" ".join(cmd), "2>", stem + ".mir")
+    with open(stem + ".mir", "w") as mir:        # the machine code after register allocation goes to stderr (hundreds of MB)
+        rc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=mir, text=True).returncode
+    if rc != 0:
+        _run([hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", stem + ".s"], verbose)      # again, for a readable message
+        raise RuntimeError(f"{src}: hipcc failed only with -print-after=stack-slot-coloring")
+    with open(stem + ".mir", errors="replace") as f:
+        found, problems = _exec_prologue.find_misplaced(f)
+    os.remove(stem + ".mir")
     with open(stem + ".s") as f:
-        fixed, n_fixed, n_skipped = _exec_prologue.fix(f.read().split("\n"))
+        fixed, n_fixed, p2 = _exec_prologue.apply(f.read().split("\n"), found)
     with open(stem + ".fixed.s", "w") as f:
         f.write("\n".join(fixed))
-    report[os.path.basename(src)] = (n_fixed, n_skipped)
-    if n_skipped:
-        raise RuntimeError(f"{src}: {n_skipped} block head(s) with vector writes before the exec restore could not be rewritten")
+    report[os.path.basename(src)] = (len(found), n_fixed)
+    if problems or p2:
+        raise RuntimeError(f"{src}: the exec-prologue filter cannot make this device code safe (DESIGN.md 4.1f):\n  " + "\n  ".join(problems + p2))
     _run([_llvm_tool("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", stem + ".fixed.s", "-o", stem + ".dev.o"], verbose)
     _run([_llvm_tool("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", stem + ".out", stem + ".dev.o"], verbose)
     _run([_llvm_tool("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
@@ -99,7 +114,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if name.endswith(".hip"):
                 return _build_hip_object(hipcc, src, tmp, flags, verbose, report)
             obj = os.path.join(tmp, os.path.splitext(name)[0] + ".o")
-            _run([hipcc] + flags + ["-c", src, "-o", obj], verbose)
+            _run([hipcc] + flags + [TAG_DEFINE + '"' + PIPELINE + '"', "-c", src, "-o", obj], verbose)
             return obj
         with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
             objs = list(pool.map(one, SOURCES))
@@ -108,7 +123,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         f.write(_flags() + "\n")
     with open(LIB + ".asmfix", "w") as f:       # how many block heads the assembly filter rewrote, per source
         for k in sorted(report):
-            f.write(f"{k}: {report[k][0]} rewritten, {report[k][1]} left alone\n")
+            f.write(f"{k}: {report[k][0]} misplaced block head(s) in the machine code after register allocation, {report[k][1]} rewritten in the assembly\n")
     return LIB
 
 

@@ -73,6 +73,7 @@ _P = C.POINTER
 _SIGS = {
     "grlx_last_error": (C.c_char_p, []),
     "grlx_abi_version": (C.c_int, []),
+    "grlx_build_pipeline": (C.c_char_p, []),
     "grlx_device_count": (C.c_int, []),
     "grlx_config_pendulum_sarsa": (None, [_P(Config)]),
     "grlx_config_cart_pole_ac": (None, [_P(Config)]),
@@ -160,6 +161,10 @@ def load():
         fn.argtypes = args
     if lib.grlx_abi_version() != 1:
         raise ImportError("libgrlx.so ABI version mismatch")
+    tag = (lib.grlx_build_pipeline() or b"").decode()
+    if tag != _build.PIPELINE:
+        raise ImportError(f"{path} was not built by grl_amd._build (pipeline tag {tag!r}, expected {_build.PIPELINE!r}): a plain hipcc build skips the "
+                          "exec-prologue filter and its kernels can read stale lanes (DESIGN.md 4.1f); run `python -m grl_amd._build`")
     _lib = lib
     return lib
 

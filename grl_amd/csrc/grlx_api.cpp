@@ -342,6 +342,10 @@ extern "C" {
 
 const char *grlx_last_error(void) { return g_err.c_str(); }
 int grlx_abi_version(void) { return GRLX_ABI_VERSION; }
+#ifndef GRLX_BUILD_PIPELINE
+#define GRLX_BUILD_PIPELINE ""
+#endif
+const char *grlx_build_pipeline(void) { return GRLX_BUILD_PIPELINE; }
 
 int grlx_device_count(void)
 {
@@ -717,9 +721,18 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
       uint32_t want = ctx->P.logC;
       while ((uint64_t)used * 8u > (1ull << want) && want < ctx->logC_max) ++want;
       const int rc = grow_tables(ctx, want);
-      if (rc != GRLX_OK) return rc;
+      if (rc == GRLX_ERR_OOM)
+      { // growing needs the old and the new tables at once: when that does not fit, the run goes on in the tables it has
+        // (a quarter full is not an overflow; a real one is still reported as GRLX_ERR_TABLE_FULL) and does not try again
+        g_err.clear();
+        ctx->logC_max = ctx->P.logC;
+      }
+      else if (rc != GRLX_OK) return rc;
     }
   }
+  // a run still pending on ANOTHER stream is waited for first: only one stream is remembered, and the launches below
+  // continue from the replica state that run leaves behind
+  if (ctx->run_pending && ctx->run_stream != (hipStream_t)stream) DRAIN(ctx);
   // One launch per <= kTrialsPerLaunch trials: replica state (and the actor-critic trace) persists in
   // HBM between launches, so results do not depend on the chunking (tested), and no single kernel
   // runs for minutes (compass walker: up to 1000 steps per episode).

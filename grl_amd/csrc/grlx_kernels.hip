@@ -73,11 +73,16 @@ __global__ __launch_bounds__(64) void poison_registers_kernel(uint32_t pattern)
       "  .set grlx_i, grlx_i + 1\n"
       ".endr\n"
       ".set grlx_i, 20\n"
-      ".rept 80\n"
+      ".rept 12\n"                      // s20..s31; s32..s34 are the ABI's stack / frame / base pointer registers: not clobbered
       "  s_mov_b32 s[grlx_i], %0\n"
       "  .set grlx_i, grlx_i + 1\n"
       ".endr\n"
-      :: "s"(pattern) : "memory", GRLX_ALL256("v"), GRLX_ALL256("a"), GRLX_D10("s2"), GRLX_D10("s3"), GRLX_D10("s4"), GRLX_D10("s5"),
+      ".set grlx_i, 35\n"
+      ".rept 65\n"                      // s35..s99
+      "  s_mov_b32 s[grlx_i], %0\n"
+      "  .set grlx_i, grlx_i + 1\n"
+      ".endr\n"
+      :: "s"(pattern) : "memory", GRLX_ALL256("v"), GRLX_ALL256("a"), GRLX_D10("s2"), "s30", "s31", "s35", "s36", "s37", "s38", "s39", GRLX_D10("s4"), GRLX_D10("s5"),
          GRLX_D10("s6"), GRLX_D10("s7"), GRLX_D10("s8"), GRLX_D10("s9"));
 }
 #undef GRLX_ALL256
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(64) void rehash_kernel(DevParams P, int n_tables, E
           if (atomicCAS(&nt.base[nb].key[w], 0u, kw) == 0u) { at = (nb << 2) | (uint32_t)w; break; }
         if (at == kInvalidPos) nb = (nb + 1u) & nt.bmask;
       }
-      if (at == kInvalidPos) { P.states[r].status |= ST_TABLE_FULL; continue; }
+      if (at == kInvalidPos) { atomicOr(&P.states[r].status, ST_TABLE_FULL); continue; }
       nt.base[at >> 2].aux[at & 3u] = ob.aux[way];
       nt.base[at >> 2].val[at & 3u] = ob.val[way];
       if (map) map[b * 4 + way] = at;

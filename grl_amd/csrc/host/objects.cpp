@@ -334,6 +334,9 @@ struct TileCodingProjector : Projector {
     t.tilings = tilings; t.memory = memory; t.dims = (int)resolution.size();
     if (resolution.size() > GRLX_MAX_DIMS) throw bad_param("projector/tile_coding:resolution");
     for (size_t i = 0; i < resolution.size(); ++i) { t.resolution[i] = resolution[i]; t.wrapping[i] = wrapping[i]; }
+    // safe >= 1 returns CLAIMED slots, which depend on what was written before (tile_coding.h:116-151): that state lives in an
+    // experiment's tables, not in a stand-alone projector -- refuse rather than return the unclaimed `hash % memory`
+    if (safe != 0) throw Exception(path() + ": Projector::project as a stand-alone operator serves safe = 0 only (claims live in the experiment's tables)");
     if (grlx_project(&t, in, n, out) != GRLX_OK) throw Exception(path() + ": " + grlx_last_error());
   }
   int tilings = 16, memory = 8 * 1024 * 1024, safe = 0;
@@ -374,6 +377,9 @@ struct LinearRepresentation : Representation {
   void reset(int64_t seed) override
   {
     if (outputs != 1) throw Exception(path() + ": the GPU operators serve representations with one output");
+    // a representation with a target network (interval) reads through target() and counts updates towards the next
+    // synchronisation (representation.h:266-306): the stand-alone operators do not carry that state -- refuse
+    if (interval != 0) throw Exception(path() + ": Representation::read/write/update as stand-alone operators serve interval = 0 only (no target network)");
     if (own) { grlx_destroy(own); own = nullptr; }
     grlx_config c;
     grlx_config_pendulum_sarsa(&c);

@@ -171,6 +171,11 @@ typedef struct {
 
 const char *grlx_last_error(void);
 int  grlx_abi_version(void);
+/* How the library was built: "device-asm+mir-exec-prologue-fix/2" when grl_amd/_build.py built it (the only supported
+ * build: it passes the device code through the work-around for a register-allocation bug of ROCm 7.2's compiler,
+ * DESIGN.md 4.1f), "" for a plain `hipcc -shared`, whose kernels may read stale lanes.  Bindings refuse the latter
+ * (grl_amd/capi.py: load(); the reference-side addon: integration/addons/grlx). */
+const char *grlx_build_pipeline(void);
 int  grlx_device_count(void);
 
 /* Fill *cfg with the values of the reference's tests/pendulum-sarsa-tc.yaml. */

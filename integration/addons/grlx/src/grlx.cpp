@@ -62,8 +62,19 @@ void GrlxOnlineLearningExperiment::request(ConfigurationRequest *config)
   config->push_back(CRP("save_every", "Save policy to 'output-run<run>-*.dat' at the end of every run", save_every_, CRP::Configuration, options));
 }
 
+// The only supported build of libgrlx.so is grl_amd/_build.py: it passes the device code through the work-around for a
+// register-allocation bug of ROCm 7.2's compiler.  A plain `hipcc -shared` build carries no tag.
+static void requireFilteredBuild()
+{
+  const char *tag = grlx_build_pipeline();
+  if (!tag || strncmp(tag, "device-asm+mir-exec-prologue-fix/", 33))
+    throw Exception(std::string("libgrlx.so was not built by `python -m grl_amd._build` (pipeline tag '") + (tag ? tag : "") +
+                    "'): its kernels may read stale lanes; rebuild it");
+}
+
 void GrlxOnlineLearningExperiment::configure(Configuration &config)
 {
+  requireFilteredBuild();
   agent_ = config["agent"].ptr();
   test_agent_ = config["test_agent"].ptr();
   environment_ = config["environment"].ptr();
@@ -94,8 +105,8 @@ void GrlxOnlineLearningExperiment::lowerTile(const Configurable *projector, grlx
 { // projector/tile_coding: tilings, memory, safe, resolution, wrapping (tile_coding.cpp:34-42)
   if (!typeIs(projector, "projector/tile_coding"))
     throw bad_param(projector->path() + ": the fused path needs projector/tile_coding");
-  if ((*projector)["safe"].i() > 1)
-    throw bad_param(projector->path() + ":safe (0 and 1 are built; 2 = claim always is not)");
+  if ((*projector)["safe"].i() < 0 || (*projector)["safe"].i() > 2)
+    throw bad_param(projector->path() + ":safe (0 = off, 1 = claim on write, 2 = claim always; tile_coding.cpp:38)");
   memset(t, 0, sizeof(*t));
   t->safe = (*projector)["safe"];
   t->tilings = (*projector)["tilings"];
@@ -337,6 +348,7 @@ void GrlxTileCodingProjector::request(const std::string &role, ConfigurationRequ
 
 void GrlxTileCodingProjector::configure(Configuration &config)
 {
+  requireFilteredBuild();
   memset(&spec_, 0, sizeof(spec_));
   spec_.tilings = config["tilings"];
   spec_.memory = config["memory"];

@@ -845,7 +845,7 @@ def test_walker_fused_bit_exact(grlx, agent):
     r.close()
 
 
-def test_bench_two_ranks_share_the_replica_range(grlx):
+def _bench_two_ranks(extra, timeout=900):
     """bench.py launched as the driver launches it (torch.distributed.run, one process per rank);
     on this one-GPU box both ranks use the same device and gloo stands in for RCCL."""
     import json, socket, subprocess, sys
@@ -854,15 +854,54 @@ def test_bench_two_ranks_share_the_replica_range(grlx):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--backend", "gloo", "--replicas", "256", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return json.loads(line)
+
+
+def test_bench_two_ranks_share_the_replica_range(grlx):
+    out = _bench_two_ranks(["--steps", "3", "--warmup", "1", "--replicas", "256", "--no-secondary"])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["env_steps_per_step"] == 2 * 256 * 1100
-    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert out["curve_replicas"] == 512                                   # the all-reduced curve counts both ranks' replicas
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
+
+
+@pytest.mark.parametrize("workload,replicas", [("cart_pole_ac", 64), ("acrobot_q", 64), ("compass_walker_q", 64), ("acrobot_walker", 64)])
+def test_bench_every_rollout_workload_on_two_ranks(grlx, workload, replicas):
+    """BASELINE configs[2] and [3] have a multi-rank entry point: contiguous replica ids per rank, one all-reduce of the
+    curve statistics, env-steps counted by the devices and summed over the ranks."""
+    out = _bench_two_ranks(["--workload", workload, "--steps", "2", "--warmup", "1", "--replicas", str(replicas)])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["workload"] == workload
+    assert out["replicas_per_gpu"] == replicas and out["learn_steps"] > 0 and out["test_steps"] >= 0
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_learn_step"}
+    if workload == "acrobot_walker":
+        assert [p["graph"] for p in out["parts"]] == ["acrobot_q", "compass_walker_q"]
+        assert [p["replicas"] for p in out["parts"]] == [replicas // 2, replicas // 2]
+        assert all(p["curve_replicas"] == replicas for p in out["parts"])   # 2 ranks x replicas/2 per graph
+        assert "both halves" in out["parallelism"]
+    else:
+        assert out["curve_replicas"] == 2 * replicas
+
+
+def test_bench_batch_path_on_two_ranks(grlx):
+    """BASELINE configs[4]: replicas only -- each rank runs its own independent-seed experiments, the per-batch test
+    returns are all-reduced."""
+    out = _bench_two_ranks(["--workload", "pendulum_fqi_ann", "--replicas", "2", "--fqi-batch-size", "2000", "--fqi-epochs", "20"])
+    assert out["n_gpus"] == 2 and out["unit"] == "sample-epochs/s" and out["value"] > 0
+    assert out["curve_replicas"] == 4 and out["roofline"]["bound"] == "valu" and "replicas only" in out["parallelism"]
+
+
+def test_bench_default_line_with_all_secondaries_on_two_ranks(grlx):
+    """What the driver's scaling run launches (no --workload): the headline plus every other configuration, all sharded."""
+    out = _bench_two_ranks(["--steps", "2", "--warmup", "1", "--replicas", "128", "--secondary-replicas", "32", "--fqi-replicas", "1",
+                            "--fqi-batch-size", "2000", "--fqi-epochs", "20"], timeout=1500)
+    assert out["n_gpus"] == 2 and out["metric"].startswith("env-steps/sec")
+    names = [s["workload"] for s in out["secondary"]]
+    assert names == ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker", "pendulum_fqi_ann"]
+    assert all(s["n_gpus"] == 2 and s["value"] > 0 and "roofline" in s for s in out["secondary"])
 
 
 # ------------------------------------------------ BASELINE.json full sizes ---
