@@ -55,7 +55,8 @@ struct FqiParams {
   double  *in, *next_obs, *reward, *targets;        // [R][cap][...]
   int32_t *absorbing;
   double  *net;                                     // [R][4][P]: params, eta, Delta (unused), prev_Delta
-  double  *partial;                                 // [R][chunks_cap][P + 1]
+  double  *vL;                                      // [R][64][P + 1]: the 64 partial sums of level 2, per epoch
+  unsigned int *sync;                               // [R][4]: arrival counter of the replica's blocks (16-byte slots), zeroed per launch
   double  *row_reward;                              // [R][max_rows]
   int64_t *row_batch, *row_transitions;
   int32_t  max_rows;
@@ -212,113 +213,181 @@ __global__ __launch_bounds__(256) void fqi_targets_kernel(FqiParams F, int first
   }
 }
 
-__device__ __forceinline__ double shfl_down_f64(double v, int off)
-{
-  return __shfl_down(v, off, 64);
+// ---------------------------------------------------------------------------------------------------------------
+// The epochs of one iteration in ONE launch: `fqi_epochs_kernel`.
+//
+// An epoch = the gradient of every stored transition (ann.cpp:224-263), summed, and one RPROP step (ann.cpp:186-192).  The
+// specification's sum (oracle/fqi.c) is a fixed tree: level 1 = a chunk of 64 samples in sample order; level 2 = 64 partial
+// sums per parameter, the L-th over the chunks L, L+64, L+128, ... in this order; level 3 = v[L] += v[L + off], off = 32..1.
+// Level 2 is the mapping: wave (replica r, L) walks ITS chunks in order and keeps its partial sums in registers -- no
+// per-chunk sums ever reach memory (round 2 wrote and re-read 41 MB of them per epoch at 16 x 200 000 transitions, in two
+// launches per epoch whose dispatch gaps were a quarter of the time).  A block = 4 waves = 4 consecutive L of one replica;
+// 16 blocks per replica; 16 replicas fill the 256 CUs with one block each (92 KB of LDS per block: four factor tiles).
+// Per epoch the 64 waves of a replica meet twice (agent-scope hand-off, cdna_hip_programming.md Guideline 16):
+//   1. every wave publishes its 102 partial sums (write-through stores), the block's leader adds 1 to the replica's
+//      arrival counter and polls it; behind an agent-scope acquire the block's waves take 1-2 parameters each: lane l loads
+//      partial sum l, the tree runs in the wave (v += shfl_down(v, off)), lane 0 makes the RPROP step;
+//   2. same hand-off for the 101 new parameters, which every block then reloads into LDS.
+// The replicas never wait for each other.  All blocks of a launch must be resident (they spin on each other): the launch is
+// cooperative (the runtime refuses a grid that does not fit) and every spin is bounded -- a wait that runs out raises
+// ST_SYNC_TIMEOUT and the block leaves, so the grid always drains.
+typedef __attribute__((address_space(1))) unsigned int fqi_gu32;
+typedef __attribute__((address_space(1))) unsigned long long fqi_gu64;
+#define FQI_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr uint32_t ST_SYNC_TIMEOUT = 32u;
+constexpr unsigned kFqiSpinLimit = 4u << 20;            // x (s_sleep 2 + one L2 round trip) = seconds
+
+__device__ __forceinline__ void fqi_publish(double *p, double x)
+{ // write-through (sc1) 8-byte store: visible to other XCDs without a release fence once drained
+  __hip_atomic_store((fqi_gu64 *)p, (unsigned long long)__double_as_longlong(x), FQI_RLX_AGENT);
 }
 
-// one epoch, part 1 (ann.cpp:224-263 over every sample): block = one wave = a chunk of 64 samples, lane = sample for the
-// forward / backward pass; the lanes then leave their factors (inputs, hidden deltas, activations, output delta: 44
-// doubles, plus a constant 1) in LDS and turn into one lane per PARAMETER, which forms the per-sample products and adds
-// them in sample order -- level 1 of the specification's reduction.  partial[r][chunk][0..P] (P = squared error).
+// All threads of the block call this after their publishing stores.  Returns false when the wait timed out.
+__device__ __forceinline__ bool fqi_meet(unsigned int *counter, unsigned target, int *sh_ok)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
+  __syncthreads();                                       // ... before the leader signals for all of them
+  if (threadIdx.x == 0)
+  {
+    __hip_atomic_fetch_add((fqi_gu32 *)counter, 1u, FQI_RLX_AGENT);
+    bool ok = true;
+    for (unsigned spins = 0; __hip_atomic_load((fqi_gu32 *)counter, FQI_RLX_AGENT) < target;)
+    {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kFqiSpinLimit) { ok = false; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire after the match: drops this CU's stale lines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *sh_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *sh_ok != 0;
+}
+
 constexpr int kFqiCols = 2 * 20 + kFqiNIn + 2;       // in[3], d1[H], a[H], d2, 1.0  (H = 20)
+constexpr int kFqiBlocksPerReplica = 16;             // x 4 waves = the 64 partial sums of level 2
 template <int H>
-__global__ __launch_bounds__(64) void fqi_grad_kernel(FqiParams F)
+__global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_first, int epochs)
 {
   static_assert(H == 20, "column layout of the factor tile");
   constexpr int P = (kFqiNIn + 1) * H + H + 1;
   constexpr int C_IN = 0, C_D1 = kFqiNIn, C_A = kFqiNIn + H, C_D2 = kFqiNIn + 2 * H, C_ONE = C_D2 + 1, COLS = C_ONE + 1;
   static_assert(COLS == kFqiCols, "factor tile width");
   __shared__ double sh_net[P];
-  __shared__ double sh_f[64 * COLS];
-  const int r = blockIdx.y;
-  const FqiRep &rep = F.rep[r];
-  if (rep.done) return;
-  const int64_t c0 = (int64_t)blockIdx.x * 64;
-  if (c0 >= rep.n) return;
-  const int lane = threadIdx.x;
-  const double *net = F.net + (size_t)r * 4 * F.P;
-  for (int k = lane; k < P; k += 64) sh_net[k] = net[k];
-  __syncthreads();
-  const int64_t s = c0 + lane;
-  double *row = sh_f + lane * COLS;
-  if (s < rep.n)
+  __shared__ double sh_tile[4][64 * COLS];
+  __shared__ int sh_ok;
+  const int r = r_first + (int)blockIdx.x / kFqiBlocksPerReplica, bl = (int)blockIdx.x % kFqiBlocksPerReplica;
+  if (r >= F.R) return;
+  FqiRep &rep = F.rep[r];
+  if (rep.done) return;                                  // uniform over the replica's 16 blocks
+  const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int L = bl * 4 + w;
+  const int64_t n = rep.n, chunks = (n + 63) / 64;
+  double *net = F.net + (size_t)r * 4 * F.P;
+  double *vL = F.vL + (size_t)r * 64 * (size_t)(P + 1);
+  unsigned int *counter = F.sync + (size_t)r * 4;        // one 16-byte slot per replica
+  double *tile = sh_tile[w];
+  double *row = tile + lane * COLS;
+  // the two factors of the per-sample gradient terms this lane sums (parameters lane and lane + 64; x * 1.0 is exact)
+  int cx[2], cy[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
   {
-    const size_t at = (size_t)r * (size_t)F.cap + (size_t)s;
-    double in[kFqiNIn], a[H];
-#pragma unroll
-    for (int i = 0; i < kFqiNIn; ++i) in[i] = F.in[at * kFqiNIn + i];
-    const double out = ann_forward<H>(sh_net, in, a);
-    const double d2 = out - F.targets[at];
-    const double *W2 = sh_net + (kFqiNIn + 1) * H;
-#pragma unroll
-    for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
-#pragma unroll
-    for (int h = 0; h < H; ++h)
-    {
-      row[C_D1 + h] = (W2[h] * d2) * (a[h] * (1. - a[h]));       // ann.cpp:249 with deviation D2
-      row[C_A + h] = a[h];
-    }
-    row[C_D2] = d2;
-    row[C_ONE] = 1.;
-  }
-  __syncthreads();
-  const int n_here = (int)((rep.n - c0 < 64) ? rep.n - c0 : 64);
-  double *out = F.partial + ((size_t)r * (size_t)F.chunks_cap + (size_t)blockIdx.x) * (size_t)(P + 1);
-  for (int p = lane; p <= P; p += 64)
-  { // the two factors of parameter p's per-sample gradient term (x * 1.0 is exact)
-    int cx, cy;
+    const int p = lane + 64 * k;
     if (p < (kFqiNIn + 1) * H)
     {
       const int h = p / (kFqiNIn + 1), i = p % (kFqiNIn + 1);
-      cx = (i < kFqiNIn) ? C_IN + i : C_ONE;                      // Delta1(i, h) += a0[i] * d1[h]; bias row: d1[h]
-      cy = C_D1 + h;
+      cx[k] = (i < kFqiNIn) ? C_IN + i : C_ONE;                    // Delta1(i, h) += a0[i] * d1[h]; bias row: d1[h]
+      cy[k] = C_D1 + h;
     }
-    else if (p < P - 1) { cx = C_A + (p - (kFqiNIn + 1) * H); cy = C_D2; }   // Delta2(h) += a1[h] * d2
-    else if (p == P - 1) { cx = C_ONE; cy = C_D2; }                          // bias: d2
-    else { cx = C_D2; cy = C_D2; }                                           // squared error (ann.cpp:240)
-    double v = 0.;
-    for (int q = 0; q < n_here; ++q) v += sh_f[q * COLS + cx] * sh_f[q * COLS + cy];
-    out[p] = v;
+    else if (p < P - 1) { cx[k] = C_A + (p - (kFqiNIn + 1) * H); cy[k] = C_D2; }   // Delta2(h) += a1[h] * d2
+    else if (p == P - 1) { cx[k] = C_ONE; cy[k] = C_D2; }                          // bias: d2
+    else { cx[k] = C_D2; cy[k] = C_D2; }                                           // p == P: squared error (ann.cpp:240); beyond: unused
   }
-}
-
-// one epoch, part 2: level 3 of the tree and the RPROP step of ANNRepresentation::finalize (ann.cpp:186-192, 199).
-// Level 3 as specified (oracle/fqi.c): 64 partial sums per parameter, the L-th over the chunks L, L+64, ... in this order, then
-// the tree v[L] += v[L + off], off = 32 .. 1.  One block = 16 parameters x the 64 partial sums: the 16 threads of a row read 16
-// consecutive parameters of one chunk (the chunk sums are stored [chunk][parameter]), so a row is one 128-byte request instead
-// of the 64 separate lines that one wave per parameter used to touch per load (36 -> 9 us per epoch at 16 x 200 000 samples).
-constexpr int kStepCols = 16;
-__global__ __launch_bounds__(kStepCols * 64) void fqi_step_kernel(FqiParams F)
-{
-  __shared__ double sh[64][kStepCols + 1];
-  const int r = blockIdx.y, kx = threadIdx.x, L = threadIdx.y;
-  const int k = blockIdx.x * kStepCols + kx;
-  FqiRep &rep = F.rep[r];
-  if (rep.done) return;                                                      // uniform over the block
-  const int64_t chunks = (rep.n + 63) / 64;
-  const double *part = F.partial + (size_t)r * (size_t)F.chunks_cap * (size_t)(F.P + 1);
-  double v = 0.;
-  if (k <= F.P)
-    for (int64_t c = L; c < chunks; c += 64) v += part[(size_t)c * (size_t)(F.P + 1) + (size_t)k];
-  sh[L][kx] = v;
-  __syncthreads();
-  for (int off = 32; off > 0; off >>= 1)
+  unsigned phase = 0;
+  for (int e = 0; e < epochs; ++e)
   {
-    if (L < off) sh[L][kx] += sh[L + off][kx];
+    for (int k = (int)threadIdx.x; k < P; k += 256) sh_net[k] = net[k];
     __syncthreads();
+    double acc[2] = {0., 0.};
+    for (int64_t c = L; c < chunks; c += 64)
+    { // level 1: one chunk of 64 samples; lane = sample for the forward / backward pass (ann.cpp:224-263)
+      const int64_t s = c * 64 + lane;
+      if (s < n)
+      {
+        const size_t at = (size_t)r * (size_t)F.cap + (size_t)s;
+        double in[kFqiNIn], a[H];
+#pragma unroll
+        for (int i = 0; i < kFqiNIn; ++i) in[i] = F.in[at * kFqiNIn + i];
+        const double out = ann_forward<H>(sh_net, in, a);
+        const double d2 = out - F.targets[at];
+        const double *W2 = sh_net + (kFqiNIn + 1) * H;
+#pragma unroll
+        for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+        {
+          row[C_D1 + h] = (W2[h] * d2) * (a[h] * (1. - a[h]));       // ann.cpp:249 with deviation D2
+          row[C_A + h] = a[h];
+        }
+        row[C_D2] = d2;
+        row[C_ONE] = 1.;
+      }
+      // the tile belongs to this wave alone: its LDS writes are complete before its LDS reads issue (in-order LDS, one wave)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int n_here = (int)((n - c * 64 < 64) ? n - c * 64 : 64);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+      { // the lane turns into one lane per PARAMETER: per-sample products added in sample order (level 1), then level 2
+        double v = 0.;
+        for (int q = 0; q < n_here; ++q) v += tile[q * COLS + cx[k]] * tile[q * COLS + cy[k]];
+        acc[k] += v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // meet 1: the 64 partial sums of every parameter
+    fqi_publish(vL + (size_t)L * (P + 1) + lane, acc[0]);
+    if (lane + 64 <= P) fqi_publish(vL + (size_t)L * (P + 1) + lane + 64, acc[1]);
+    ++phase;
+    if (!fqi_meet(counter, phase * kFqiBlocksPerReplica, &sh_ok))
+    {
+      if (threadIdx.x == 0) atomicOr(&rep.status, ST_SYNC_TIMEOUT);
+      return;
+    }
+    // level 3 and the RPROP step of ANNRepresentation::finalize (ann.cpp:186-192, 199): parameter p = bl + 16 j, wave j mod 4
+    for (int j = w; bl + kFqiBlocksPerReplica * j <= P; j += 4)
+    {
+      const int p = bl + kFqiBlocksPerReplica * j;
+      double v = vL[(size_t)lane * (P + 1) + p];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0)
+      {
+        if (p == P) rep.last_error = v / (double)n;
+        else
+        {
+          const double Delta = 0. + v;                               // Delta was zero before this epoch (ann.cpp:199)
+          double eta = net[F.P + p];
+          const double prev = net[3 * F.P + p];
+          eta = (Delta * prev > 0) ? eta * 1.2 : eta * 0.5;
+          fqi_publish(net + p, net[p] - ((Delta > 0) ? eta : -eta));
+          net[F.P + p] = eta;                                        // eta and prev_Delta: read by this lane only
+          net[3 * F.P + p] = Delta;
+        }
+      }
+    }
+    // meet 2: the new parameters
+    ++phase;
+    if (!fqi_meet(counter, phase * kFqiBlocksPerReplica, &sh_ok))
+    {
+      if (threadIdx.x == 0) atomicOr(&rep.status, ST_SYNC_TIMEOUT);
+      return;
+    }
   }
-  if (L != 0 || k > F.P) return;
-  v = sh[0][kx];
-  if (k == F.P) { rep.last_error = v / (double)rep.n; return; }
-  double *net = F.net + (size_t)r * 4 * F.P;
-  const double Delta = 0. + v;                                               // Delta was zero before this epoch (ann.cpp:199)
-  double eta = net[F.P + k];
-  const double prev = net[3 * F.P + k];
-  eta = (Delta * prev > 0) ? eta * 1.2 : eta * 0.5;
-  net[k] -= (Delta > 0) ? eta : -eta;
-  net[F.P + k] = eta;
-  net[3 * F.P + k] = Delta;
 }
 
 // the test trial after a batch (batch_learning.cpp:141-186): agent/fixed + policy/discrete/q + sampler/greedy; one lane per replica
@@ -392,6 +461,7 @@ struct grlx_fqi_ctx {
   std::vector<void *> bufs;
   uint64_t *r0 = nullptr;
   int batches_run = 0;
+  int replicas_per_launch = 1;       // how many replicas' blocks (16 each) are resident at once
 };
 
 namespace {
@@ -508,7 +578,7 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
       (rc = dev_alloc(ctx, &F.next_obs, R * cap * kFqiD)) != GRLX_OK || (rc = dev_alloc(ctx, &F.reward, R * cap)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.targets, R * cap)) != GRLX_OK || (rc = dev_alloc(ctx, &F.absorbing, R * cap)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.net, R * 4 * (size_t)F.P)) != GRLX_OK ||
-      (rc = dev_alloc(ctx, &F.partial, R * (size_t)F.chunks_cap * (size_t)(F.P + 1))) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.vL, R * 64 * (size_t)(F.P + 1))) != GRLX_OK || (rc = dev_alloc(ctx, &F.sync, R * 4)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.row_reward, R * (size_t)F.max_rows)) != GRLX_OK || (rc = dev_alloc(ctx, &F.row_batch, R * (size_t)F.max_rows)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.row_transitions, R * (size_t)F.max_rows)) != GRLX_OK || (rc = dev_alloc(ctx, &ctx->r0, R)) != GRLX_OK)
   {
@@ -535,6 +605,16 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
     grlx_fqi_destroy(ctx);
     return ffail(GRLX_ERR_HIP, "hipMemcpy failed");
   }
+  {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fqi_epochs_kernel<20>, 256, 0) != hipSuccess || cus * per_cu < kFqiBlocksPerReplica)
+    {
+      grlx_fqi_destroy(ctx);
+      return ffail(GRLX_ERR_HIP, "fqi_epochs_kernel: the device cannot hold the %d resident blocks of one replica", kFqiBlocksPerReplica);
+    }
+    ctx->replicas_per_launch = (cus * per_cu) / kFqiBlocksPerReplica;
+  }
   hipLaunchKernelGGL(fqi_init_kernel, dim3((F.P + 127) / 128, F.R), dim3(128), 0, nullptr, F, ctx->r0);
   if (hipDeviceSynchronize() != hipSuccess)
   {
@@ -560,19 +640,22 @@ int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
   hipStream_t stream = (hipStream_t)stream_;
   const FqiParams &F = ctx->F;
   const int n_after = (ctx->batches_run + 1) * F.batch_size;
-  const int chunks = (n_after + 255) / 256, gchunks = (n_after + 63) / 64;
-  // (the epochs of one iteration captured into a HIP graph and replayed were measured: no gain -- 337 us per epoch either way at
-  // 16 x 200 000 samples, of which the two kernels account for 241; the rest is dispatch and drain of two dependent launches)
+  const int chunks = (n_after + 255) / 256;
   hipLaunchKernelGGL(fqi_generate_kernel, dim3((F.batch_size + 255) / 256, F.R), dim3(256), 0, stream, F);
   hipLaunchKernelGGL(fqi_batch_begin_kernel, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
   for (int ii = 0; ii < ctx->cfg.iterations; ++ii)
   {
     hipLaunchKernelGGL(fqi_iter_begin_kernel, dim3((F.R + 63) / 64), dim3(64), 0, stream, F, ii);
     hipLaunchKernelGGL(fqi_targets_kernel<20>, dim3(chunks, F.R), dim3(256), 0, stream, F, ii == 0 ? 1 : 0);
-    for (int e = 0; e < ctx->cfg.epochs; ++e)
+    // the epochs of the iteration: one cooperative launch per group of replicas that fills the chip (16 blocks per replica)
+    for (int r0 = 0; r0 < F.R; r0 += ctx->replicas_per_launch)
     {
-      hipLaunchKernelGGL(fqi_grad_kernel<20>, dim3(gchunks, F.R), dim3(64), 0, stream, F);
-      hipLaunchKernelGGL(fqi_step_kernel, dim3((F.P + 1 + kStepCols - 1) / kStepCols, F.R), dim3(kStepCols, 64), 0, stream, F);
+      const int nr = (F.R - r0 < ctx->replicas_per_launch) ? F.R - r0 : ctx->replicas_per_launch;
+      FQI_TRY(hipMemsetAsync(F.sync + (size_t)r0 * 4, 0, (size_t)nr * 4 * sizeof(unsigned int), stream));
+      FqiParams Fa = F;
+      int r_first = r0, epochs = ctx->cfg.epochs;
+      void *args[] = {&Fa, &r_first, &epochs};
+      FQI_TRY(hipLaunchCooperativeKernel((const void *)fqi_epochs_kernel<20>, dim3(nr * kFqiBlocksPerReplica), dim3(256), args, 0, stream));
     }
   }
   hipLaunchKernelGGL(fqi_test_kernel<20>, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
@@ -591,6 +674,7 @@ int grlx_fqi_sync(grlx_fqi_ctx *ctx, void *stream)
   for (const FqiRep &r : hr) st |= r.status;
   if (st & ST_DOMAIN) return ffail(GRLX_ERR_DOMAIN, "sin/cos argument outside |x| < 2^20");
   if (st & ST_ROWS_FULL) return ffail(GRLX_ERR_ROWS_FULL, "more batches than max_batches");
+  if (st & ST_SYNC_TIMEOUT) return ffail(GRLX_ERR_HIP, "fqi_epochs_kernel: a wait between the blocks of a replica timed out (were all of its blocks resident?)");
   return GRLX_OK;
 }
 

@@ -7,6 +7,7 @@
  * family serves the graph from the objects' d_type() strings, and fills the grlx_config of include/grlx.h.
  * Errors of the library (GRLX_ERR_INVALID = the reference's bad_param conditions) are re-thrown as grl exceptions.
  */
+#include <cstring>
 #include <fstream>
 #include <iomanip>
 
