@@ -238,8 +238,10 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
     for k, (graph, seeds) in enumerate(parts):
         g = GRAPHS[graph]
         rows_total = ((steps + warmup) * g["trials"]) // TRIALS_PER_STEP          # test_interval 10: one row per 11 trials
-        # two contexts share the GPU: 8 replicas per wave each (2 x 512 waves = one wave per SIMD, both kernels resident at once)
-        cfg = graph_config(graph, len(seeds), rows_total + 1, table_log2, 8 if len(parts) > 1 and len(seeds) >= 8 else 0)
+        # (two contexts sharing the GPU keep the layout grlx_create picks for their batch: forcing 8 replicas per wave to make both
+        # kernels resident at once -- 2 x 512 waves -- was measured: the launch lasts as long as the walkers' longest episodes either
+        # way, so it only idles half the SIMDs; with 4 replicas per wave the hardware backfills SIMDs as the acrobot's waves retire)
+        cfg = graph_config(graph, len(seeds), rows_total + 1, table_log2)
         stream = main_stream if len(parts) == 1 else torch.cuda.Stream()
         ctx.append(dict(graph=graph, g=g, seeds=seeds, runner=grl_amd.Runner(cfg, seeds), stream=stream, rows=rows_total,
                         ev=[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]))

@@ -18,6 +18,10 @@ HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_
            os.path.join("..", "..", "include", "grlx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 TAG_DEFINE = "-DGRLX_BUILD_PIPELINE="
+# per-source device flags.  The batch path runs ONE wave per SIMD (92 KB of LDS per block): nothing but instruction-level parallelism
+# inside the wave hides its f64 latencies, so its translation unit is scheduled for that (the rollout kernels are not: they are
+# scheduled for register pressure).
+SOURCE_FLAGS = {"grlx_fqi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 # The device code is not taken from hipcc as is: it is compiled to assembly together with the compiler's machine code
 # after register allocation, passed through _exec_prologue (a work-around for a register-allocation bug of this
 # compiler, see that file and DESIGN.md section 4.1f: the misplaced copies are FOUND in the machine code and MOVED in the
@@ -30,7 +34,7 @@ FLAGS_FILE = LIB + ".flags"      # the flags the library was built with: a chang
 
 
 def _flags() -> str:
-    return " ".join(FLAGS + os.environ.get("GRLX_EXTRA_FLAGS", "").split() + [PIPELINE])
+    return " ".join(FLAGS + os.environ.get("GRLX_EXTRA_FLAGS", "").split() + [PIPELINE] + [k + ":" + " ".join(v) for k, v in sorted(SOURCE_FLAGS.items())])
 
 
 def _stale() -> bool:
@@ -69,6 +73,7 @@ def _build_hip_object(hipcc, src, tmp, flags, verbose, report):
     """One .hip source -> host object carrying the filtered device code."""
     from . import _exec_prologue
     stem = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0])
+    flags = flags + SOURCE_FLAGS.get(os.path.basename(src), [])
     cmd = [hipcc] + flags + ["--cuda-device-only", "-S", src, "-o", stem + ".s", "-mllvm", "-print-after=stack-slot-coloring"]
     if verbose:
         print(" ".join(cmd), "2>", stem + ".mir")

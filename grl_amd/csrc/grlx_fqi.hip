@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,29 +56,41 @@ struct FqiParams {
   double  *in, *next_obs, *reward, *targets;        // [R][cap][...]
   int32_t *absorbing;
   double  *net;                                     // [R][4][P]: params, eta, Delta (unused), prev_Delta
-  double  *vL;                                      // [R][64][P + 1]: the 64 partial sums of level 2, per epoch
+  double  *vL;                                      // [2][R][P + 1][64]: the 64 partial sums of level 2 per parameter, double-buffered by epoch parity
+  unsigned long long *stamps;                       // diagnostic (GRLX_FQI_STAMPS=1): [R][16][4 epochs][8] shader-clock stamps, else null
   unsigned int *sync;                               // [R][4]: arrival counter of the replica's blocks (16-byte slots), zeroed per launch
   double  *row_reward;                              // [R][max_rows]
   int64_t *row_batch, *row_transitions;
   int32_t  max_rows;
 };
 
-// ANNRepresentation::read (ann.cpp:133-160): net input ((w0 a0 + w1 a1) + w2 a2) + bias, logistic hidden layer, linear output
+// ANNRepresentation::read (ann.cpp:133-160): net input ((w0 a0 + w1 a1) + w2 a2) + bias, logistic hidden layer, linear output.
+// Written stage by stage over the H hidden units (per unit the operations and their order are those of the scalar text:
+// oracle/fqi.c ann_forward): H independent chains for the wave to overlap -- a branchy exp per unit serialises them.
 template <int H>
 __device__ __forceinline__ double ann_forward(const double *w, const double (&in)[kFqiNIn], double *a_out)
 {
   const double *W2 = w + (kFqiNIn + 1) * H;
-  double out = 0;
+  double net[H], e[H];
 #pragma unroll
   for (int h = 0; h < H; ++h)
   {
-    double net = 0;
+    double v = 0;
 #pragma unroll
-    for (int i = 0; i < kFqiNIn; ++i) net += w[h * (kFqiNIn + 1) + i] * in[i];
-    net += w[h * (kFqiNIn + 1) + kFqiNIn];
-    const double a = 1. / (1. + pexp(-net));
-    if (a_out) a_out[h] = a;
-    out += W2[h] * a;
+    for (int i = 0; i < kFqiNIn; ++i) v += w[h * (kFqiNIn + 1) + i] * in[i];
+    v += w[h * (kFqiNIn + 1) + kFqiNIn];
+    net[h] = -v;
+  }
+  pexp_batch<H>(net, e);
+  double out = 0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) net[h] = 1. + e[h];
+  pdiv_batch<H>(1., net, e);                                    // a = 1 / (1 + exp(-net)), ann.h:108-111
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+  {
+    if (a_out) a_out[h] = e[h];
+    out += W2[h] * e[h];
   }
   out += W2[H];
   return out;
@@ -222,12 +235,16 @@ __global__ __launch_bounds__(256) void fqi_targets_kernel(FqiParams F, int first
 // Level 2 is the mapping: wave (replica r, L) walks ITS chunks in order and keeps its partial sums in registers -- no
 // per-chunk sums ever reach memory (round 2 wrote and re-read 41 MB of them per epoch at 16 x 200 000 transitions, in two
 // launches per epoch whose dispatch gaps were a quarter of the time).  A block = 4 waves = 4 consecutive L of one replica;
-// 16 blocks per replica; 16 replicas fill the 256 CUs with one block each (92 KB of LDS per block: four factor tiles).
-// Per epoch the 64 waves of a replica meet twice (agent-scope hand-off, cdna_hip_programming.md Guideline 16):
-//   1. every wave publishes its 102 partial sums (write-through stores), the block's leader adds 1 to the replica's
-//      arrival counter and polls it; behind an agent-scope acquire the block's waves take 1-2 parameters each: lane l loads
-//      partial sum l, the tree runs in the wave (v += shfl_down(v, off)), lane 0 makes the RPROP step;
-//   2. same hand-off for the 101 new parameters, which every block then reloads into LDS.
+// 16 blocks per replica; 16 replicas fill the 256 CUs with one block each (93 KB of LDS per block: four factor tiles).
+// One wave per SIMD means nothing but the wave's own instruction-level parallelism hides latency: the forward pass is
+// written stage by stage over the 20 hidden units (pexp_batch, pdiv_batch: grlx_math.h), the next chunk's inputs are
+// loaded while the current one is computed.
+// Once per epoch the 64 waves of a replica meet (agent-scope hand-off, cdna_hip_programming.md Guideline 16): every wave
+// publishes its 102 partial sums (write-through stores, double-buffered by epoch parity), the block's leader adds 1 to the
+// replica's arrival counter and polls it; behind an agent-scope acquire EVERY block runs level 3 and the RPROP step for
+// ALL parameters itself (wave w: parameters w, w+4, ...: lane l loads partial sum l, the tree runs in the wave, lane 0
+// steps).  The 16 copies are bit-identical, so the network, eta and the previous gradient live in each block's LDS for
+// the whole launch and nobody waits for a second hand-off; block 0 of the replica writes them back at the end.
 // The replicas never wait for each other.  All blocks of a launch must be resident (they spin on each other): the launch is
 // cooperative (the runtime refuses a grid that does not fit) and every spin is bounded -- a wait that runs out raises
 // ST_SYNC_TIMEOUT and the block leaves, so the grid always drains.
@@ -253,7 +270,7 @@ __device__ __forceinline__ bool fqi_meet(unsigned int *counter, unsigned target,
     bool ok = true;
     for (unsigned spins = 0; __hip_atomic_load((fqi_gu32 *)counter, FQI_RLX_AGENT) < target;)
     {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > kFqiSpinLimit) { ok = false; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire after the match: drops this CU's stale lines
@@ -264,6 +281,17 @@ __device__ __forceinline__ bool fqi_meet(unsigned int *counter, unsigned target,
   return *sh_ok != 0;
 }
 
+// lane i of a row of 16 receives the value of lane i + N of the same row (DPP row_shl: N); lanes past the row's end keep their own
+template <int N>
+__device__ __forceinline__ double fqi_row_shl(double v)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)b, hi = (int)(b >> 32);
+  const int rlo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xF, 0xF, false);
+  const int rhi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
+}
+
 constexpr int kFqiCols = 2 * 20 + kFqiNIn + 2;       // in[3], d1[H], a[H], d2, 1.0  (H = 20)
 constexpr int kFqiBlocksPerReplica = 16;             // x 4 waves = the 64 partial sums of level 2
 template <int H>
@@ -272,22 +300,29 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
   static_assert(H == 20, "column layout of the factor tile");
   constexpr int P = (kFqiNIn + 1) * H + H + 1;
   constexpr int C_IN = 0, C_D1 = kFqiNIn, C_A = kFqiNIn + H, C_D2 = kFqiNIn + 2 * H, C_ONE = C_D2 + 1, COLS = C_ONE + 1;
+  constexpr int TREES = (P + 1 + 3) / 4;                 // level-3 trees per wave: parameters w, w + 4, ... (and the squared error)
+  constexpr int GROUPS = (TREES + 3) / 4;                // ... taken four at a time, one per row of 16 lanes
   static_assert(COLS == kFqiCols, "factor tile width");
-  __shared__ double sh_net[P];
+  __shared__ double sh_net[P], sh_eta[P], sh_prev[P];
   __shared__ double sh_tile[4][64 * COLS];
   __shared__ int sh_ok;
   const int r = r_first + (int)blockIdx.x / kFqiBlocksPerReplica, bl = (int)blockIdx.x % kFqiBlocksPerReplica;
-  if (r >= F.R) return;
+  if (r >= F.R || epochs <= 0) return;
   FqiRep &rep = F.rep[r];
   if (rep.done) return;                                  // uniform over the replica's 16 blocks
   const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int L = bl * 4 + w;
   const int64_t n = rep.n, chunks = (n + 63) / 64;
   double *net = F.net + (size_t)r * 4 * F.P;
-  double *vL = F.vL + (size_t)r * 64 * (size_t)(P + 1);
   unsigned int *counter = F.sync + (size_t)r * 4;        // one 16-byte slot per replica
   double *tile = sh_tile[w];
   double *row = tile + lane * COLS;
+  for (int k = (int)threadIdx.x; k < P; k += 256)
+  {
+    sh_net[k] = net[k];
+    sh_eta[k] = net[F.P + k];
+    sh_prev[k] = net[3 * F.P + k];
+  }
   // the two factors of the per-sample gradient terms this lane sums (parameters lane and lane + 64; x * 1.0 is exact)
   int cx[2], cy[2];
 #pragma unroll
@@ -304,23 +339,45 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
     else if (p == P - 1) { cx[k] = C_ONE; cy[k] = C_D2; }                          // bias: d2
     else { cx[k] = C_D2; cy[k] = C_D2; }                                           // p == P: squared error (ann.cpp:240); beyond: unused
   }
-  unsigned phase = 0;
+  row[C_ONE] = 1.;                                        // the constant factor of the bias terms: written once
+  const size_t base = (size_t)r * (size_t)F.cap;
+  double last_error = 0.;
+  __syncthreads();
+#define FQI_STAMP(k) do { if (F.stamps && e < 4 && threadIdx.x == 0) F.stamps[(((size_t)r * 16 + bl) * 4 + e) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   for (int e = 0; e < epochs; ++e)
   {
-    for (int k = (int)threadIdx.x; k < P; k += 256) sh_net[k] = net[k];
-    __syncthreads();
+    FQI_STAMP(0);
     double acc[2] = {0., 0.};
+    // inputs of the wave's first chunk; inside the loop the next chunk's are requested before the current one is worked on
+    double nin[kFqiNIn] = {0., 0., 0.}, ntarget = 0.;
+    if (L < chunks && (int64_t)L * 64 + lane < n)
+    {
+      const size_t at = base + (size_t)L * 64 + (size_t)lane;
+#pragma unroll
+      for (int i = 0; i < kFqiNIn; ++i) nin[i] = F.in[at * kFqiNIn + i];
+      ntarget = F.targets[at];
+    }
     for (int64_t c = L; c < chunks; c += 64)
     { // level 1: one chunk of 64 samples; lane = sample for the forward / backward pass (ann.cpp:224-263)
       const int64_t s = c * 64 + lane;
+      double in[kFqiNIn];
+#pragma unroll
+      for (int i = 0; i < kFqiNIn; ++i) in[i] = nin[i];
+      const double target = ntarget;
+      if (c + 64 < chunks && s + 64 * 64 < n)
+      {
+        const size_t at = base + (size_t)s + 64 * 64;
+#pragma unroll
+        for (int i = 0; i < kFqiNIn; ++i) nin[i] = F.in[at * kFqiNIn + i];
+        ntarget = F.targets[at];
+      }
+      if (c == L) FQI_STAMP(5);
       if (s < n)
       {
-        const size_t at = (size_t)r * (size_t)F.cap + (size_t)s;
-        double in[kFqiNIn], a[H];
-#pragma unroll
-        for (int i = 0; i < kFqiNIn; ++i) in[i] = F.in[at * kFqiNIn + i];
+        double a[H];
         const double out = ann_forward<H>(sh_net, in, a);
-        const double d2 = out - F.targets[at];
+        if (c == L) FQI_STAMP(6);
+        const double d2 = out - target;
         const double *W2 = sh_net + (kFqiNIn + 1) * H;
 #pragma unroll
         for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
@@ -331,62 +388,145 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
           row[C_A + h] = a[h];
         }
         row[C_D2] = d2;
-        row[C_ONE] = 1.;
       }
       // the tile belongs to this wave alone: its LDS writes are complete before its LDS reads issue (in-order LDS, one wave)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int n_here = (int)((n - c * 64 < 64) ? n - c * 64 : 64);
+      if (c == L) FQI_STAMP(7);
+      { // the lane turns into one lane per PARAMETER (two of them): per-sample products added in sample order (level 1), then level 2
+        double v0 = 0., v1 = 0.;
+        if (n_here == 64)
+        { // 256 LDS reads per wave and chunk: issued as plain ds_read_b64 (2 LDS cycles each; the compiler pairs neighbouring rows
+          // into ds_read2_b64, 8 cycles per pair: MI355X_MICROARCH.md, LDS table), three samples (12 reads) per batch, the next
+          // batch in flight while the current one is multiplied and added (lgkmcnt counts at most 15 operations)
+          double x[2][12];
+#define FQI_RD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define FQI_ISSUE(buf, q0)                                                                                                \
+          _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                                    \
+          {                                                                                                               \
+            FQI_RD(x[buf][4 * t + 0], a_cx0, ((q0) + t) * COLS * 8); FQI_RD(x[buf][4 * t + 1], a_cy0, ((q0) + t) * COLS * 8); \
+            FQI_RD(x[buf][4 * t + 2], a_cx1, ((q0) + t) * COLS * 8); FQI_RD(x[buf][4 * t + 3], a_cy1, ((q0) + t) * COLS * 8); \
+          }
+#define FQI_USE(buf, cnt)                                                                                                 \
+          _Pragma("unroll") for (int t = 0; t < (cnt); ++t)                                                                \
+          {                                                                                                               \
+            v0 += x[buf][4 * t + 0] * x[buf][4 * t + 1];                                                                  \
+            v1 += x[buf][4 * t + 2] * x[buf][4 * t + 3];                                                                  \
+          }
+#define FQI_WAIT(buf, n_out)                                                                                              \
+          asm volatile("s_waitcnt lgkmcnt(" #n_out ")"                                                                    \
+                       : "+v"(x[buf][0]), "+v"(x[buf][1]), "+v"(x[buf][2]), "+v"(x[buf][3]), "+v"(x[buf][4]), "+v"(x[buf][5]),   \
+                         "+v"(x[buf][6]), "+v"(x[buf][7]), "+v"(x[buf][8]), "+v"(x[buf][9]), "+v"(x[buf][10]), "+v"(x[buf][11]))
+          const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) double *)tile;
+          const unsigned a_cx0 = lds0 + cx[0] * 8, a_cy0 = lds0 + cy[0] * 8, a_cx1 = lds0 + cx[1] * 8, a_cy1 = lds0 + cy[1] * 8;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the tile writes of this wave have left for the LDS
+          FQI_ISSUE(0, 0);
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-      { // the lane turns into one lane per PARAMETER: per-sample products added in sample order (level 1), then level 2
-        double v = 0.;
-        for (int q = 0; q < n_here; ++q) v += tile[q * COLS + cx[k]] * tile[q * COLS + cy[k]];
-        acc[k] += v;
+          for (int b = 0; b < 21; ++b)
+          { // batch b = samples 3b .. 3b+2 (the 22nd batch is the single sample 63)
+            if (b & 1)
+            {
+              if (b < 20) { FQI_ISSUE(0, 3 * (b + 1)); FQI_WAIT(1, 12); }
+              else { FQI_RD(x[0][0], a_cx0, 63 * COLS * 8); FQI_RD(x[0][1], a_cy0, 63 * COLS * 8); FQI_RD(x[0][2], a_cx1, 63 * COLS * 8); FQI_RD(x[0][3], a_cy1, 63 * COLS * 8); FQI_WAIT(1, 4); }
+              FQI_USE(1, 3);
+            }
+            else
+            {
+              if (b < 20) { FQI_ISSUE(1, 3 * (b + 1)); FQI_WAIT(0, 12); }
+              else { FQI_RD(x[1][0], a_cx0, 63 * COLS * 8); FQI_RD(x[1][1], a_cy0, 63 * COLS * 8); FQI_RD(x[1][2], a_cx1, 63 * COLS * 8); FQI_RD(x[1][3], a_cy1, 63 * COLS * 8); FQI_WAIT(0, 4); }
+              FQI_USE(0, 3);
+            }
+          }
+          FQI_WAIT(1, 0);                                          // b = 20 is even: the last sample went into buffer 1
+          FQI_USE(1, 1);
+#undef FQI_RD
+#undef FQI_ISSUE
+#undef FQI_USE
+#undef FQI_WAIT
+        }
+        else
+          for (int q = 0; q < n_here; ++q)
+          {
+            v0 += tile[q * COLS + cx[0]] * tile[q * COLS + cy[0]];
+            v1 += tile[q * COLS + cx[1]] * tile[q * COLS + cy[1]];
+          }
+        acc[0] += v0;
+        acc[1] += v1;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // meet 1: the 64 partial sums of every parameter
-    fqi_publish(vL + (size_t)L * (P + 1) + lane, acc[0]);
-    if (lane + 64 <= P) fqi_publish(vL + (size_t)L * (P + 1) + lane + 64, acc[1]);
-    ++phase;
-    if (!fqi_meet(counter, phase * kFqiBlocksPerReplica, &sh_ok))
+    FQI_STAMP(1);
+    // the hand-off: the 64 partial sums of every parameter (buffer e mod 2: a block that is one epoch ahead writes the other one)
+    double *vL = F.vL + ((size_t)(e & 1) * (size_t)F.R + (size_t)r) * 64 * (size_t)(P + 1);
+    fqi_publish(vL + (size_t)lane * 64 + L, acc[0]);                 // [parameter][L]: the 64 leaves of a tree are 512 contiguous bytes
+    if (lane + 64 <= P) fqi_publish(vL + (size_t)(lane + 64) * 64 + L, acc[1]);
+    if (!fqi_meet(counter, (unsigned)(e + 1) * kFqiBlocksPerReplica, &sh_ok))
     {
       if (threadIdx.x == 0) atomicOr(&rep.status, ST_SYNC_TIMEOUT);
       return;
     }
-    // level 3 and the RPROP step of ANNRepresentation::finalize (ann.cpp:186-192, 199): parameter p = bl + 16 j, wave j mod 4
-    for (int j = w; bl + kFqiBlocksPerReplica * j <= P; j += 4)
-    {
-      const int p = bl + kFqiBlocksPerReplica * j;
-      double v = vL[(size_t)lane * (P + 1) + p];
+    FQI_STAMP(2);
+    // level 3 and the RPROP step of ANNRepresentation::finalize (ann.cpp:186-192, 199), in every block for all parameters
+    // Four trees at a time, one per row of 16 lanes: lane j of row t loads leaves j, j+32, j+16, j+48 of its tree and adds them as
+    // levels 32 and 16 do -- (v[j] + v[j+32]) + (v[j+16] + v[j+48]) --, levels 8..1 are row shifts (DPP); lane 0 of the row holds the
+    // sum and steps the parameter, whose eta / previous gradient live in LDS beside the network.
+    const int rowi = lane >> 4, j16 = lane & 15;
+    double leaf[GROUPS][4];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0)
+    for (int g = 0; g < GROUPS; ++g)
+    {
+      const int p = w + 4 * (4 * g + rowi);
+      const double *t = vL + (size_t)(p <= P ? p : P) * 64 + j16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) leaf[g][k] = t[16 * k];
+    }
+    double st_eta[GROUPS], st_prev[GROUPS], st_net[GROUPS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g)
+    {
+      const int p = w + 4 * (4 * g + rowi), pc = p < P ? p : 0;
+      st_eta[g] = sh_eta[pc]; st_prev[g] = sh_prev[pc]; st_net[g] = sh_net[pc];
+    }
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g)
+    {
+      double v = (leaf[g][0] + leaf[g][2]) + (leaf[g][1] + leaf[g][3]);
+      v += fqi_row_shl<8>(v);
+      v += fqi_row_shl<4>(v);
+      v += fqi_row_shl<2>(v);
+      v += fqi_row_shl<1>(v);
+      const int p = w + 4 * (4 * g + rowi);
+      if (j16 == 0)
       {
-        if (p == P) rep.last_error = v / (double)n;
-        else
+        if (p == P) last_error = v / (double)n;
+        else if (p < P)
         {
           const double Delta = 0. + v;                               // Delta was zero before this epoch (ann.cpp:199)
-          double eta = net[F.P + p];
-          const double prev = net[3 * F.P + p];
-          eta = (Delta * prev > 0) ? eta * 1.2 : eta * 0.5;
-          fqi_publish(net + p, net[p] - ((Delta > 0) ? eta : -eta));
-          net[F.P + p] = eta;                                        // eta and prev_Delta: read by this lane only
-          net[3 * F.P + p] = Delta;
+          const double eta = (Delta * st_prev[g] > 0) ? st_eta[g] * 1.2 : st_eta[g] * 0.5;
+          sh_net[p] = st_net[g] - ((Delta > 0) ? eta : -eta);
+          sh_eta[p] = eta;
+          sh_prev[p] = Delta;
         }
       }
     }
-    // meet 2: the new parameters
-    ++phase;
-    if (!fqi_meet(counter, phase * kFqiBlocksPerReplica, &sh_ok))
+    FQI_STAMP(3);
+    __syncthreads();
+    FQI_STAMP(4);
+  }
+#undef FQI_STAMP
+  if (bl == 0)
+  { // the 16 blocks hold the same bits: one of them writes the state back for the kernels and launches that follow
+    for (int k = (int)threadIdx.x; k < P; k += 256)
     {
-      if (threadIdx.x == 0) atomicOr(&rep.status, ST_SYNC_TIMEOUT);
-      return;
+      net[k] = sh_net[k];
+      net[F.P + k] = sh_eta[k];
+      net[3 * F.P + k] = sh_prev[k];
     }
+    if ((lane & 15) == 0 && w + 4 * (4 * ((P - w) / 16) + (lane >> 4)) == P) rep.last_error = last_error;   // the row that ran the tree of p == P
   }
 }
 
@@ -578,7 +718,7 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
       (rc = dev_alloc(ctx, &F.next_obs, R * cap * kFqiD)) != GRLX_OK || (rc = dev_alloc(ctx, &F.reward, R * cap)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.targets, R * cap)) != GRLX_OK || (rc = dev_alloc(ctx, &F.absorbing, R * cap)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.net, R * 4 * (size_t)F.P)) != GRLX_OK ||
-      (rc = dev_alloc(ctx, &F.vL, R * 64 * (size_t)(F.P + 1))) != GRLX_OK || (rc = dev_alloc(ctx, &F.sync, R * 4)) != GRLX_OK ||
+      (rc = dev_alloc(ctx, &F.vL, 2 * R * 64 * (size_t)(F.P + 1))) != GRLX_OK || (rc = dev_alloc(ctx, &F.sync, R * 4)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.row_reward, R * (size_t)F.max_rows)) != GRLX_OK || (rc = dev_alloc(ctx, &F.row_batch, R * (size_t)F.max_rows)) != GRLX_OK ||
       (rc = dev_alloc(ctx, &F.row_transitions, R * (size_t)F.max_rows)) != GRLX_OK || (rc = dev_alloc(ctx, &ctx->r0, R)) != GRLX_OK)
   {
@@ -615,6 +755,12 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
     }
     ctx->replicas_per_launch = (cus * per_cu) / kFqiBlocksPerReplica;
   }
+  if (const char *st = getenv("GRLX_FQI_STAMPS"))
+    if (st[0] && st[0] != '0' && (rc = dev_alloc(ctx, &F.stamps, R * 16 * 4 * 8)) != GRLX_OK)
+    {
+      grlx_fqi_destroy(ctx);
+      return rc;
+    }
   hipLaunchKernelGGL(fqi_init_kernel, dim3((F.P + 127) / 128, F.R), dim3(128), 0, nullptr, F, ctx->r0);
   if (hipDeviceSynchronize() != hipSuccess)
   {
@@ -708,6 +854,15 @@ int grlx_fqi_get_transitions(grlx_fqi_ctx *ctx, int replica, int first, int coun
   if (next_obs) FQI_TRY(hipMemcpy(next_obs, ctx->F.next_obs + at * kFqiD, sizeof(double) * (size_t)count * kFqiD, hipMemcpyDeviceToHost));
   if (reward) FQI_TRY(hipMemcpy(reward, ctx->F.reward + at, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
   if (targets) FQI_TRY(hipMemcpy(targets, ctx->F.targets + at, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+// diagnostic, not part of include/grlx.h: the stamps of the LAST fqi_epochs_kernel launch (GRLX_FQI_STAMPS=1 at create)
+int grlx_fqi_debug_stamps(grlx_fqi_ctx *ctx, unsigned long long *out, int count)
+{
+  if (!ctx || !out || !ctx->F.stamps || count != ctx->F.R * 16 * 4 * 8) return ffail(GRLX_ERR_INVALID, "no stamps (GRLX_FQI_STAMPS=1 at create; count = R * 512)");
+  FQI_TRY(hipDeviceSynchronize());
+  FQI_TRY(hipMemcpy(out, ctx->F.stamps, sizeof(unsigned long long) * (size_t)count, hipMemcpyDeviceToHost));
   return GRLX_OK;
 }
 

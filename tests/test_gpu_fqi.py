@@ -61,6 +61,30 @@ def test_fqi_many_chunks_bit_exact(grlx):
     _both(grlx, [7], 1, batch_size=20000, iterations=2, epochs=12)
 
 
+def test_fqi_several_rounds_of_chunks_on_several_replicas_bit_exact(grlx):
+    """The persistent epochs kernel at a size where every wave walks several chunks (level 2 of the sum in registers): two
+    batches of 6500 transitions -- the second rebuild runs over 13000 stored transitions = 204 chunks, i.e. 3-4 chunks per
+    wave with a ragged last one -- on five replicas (80 resident blocks that meet once per epoch), 2 x 25 epochs each."""
+    _both(grlx, [11, 12, 13, 14, 15], 2, batch_size=6500, iterations=2, epochs=25)
+
+
+def test_fqi_more_replicas_than_one_launch_holds(grlx):
+    """18 replicas need 288 resident blocks: more than the 256 CUs hold, so the epochs run as two cooperative launches
+    (16 + 2 replicas) per iteration; results per replica do not depend on the grouping."""
+    seeds = list(range(21, 39))
+    cfg = grlx.pendulum_fqi_config(len(seeds), max_batches=1, batch_size=640, iterations=2, epochs=6)
+    r = grlx.FqiRunner(cfg, seeds)
+    r.run_batch()
+    r.sync()
+    for k in (0, 15, 16, 17):
+        e = ob.FqiExperiment(ob.pendulum_fqi_spec(batch_size=640, iterations=2, epochs=6), seed=seeds[k])
+        row = e.run_batch()
+        assert_bit_equal(r.params(k), e.params(), f"replica {k}: network parameters")
+        assert_bit_equal(r.rows(k, 1)[2], [row.reward], f"replica {k}: return")
+        e.close()
+    r.close()
+
+
 def test_fqi_iteration_loop_stops_per_replica(grlx):
     """gamma = 0: the targets are the rewards and the second iteration changes nothing (fqi.cpp:213); the stop is taken
     on the device, per replica, without a host round trip."""
