@@ -708,6 +708,54 @@ int grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2)
   return grow_tables(ctx, new_log2);
 }
 
+// Experiment::reset() between two runs of one process (online_learning.cpp:307-308 -> {action: reset} over the experiment's subtree):
+// every parameter is drawn again from the CONTINUING thread-local stream (linear.cpp:104-125; with lazy initialisation: the stream
+// position becomes the new base of the draws and moves on by the tables' sizes, the sparse tables empty), the traces are cleared
+// (sarsa.cpp:60-66, td.cpp:64), the exploration decay of sampler/epsilon_greedy and mapping/policy/action goes back to 1
+// (greedy.cpp:140-141, action.cpp:93-97), the run's counters (ss, tt) and rows start again.  Nothing is reseeded: the global stream,
+// the samplers' private streams and the environment state continue -- which is why run 1 of `runs: 2` differs from a fresh process.
+int grlx_reset_run(grlx_ctx *ctx)
+{
+  if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
+  if (ctx->cfg.target_interval > 0 || ctx->cfg.projector.safe != 0)
+    return fail(GRLX_ERR_INVALID, "experiment reset (runs > 1) is not built for representations with a target network (interval) or projectors with safe >= 1");
+  DRAIN(ctx);
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t N = (size_t)ctx->P.n_replicas;
+  std::vector<ReplicaState> hs(N);
+  HIP_TRY(hipMemcpy(hs.data(), ctx->states, sizeof(ReplicaState) * N, hipMemcpyDeviceToHost));
+  uint64_t table_draws = (uint64_t)ctx->cfg.projector.memory;
+  if (ctx->cfg.agent == GRLX_AGENT_AC || ctx->cfg.agent == GRLX_AGENT_QV) table_draws += (uint64_t)ctx->cfg.actor_projector.memory;
+  for (ReplicaState &s : hs)
+  {
+    s.TL0 = s.TL;                         // the re-draw starts where the stream stands
+    s.TL = h_jump(s.TL, table_draws);
+    s.eps_decay = 1;
+    s.ac_decay = 1;
+    s.tr_len = 0;
+    s.tr_total = 1;
+    s.tt = 0;
+    s.ss = 0;
+    s.test_steps = 0;                     // (grlx_step_counts counts per run)
+    s.rows = 0;
+    s.n_slots[0] = s.n_slots[1] = 0;
+    s.lazy_base[0] = s.lazy_base[1] = nullptr;      // a loaded policy is overwritten by the re-draw like every other parameter
+  }
+  HIP_TRY(hipMemcpy(ctx->states, hs.data(), sizeof(ReplicaState) * N, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(ctx->tables, 0, (N * (size_t)ctx->n_tables * sizeof(Entry)) << ctx->P.logC));
+  HIP_TRY(hipMemset(ctx->max_load, 0, sizeof(uint32_t)));
+  if (ctx->trace_state)
+  {
+    const size_t words = N * 16 * kMaxTrace * 2;
+    std::vector<uint32_t> init(words, 0u);
+    for (size_t i = 0; i < words; i += 2) init[i] = kInvalidPos;
+    HIP_TRY(hipMemcpy(ctx->trace_state, init.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  if (ctx->tap_count) HIP_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
+  ctx->trials_run = 0;
+  return GRLX_OK;
+}
+
 int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");

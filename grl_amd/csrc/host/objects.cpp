@@ -871,10 +871,11 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     if (test_interval >= 0 && !config["test_agent"].ptr()) throw bad_param("experiment/online_learning:test_agent");   // :100-101
     if (!environment || !agent || (config["test_agent"].ptr() && !test_agent))
       throw Exception(path() + ": the accelerated path needs environment/modeled, agent/td and agent/fixed");
-    if (save_every != "never" && save_every != "run")
-      throw Exception(path() + ": save_every must be never or run on the accelerated path (test/trial would stop the device every episode)");
-    if ((int)config["rate"] != 0 || test_trials != 1 || steps != 0)
-      throw Exception(path() + ": rate/test_trials/steps are outside the accelerated path");
+    if (save_every != "never" && save_every != "run" && save_every != "test" && save_every != "trial")
+      throw bad_param("experiment/online_learning:save_every");
+    if (steps < 0) throw bad_param("experiment/online_learning:steps");
+    if ((int)config["rate"] != 0 || test_trials != 1)
+      throw Exception(path() + ": rate / test_trials are outside the accelerated path");
     exporter = dynamic_cast<CSVExporter *>(config["exporter"].ptr());
     if (config["exporter"].ptr() && !exporter) throw Exception(path() + ": only exporter/csv is available on the accelerated path");
     if (exporter) exporter->init({"time", "observation", "action", "reward", "terminal"});      // online_learning.cpp:74-75
@@ -1001,13 +1002,43 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     return reprs;
   }
 
+  // ParameterizedRepresentation {action: save} (representation.h:201-229) of every representation of the agent: raw double[memory] to
+  // <base>[@clone]-<config path with '/'->'_'>.dat
+  void save_policy(grlx_ctx *ctx, const grlx_config &c, const std::string &base, int replicas)
+  {
+    const std::vector<const Configurable *> reprs = representations();
+    for (size_t tb = 0; tb < reprs.size(); ++tb)
+      for (int i = 0; i < replicas; ++i)
+      {
+        const int memory = tb == 1 ? c.actor_projector.memory : c.projector.memory;
+        std::vector<double> dense((size_t)memory);
+        if (grlx_export_weights(ctx, (int)tb, i, dense.data()) != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
+        std::string cfg_path = reprs[tb]->path();
+        std::replace(cfg_path.begin(), cfg_path.end(), '/', '_');
+        std::ostringstream name;
+        name << base;
+        if (replicas > 1) name << "@" << i;
+        name << "-" << cfg_path << ".dat";
+        std::ofstream f(name.str(), std::ios::binary);
+        if (!f) { log(1, "Could not open '" + name.str() + "' for writing"); continue; }
+        f.write(reinterpret_cast<const char *>(dense.data()), (std::streamsize)(dense.size() * sizeof(double)));
+      }
+  }
+
   std::vector<double> run(const RunOptions &opt) override
   {
-    if (trials <= 0) throw Exception(path() + ": trials must be > 0 (the reference's trials: 0 runs forever)");
+    if (trials <= 0 && steps <= 0) throw Exception(path() + ": trials or steps must be > 0 (the reference's trials: 0, steps: 0 runs forever)");
+    // the trial loop of online_learning.cpp:154 ends a run at the first trial boundary with `ss >= steps`, and save_every: test | trial
+    // writes the policy between trials: both need the host between trials, so such runs launch one trial at a time
+    const bool by_trial = steps > 0 || save_every == "test" || save_every == "trial";
+    if (steps > 0 && opt.replicas > 1)
+      throw Exception(path() + ": a steps budget ends every clone at a trial of its own; on the accelerated path it is built for one replica");
+    // rows a run can write: with a steps budget alone, a trial has at least one learning step
+    const int trial_cap = trials > 0 ? trials : steps * (test_interval >= 0 ? 2 : 1) + 1;
     grlx_config c;
     lower(&c);
     c.n_replicas = opt.replicas;
-    c.max_rows = (test_interval >= 0 ? trials / (test_interval + 1) : trials) + 1;
+    c.max_rows = (test_interval >= 0 ? trial_cap / (test_interval + 1) : trial_cap) + 1;
     if (opt.table_log2_capacity) c.table_log2_capacity = opt.table_log2_capacity;
     std::vector<double> curve;
     int obs_dims = 0, state_dims = 0;
@@ -1016,7 +1047,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     { // transition log of replica 0: every step and every trial start is tapped on the device and
       // written after the run (the reference writes one row per step, online_learning.cpp:183-206)
       const double per_trial = std::floor(c.timeout / c.control_step) + 3;
-      const double want = per_trial * (double)trials;
+      const double want = per_trial * (double)trial_cap;
       if (want > 4e6) throw Exception(path() + ": transition log of " + std::to_string((long long)want) + " rows is too large for the device-side tap buffer");
       c.tap_replica = 0;
       c.tap_capacity = (int)want;
@@ -1028,12 +1059,14 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       std::ofstream ofs(output + ".yaml");
       ofs << configurator->root()->yaml();
     }
+    // ONE instantiation for all runs, as in the reference: between two runs the experiment is reset (online_learning.cpp:307-308),
+    // not re-created -- the random streams continue, so run 1 differs from a fresh process with another seed
+    std::vector<int64_t> seeds((size_t)opt.replicas);
+    for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i;
+    grlx_ctx *ctx = nullptr;
+    if (grlx_create(&c, seeds.data(), &ctx) != GRLX_OK) throw Exception(grlx_last_error());
     for (int rr = run_offset; rr < runs + run_offset; ++rr)
     {
-      std::vector<int64_t> seeds((size_t)opt.replicas);
-      for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i + (int64_t)(rr - run_offset) * opt.replicas;
-      grlx_ctx *ctx = nullptr;
-      if (grlx_create(&c, seeds.data(), &ctx) != GRLX_OK) throw Exception(grlx_last_error());
       // Load policy every run (online_learning.cpp:140-150 -> ParameterizedRepresentation {action: load},
       // representation.h:231-263): <load_file with $run -> rr>-<config path with '/'->'_'>.dat, raw
       // double[memory]; a missing or wrong-sized file is a warning, not an error, as in the reference.
@@ -1061,8 +1094,34 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
         }
       }
       auto start = std::chrono::steady_clock::now();
-      int rc = grlx_run(ctx, trials, nullptr);
-      if (rc == GRLX_OK) rc = grlx_sync(ctx, nullptr);
+      int rc = GRLX_OK;
+      if (!by_trial)
+      {
+        rc = grlx_run(ctx, trials, nullptr);
+        if (rc == GRLX_OK) rc = grlx_sync(ctx, nullptr);
+      }
+      else
+      { // for (ss = 0, tt = 0; (!trials || tt < trials) && (!steps || ss < steps); ++tt)   -- online_learning.cpp:154
+        uint64_t learn0 = 0, test0 = 0;
+        grlx_step_counts(ctx, &learn0, &test0);
+        uint64_t ss = 0;
+        for (int tt = 0; (trials <= 0 || tt < trials) && (steps <= 0 || ss < (uint64_t)steps) && rc == GRLX_OK; ++tt)
+        {
+          rc = grlx_run(ctx, 1, nullptr);
+          if (rc == GRLX_OK) rc = grlx_sync(ctx, nullptr);
+          if (rc != GRLX_OK) break;
+          uint64_t learn = 0, test = 0;
+          grlx_step_counts(ctx, &learn, &test);
+          ss = learn - learn0;                         // one replica when a budget is set; unused otherwise
+          const bool was_test = test_interval >= 0 && tt % (test_interval + 1) == test_interval;
+          if ((save_every == "trial" || (was_test && save_every == "test")) && !output.empty())
+          { // online_learning.cpp:281-290: <output>-run<rr>-trial<tt>-<config path>.dat
+            std::ostringstream base;
+            base << output << "-run" << rr << "-trial" << tt;
+            save_policy(ctx, c, base.str(), opt.replicas);
+          }
+        }
+      }
       if (rc != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
       double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 
@@ -1158,23 +1217,9 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       // representation.h:201-229): raw double[memory] to <output>-run<rr>-<config path with '/'->'_'>.dat
       if (save_every == "run" && !output.empty())
       {
-        const std::vector<const Configurable *> reprs = representations();
-        for (size_t tb = 0; tb < reprs.size(); ++tb)
-          for (int i = 0; i < opt.replicas; ++i)
-          {
-            const int memory = tb == 1 ? c.actor_projector.memory : c.projector.memory;
-            std::vector<double> dense((size_t)memory);
-            if (grlx_export_weights(ctx, (int)tb, i, dense.data()) != GRLX_OK) { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
-            std::string cfg_path = reprs[tb]->path();
-            std::replace(cfg_path.begin(), cfg_path.end(), '/', '_');
-            std::ostringstream name;
-            name << output << "-run" << rr;
-            if (opt.replicas > 1) name << "@" << i;
-            name << "-" << cfg_path << ".dat";
-            std::ofstream f(name.str(), std::ios::binary);
-            if (!f) { log(1, "Could not open '" + name.str() + "' for writing"); continue; }
-            f.write(reinterpret_cast<const char *>(dense.data()), (std::streamsize)(dense.size() * sizeof(double)));
-          }
+        std::ostringstream base;
+        base << output << "-run" << rr;
+        save_policy(ctx, c, base.str(), opt.replicas);
       }
       uint64_t learn = 0, test = 0;
       grlx_step_counts(ctx, &learn, &test);
@@ -1182,8 +1227,10 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       msg << "run " << rr << ": " << opt.replicas << " replicas, " << (learn + test) << " env-steps in " << wall << " s = "
           << (double)(learn + test) / wall / 1e6 << " M env-steps/s";
       log(2, msg.str());
-      grlx_destroy(ctx);
+      if (rr < runs + run_offset - 1 && grlx_reset_run(ctx) != GRLX_OK)        // online_learning.cpp:307-308
+      { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
     }
+    grlx_destroy(ctx);
     return curve;
   }
 };

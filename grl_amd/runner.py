@@ -198,6 +198,10 @@ class Runner:
         capi.check(self.lib.grlx_table_capacity(self._ctx, C.byref(n)))
         return int(n.value)
 
+    def reset_run(self):
+        """Experiment::reset() between two runs (online_learning.cpp:307-308): see grlx_reset_run."""
+        capi.check(self.lib.grlx_reset_run(self._ctx))
+
     def grow_tables(self, new_log2: int):
         capi.check(self.lib.grlx_grow_tables(self._ctx, new_log2))
 

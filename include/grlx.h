@@ -253,6 +253,12 @@ int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_us
  * work first; no-op if the tables are at least that large). */
 int  grlx_table_capacity(grlx_ctx *ctx, uint32_t *log2_entries);
 int  grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2);
+/* Experiment::reset() between two runs of `runs: N` (online_learning.cpp:307-308; Configurable::reset, configurable.h:770-776):
+ * the representations' parameters are drawn again from the CONTINUING thread-local stream (linear.cpp:104-125), predictors clear
+ * their traces (sarsa.cpp:60-66), epsilon-greedy and the action policy set decay_ = 1 (greedy.cpp:140-141, action.cpp:93-97); the
+ * run's step / trial counters and rows start again; no stream is reseeded.  GRLX_ERR_INVALID for contexts with a target network
+ * (interval) or safe >= 1. */
+int  grlx_reset_run(grlx_ctx *ctx);
 /* Replaces reading target()->params() (representation.h:266-282): the target network's current value of the given
  * reference slots of the Q table, and the number of synchronisations so far; contexts with target_interval > 0 only. */
 int  grlx_get_target_weights(grlx_ctx *ctx, int replica, const uint32_t *slots, int n, double *out, uint32_t *n_syncs);

@@ -683,6 +683,39 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
   return e;
 }
 
+int orc_reset_run(orc_exp *e)
+{ /* Experiment reset between runs (online_learning.cpp:307-308 -> Configurable::reset: {action: reset} walks the experiment's
+   * subtree).  What the objects of this path do with it:
+   *   representation/parameterized/linear (linear.cpp:104-125): every parameter is drawn again from the thread-local RandGen --
+   *     the CONTINUING stream, nothing is reseeded -- in the order the representations stand in the yaml (the same order as at
+   *     instantiation), followed by synchronize();
+   *   predictor/critic/{sarsa,q,...} (sarsa.cpp:60-66, advantage.cpp:67, qv.cpp:71, td.cpp:64): finalize() = the trace is cleared;
+   *   sampler/epsilon_greedy (greedy.cpp:140-141) and mapping/policy/action (action.cpp:93-97): decay_ = 1;
+   *   sampler/greedy, the environment, the tile coding without a claim table: nothing (greedy.cpp:43-45).
+   * The run's own counters (ss, tt: loop variables of online_learning.cpp:154) start again.  Returns -1 for the two options whose
+   * reset is not restated here (a target network: synchronize() blends the re-drawn parameters into the OLD target; safe >= 1). */
+  const orc_spec *s = &e->spec;
+  if (e->wt || e->claim || s->agent == ORC_AGENT_PID) return -1;
+  const int first = (s->agent == ORC_AGENT_AC) ? 1 : 0, second = (s->agent == ORC_AGENT_AC) ? 0 : 1;
+  const orc_tile_spec *ts[2] = {&s->projector, &s->actor_projector};
+  const orc_linear_spec *ls[2] = {&s->representation, &s->actor_representation};
+  const int order[2] = {first, second};
+  for (int k = 0; k < 2; ++k)
+  {
+    const int t = order[k];
+    if (!e->w[t]) continue;
+    const size_t n = (size_t)ts[t]->memory;
+    for (size_t i = 0; i < n; ++i)
+      e->w[t][i] = ls[t]->init_min + orc_drand48(&e->TL) * (ls[t]->init_max - ls[t]->init_min);
+  }
+  trace_clear(&e->trace);
+  e->eps_decay = 1;
+  e->ac_decay = 1;
+  e->tt = 0;
+  e->ss = 0;
+  return 0;
+}
+
 void orc_destroy(orc_exp *e)
 {
   if (!e) return;

@@ -208,6 +208,10 @@ void     orc_destroy(orc_exp *e);
 int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             orc_tap *tap, int tap_cap, int *tap_n);
 
+/* Experiment::reset() between two runs of one process (online_learning.cpp:307-308): parameters re-drawn from the continuing
+ * thread-local stream, traces cleared, exploration decay back to 1, the run's counters restart; the streams are NOT reseeded.
+ * 0, or -1 for graphs whose reset is not restated (target network, safe >= 1, the PID agent). */
+int           orc_reset_run(orc_exp *e);
 void          orc_get_stats(const orc_exp *e, orc_stats *out);
 const double *orc_weights(const orc_exp *e, int table);        /* table 0: Q/critic, 1: actor, 2: target network of table 0 */
 int64_t       orc_target_syncs(const orc_exp *e);              /* synchronisations of the target network so far */

@@ -104,6 +104,7 @@ def load():
     L.orc_run.argtypes = [C.c_void_p, C.c_int, P(Row), C.c_int, P(Tap), C.c_int, P(C.c_int)]; L.orc_run.restype = C.c_int
     L.orc_get_stats.argtypes = [C.c_void_p, P(Stats)]
     L.orc_weights.argtypes = [C.c_void_p, C.c_int]; L.orc_weights.restype = P(C.c_double)
+    L.orc_reset_run.argtypes = [C.c_void_p]; L.orc_reset_run.restype = C.c_int
     L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_double), C.c_size_t]; L.orc_set_weights.restype = C.c_int
     L.orc_target_syncs.argtypes = [C.c_void_p]; L.orc_target_syncs.restype = C.c_int64
     L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
@@ -176,6 +177,11 @@ class Experiment:
             self.L.orc_format_row(C.byref(r), buf, 128)
             out.append(buf.value.decode())
         return "".join(out)
+
+    def reset_run(self):
+        """Experiment::reset() between two runs (online_learning.cpp:307-308)."""
+        if self.L.orc_reset_run(self.h) != 0:
+            raise ValueError("orc_reset_run: not restated for this graph")
 
     def stats(self) -> Stats:
         s = Stats()

@@ -539,3 +539,102 @@ def test_other_kernel_families_under_poisoned_registers(grlx, monkeypatch, famil
             assert_bit_equal(r.weights(k, slots, t), e.weights(slots, t), f"{family}: table {t} of replica {k}")
         e.close()
     r.close()
+
+
+# ------------------------------------------------ runs > 1: Experiment::reset() between runs ---
+@pytest.mark.parametrize("graph", ["pendulum_sarsa", "pendulum_q", "cart_pole_ac", "pendulum_qv"])
+def test_second_run_continues_the_streams_like_the_reference(grlx, graph):
+    """`runs: 2` (online_learning.cpp:124, 307-308): after run 0 the experiment is RESET, not re-created -- the parameters are drawn
+    again from the continuing thread-local stream (linear.cpp:104-125), traces are cleared, exploration decay returns to 1, the
+    run's counters restart, and no stream is reseeded.  Rows, RNG positions, environment state and the complete dense tables of
+    run 1 equal the oracle's; and they differ from what a fresh experiment gives (the deviation round 2 had)."""
+    from tests import configs
+    make = {"pendulum_sarsa": lambda n: configs.pendulum(grlx, n, agent=0), "pendulum_q": lambda n: configs.pendulum(grlx, n, agent=1),
+            "cart_pole_ac": lambda n: configs.cart_pole_ac(grlx, n), "pendulum_qv": lambda n: configs.pendulum_qv(grlx, n)}[graph]
+    seeds = [1, 2, 3, 4, 5]
+    cfg, spec = make(len(seeds))
+    spec.math = ob.MATH_PORTABLE
+    trials = 23
+    r = grlx.Runner(cfg, seeds)
+    r.run(trials); r.sync()
+    first_run = [r.rows(k)[2].copy() for k in range(len(seeds))]
+    r.reset_run()
+    assert r.n_rows() == 0 and r.step_counts() == (0, 0)
+    r.run(trials); r.sync()
+    n_tables = 2 if graph in ("cart_pole_ac", "pendulum_qv") else 1
+    for k in (0, 4):
+        e = ob.Experiment(spec, seed=seeds[k])
+        rows0, _ = e.run(trials)
+        assert_bit_equal(first_run[k], [x.reward for x in rows0], f"run 0, replica {k}")
+        e.reset_run()
+        rows1, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows1] and list(s) == [x.steps for x in rows1], f"run 1, replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows1], f"returns of run 1, replica {k}")
+        assert list(r.rng(k)) == list(e.rng())
+        assert_bit_equal(r.env_state(k), e.state(), f"env state after run 1, replica {k}")
+        for tb in range(n_tables):
+            assert_bit_equal(r.export_weights(k, tb), e.all_weights(tb), f"table {tb} after run 1, replica {k}")
+        # ... and NOT the rows of a fresh experiment with the same seed (what re-creating per run would print)
+        assert not np.array_equal(rew, first_run[k])
+        e.close()
+    r.close()
+
+
+def test_reset_run_refuses_what_it_does_not_restate(grlx):
+    cfg = grlx.pendulum_sarsa_config(1, target_interval=10)
+    r = grlx.Runner(cfg, [1])
+    with pytest.raises(grlx.capi.GrlxError) as ei:
+        r.reset_run()
+    assert ei.value.code == grlx.capi.ERR_INVALID
+    r.close()
+
+
+def _golden_yaml():
+    return open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")).read()
+
+
+def test_deployer_two_runs_steps_budget_and_save_every(grlx, tmp_path):
+    """The edges of OnlineLearningExperiment::run through grlxd and the reference's own yaml keys:
+    runs: 2 (run 1 continues the streams, online_learning.cpp:307-308), steps (a run ends at the first trial boundary with
+    ss >= steps, :154), save_every: test (a policy file after every test trial, :281-290)."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = _golden_yaml()
+    assert "runs: 1" in text and "steps: 0" in text and "trials: 2000" in text
+    # (a) runs: 2
+    y = tmp_path / "two.yaml"
+    y.write_text(text.replace("runs: 1", "runs: 2").replace("trials: 2000", "trials: 33"))
+    res = subprocess.run([grlxd, "-s", "5", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=5)
+    rows0, _ = e.run(33)
+    e.reset_run()
+    rows1, _ = e.run(33)
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows0)
+    assert (tmp_path / "pendulum-sarsa-tc-1.txt").read_text() == e.format_rows(rows1)
+    assert e.format_rows(rows0) != e.format_rows(rows1)
+    e.close()
+    # (b) steps: 2450 with trials: 0 -- 100-step episodes, a test trial every 11th: learning trials 0..24 bring ss to 2500 >= 2450
+    # at the boundary after trial index 26 (two test trials in between), so 27 trials run and two rows are written
+    y = tmp_path / "steps.yaml"
+    y.write_text(text.replace("steps: 0", "steps: 2450").replace("trials: 2000", "trials: 0"))
+    res = subprocess.run([grlxd, "-s", "5", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=5)
+    rows, _ = e.run(27)
+    assert e.stats().learn_steps == 2500 and len(rows) == 2
+    assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)
+    e.close()
+    # (c) save_every: test -- the file written after the first test trial (trial index 10) holds the table at that moment
+    y = tmp_path / "save.yaml"
+    y.write_text(text.replace("save_every: never", "save_every: test").replace("trials: 2000", "trials: 12"))
+    res = subprocess.run([grlxd, "-s", "5", "-l", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    files = sorted(p.name for p in tmp_path.glob("pendulum-sarsa-tc-run0-trial*.dat"))
+    assert files == ["pendulum-sarsa-tc-run0-trial10-experiment_agent_policy_representation.dat"]
+    e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=5)
+    e.run(11)
+    assert_bit_equal(np.fromfile(tmp_path / files[0], dtype="<f8"), e.all_weights(0), "policy saved after the first test trial")
+    e.close()
