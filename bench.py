@@ -128,6 +128,8 @@ def graph_config(graph, n, max_rows, table_log2=None, replicas_per_wave=0):
     make = {"pendulum_sarsa": grl_amd.pendulum_sarsa_config, "cart_pole_ac": grl_amd.cart_pole_ac_config,
             "acrobot_q": grl_amd.acrobot_q_config, "compass_walker_q": grl_amd.compass_walker_q_config}[graph]
     cfg = make(n)
+    if graph == "cart_pole_ac":
+        cfg.table_log2_capacity = 18      # pre-sized for the 66 trials of the run: no re-hash between the timed launches (the default, 2^16, grows)
     cfg.max_rows = max_rows
     if table_log2:
         cfg.table_log2_capacity = table_log2

@@ -97,6 +97,8 @@ _SIGS = {
     "grlx_table_capacity": (C.c_int, [C.c_void_p, _P(C.c_uint32)]),
     "grlx_grow_tables": (C.c_int, [C.c_void_p, C.c_uint32]),
     "grlx_reset_run": (C.c_int, [C.c_void_p]),
+    "grlx_run_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]),
+    "grlx_replica_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "grlx_get_target_weights": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_uint32), C.c_int, _P(C.c_double), _P(C.c_uint32)]),
     "grlx_export_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_load_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_uint64]),

@@ -439,7 +439,10 @@ void grlx_config_cart_pole_ac(grlx_config *c)
   c->ac_decay_min = 0;
   c->ac_update_method = 0;                        // proportional
   c->ac_step_limit = -1;
-  c->table_log2_capacity = 18;
+  // initial size; the tables grow between launches (grlx.h).  2^16 entries hold what ONE launch of 32 cart-pole trials creates from
+  // empty tables (about 25 000 slots per table) at a load the 4-way buckets take; 16384 replicas then start at 2 x 16 GiB instead of the
+  // 2 x 64 GiB that 2^18 reserved up front.  Callers that must not re-hash between timed launches (bench.py) pass their size.
+  c->table_log2_capacity = 16;
 }
 
 int grlx_env_dims(int env, int *state_dims, int *obs_dims)
@@ -756,10 +759,19 @@ int grlx_reset_run(grlx_ctx *ctx)
   return GRLX_OK;
 }
 
-int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
+static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
   if (n_trials == 0) return GRLX_OK;
+  if (steps_budget != 0)
+  {
+    const bool plain_q = ctx->cfg.agent != GRLX_AGENT_AC && ctx->cfg.agent != GRLX_AGENT_QV && ctx->cfg.target_interval == 0 &&
+                         ctx->cfg.projector.safe == 0 && ctx->cfg.trace != GRLX_TRACE_ACCUMULATING && ctx->cfg.agent != GRLX_AGENT_ADVANTAGE;
+    if (!plain_q && ctx->cfg.agent != GRLX_AGENT_AC)
+      return fail(GRLX_ERR_INVALID, "a steps budget is built for SARSA / Q / Expected SARSA with the replacing trace and for the actor-critic agent");
+    if (ctx->P.tap_capacity > 0 || ctx->P.diag_out)
+      return fail(GRLX_ERR_INVALID, "a steps budget is not available with taps or diagnostics");
+  }
   if (!ctx->run_pending && ctx->P.logC < ctx->logC_max)
   { // nothing in flight: how full did the last run leave the fullest table?  Beyond a quarter, grow to an eighth.
     uint32_t used = 0;
@@ -789,6 +801,11 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
   const double horizon = (ctx->cfg.env == GRLX_ENV_COMPASS_WALKER ? 2 : 1) * ctx->cfg.timeout / ctx->cfg.control_step + 1;
   int kTrialsPerLaunch = 32;
   if (horizon * kTrialsPerLaunch > kStepsPerLaunch) kTrialsPerLaunch = (int)fmax(1., floor(kStepsPerLaunch / horizon));
+  // with a steps budget the budget bounds what one replica does in a launch (its remaining steps plus one episode): all trials go into
+  // ONE launch, so that a replica which has reached its budget does not wait at 32-trial boundaries for the ones that have not
+  DevParams Pb = ctx->P;
+  Pb.steps_budget = steps_budget;
+  if (steps_budget != 0) kTrialsPerLaunch = n_trials;
   ctx->run_stream = (hipStream_t)stream;
   ctx->run_pending = true;
   for (int done = 0; done < n_trials; done += kTrialsPerLaunch)
@@ -796,19 +813,33 @@ int grlx_run(grlx_ctx *ctx, int n_trials, void *stream)
     const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
     if (ctx->poison) HIP_TRY(launch_poison_registers(ctx->poison_pattern, (hipStream_t)stream));
     if (ctx->cfg.agent == GRLX_AGENT_AC)
-      HIP_TRY(launch_rollout_ac(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+      HIP_TRY(launch_rollout_ac(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.agent == GRLX_AGENT_QV)
-      HIP_TRY(launch_rollout_qv(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+      HIP_TRY(launch_rollout_qv(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.target_interval > 0 || ctx->cfg.projector.safe != 0)
-      HIP_TRY(launch_rollout_tgt(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+      HIP_TRY(launch_rollout_tgt(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
-      HIP_TRY(launch_rollout_acc(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+      HIP_TRY(launch_rollout_acc(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else
-      HIP_TRY(launch_rollout(ctx->P, n, (hipStream_t)stream, &ctx->last_kernel));
+      HIP_TRY(launch_rollout(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
   }
   HIP_TRY(launch_max_load(ctx->P, ctx->n_tables, ctx->max_load, (hipStream_t)stream));
   ctx->trials_run += n_trials;
   return GRLX_OK;
+}
+
+int grlx_run(grlx_ctx *ctx, int n_trials, void *stream) { return run_trials(ctx, n_trials, 0, stream); }
+
+// The trial loop of OnlineLearningExperiment::run with both of its bounds (online_learning.cpp:154):
+//   for (ss = 0, tt = 0; (!trials_ || tt < trials_) && (!steps_ || ss < steps_); ++tt)
+// every replica runs at most `max_trials` further trials and starts none once its learning steps of the run (since grlx_create or
+// grlx_reset_run) have reached `steps`.  Replicas stop at trials of their own: rows are ragged (grlx_replica_rows, grlx_curve_stats
+// counts per row).  One launch: `steps` bounds the work of a replica.
+int grlx_run_steps(grlx_ctx *ctx, int max_trials, uint64_t steps, void *stream)
+{
+  if (steps == 0) return fail(GRLX_ERR_INVALID, "grlx_run_steps: steps must be > 0 (grlx_run has no budget)");
+  if (steps > (1ull << 40)) return fail(GRLX_ERR_INVALID, "grlx_run_steps: steps out of range");
+  return run_trials(ctx, max_trials, steps, stream);
 }
 
 static int status_to_error(uint64_t st)
@@ -851,6 +882,15 @@ int grlx_rows(grlx_ctx *ctx)
   ReplicaState s;
   DRAIN(ctx);
   if (hipMemcpy(&s, ctx->states, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) return fail(GRLX_ERR_HIP, "hipMemcpy failed");
+  return (int)s.rows;
+}
+
+int grlx_replica_rows(grlx_ctx *ctx, int replica)
+{
+  if (!ctx || replica < 0 || replica >= ctx->P.n_replicas) return fail(GRLX_ERR_INVALID, "bad argument");
+  ReplicaState s;
+  DRAIN(ctx);
+  if (hipMemcpy(&s, ctx->states + replica, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) return fail(GRLX_ERR_HIP, "hipMemcpy failed");
   return (int)s.rows;
 }
 

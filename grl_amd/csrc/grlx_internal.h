@@ -107,6 +107,9 @@ struct DevParams {
   int32_t  diag_deferred;       // diagnostics: stamp the deferred-update instantiation (pendulum, 3 actions only)
   double   kappa;               // predictor/critic/advantage: advantage scaling factor
   double   beta;                // predictor/critic/qv: state-value learning rate
+  // experiment/online_learning:steps (online_learning.cpp:154): a replica starts no further trial once its learning steps of the run
+  // (ReplicaState::ss) have reached this budget; 0 = none.  Honoured by rollout_kernel, rollout_wide_kernel and the actor-critic kernels.
+  uint64_t steps_budget;
   int32_t  tile_safe;           // projector/tile_coding:safe: 1 = claim table, single projections claim; 2 = batch projections claim too (plain kernel)
   int32_t  target_interval;     // > 0: the Q table has a target network synchronised every so many update() calls
   double   target_tau;          // synchronisation strength (representation.h:284-296)

@@ -547,15 +547,19 @@ __global__ __launch_bounds__(256) void curve_stats_kernel(DevParams P, int first
 {
   __shared__ double s1[256], s2[256];
   const int row = first + blockIdx.x;
-  double a = 0, b = 0;
+  __shared__ double s3[256];
+  double a = 0, b = 0, n = 0;
   for (int r = threadIdx.x; r < P.n_replicas; r += 256)
-  {
-    double v = P.row_reward[(size_t)row * P.n_replicas + r];
-    a += v;
-    b += v * v;
-  }
+    if ((uint32_t)row < P.states[r].rows)          // rows are ragged when replicas stop at a steps budget (grlx_run_steps)
+    {
+      double v = P.row_reward[(size_t)row * P.n_replicas + r];
+      a += v;
+      b += v * v;
+      n += 1;
+    }
   s1[threadIdx.x] = a;
   s2[threadIdx.x] = b;
+  s3[threadIdx.x] = n;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1)
   {
@@ -563,6 +567,7 @@ __global__ __launch_bounds__(256) void curve_stats_kernel(DevParams P, int first
     {
       s1[threadIdx.x] += s1[threadIdx.x + off];
       s2[threadIdx.x] += s2[threadIdx.x + off];
+      s3[threadIdx.x] += s3[threadIdx.x + off];
     }
     __syncthreads();
   }
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(256) void curve_stats_kernel(DevParams P, int first
   {
     out[blockIdx.x * 3 + 0] = s1[0];
     out[blockIdx.x * 3 + 1] = s2[0];
-    out[blockIdx.x * 3 + 2] = (double)P.n_replicas;
+    out[blockIdx.x * 3 + 2] = s3[0];
   }
 }
 

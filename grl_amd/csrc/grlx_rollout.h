@@ -274,16 +274,19 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
   if (DIAG) diag_last = stamp();
 
-  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  for (int trial = 0; trial < n_trials; ++trial)
   {
+    // online_learning.cpp:154: a replica whose learning steps have reached the steps budget starts no further trial
+    const bool act = live && !(P.steps_budget != 0u && (uint64_t)ss >= P.steps_budget);
+    if (!__any(act)) break;
     const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;        // online_learning.cpp:160
     double obs[D], reward = 0, total_reward = 0;
     int terminal = 0;
-    bool running = live;
+    bool running = act;
 
     // environment_->start (modeled.cpp:132-158)
-    if (live)
+    if (act)
     {
       Env<ENV>::start(N, test, TL, G, x);
       Env<ENV>::observe(N, x, obs);
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
     if (!test) trace_flush(tr, tab, true);
 
     // row of a test trial (online_learning.cpp:238-262) -- or of every trial when test_interval < 0
-    if (live && (ti >= 0 ? test : 1))
+    if (act && (ti >= 0 ? test : 1))
     {
       if (rows < (uint32_t)P.max_rows)
       {
@@ -685,6 +688,7 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
       else
         status |= ST_ROWS_FULL;
     }
+    tt += act ? 1 : 0;
   }
 
   if (DIAG && P.diag_out && lane == 0)

@@ -162,14 +162,17 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
   double pd_dW = 0, pd_dT = 0, pd_wp = 0;
   uint32_t pd_pos = kInvalidPos;
 
-  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  for (int trial = 0; trial < n_trials; ++trial)
   {
+    // online_learning.cpp:154: a replica whose learning steps have reached the steps budget starts no further trial
+    const bool act = live && !(P.steps_budget != 0u && (uint64_t)ss >= P.steps_budget);
+    if (!__any(act)) break;
     const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
     double obs[D], reward = 0, total_reward = 0;
     int terminal = 0;
-    bool running = live;
-    if (live)
+    bool running = act;
+    if (act)
     {
       Env<ENV>::start(N, test, TL, G, x);
       Env<ENV>::observe(N, x, obs);
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     // entries themselves stay -- the reference never clears the critic's trace
     if (!test) trace_flush(tr, tabC, false);
 
-    if (live && (ti >= 0 ? test : 1))
+    if (act && (ti >= 0 ? test : 1))
     {
       if (rows < (uint32_t)P.max_rows)
       {
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
       else
         status |= ST_ROWS_FULL;
     }
+    tt += act ? 1 : 0;
   }
 
   // persist the critic's trace (weights are in the table already)

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     s.running = false; s.first = true; s.test = 0;
     s.ending = false;
     s.rows = RS.rows;
-    s.trials_left = n_trials;
+    s.trials_left = (P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget) ? 0 : n_trials;
   };
   // ... and back: the critic's trace is persisted (its weights go to the table), the counters and streams to the replica
   // (the environment state follows from the env lanes, see sh_xwb)
@@ -495,6 +495,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           }
           s.tt++;
           s.trials_left--;
+          if (P.steps_budget != 0u && (uint64_t)s.ss >= P.steps_budget) s.trials_left = 0;        // online_learning.cpp:154: `ss < steps_`
           s.ending = false;
         }
         if (at_rest && s.trials_left == 0)

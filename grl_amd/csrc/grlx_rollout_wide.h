@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     s.running = false; s.first = true; s.test = 0;
     s.ending = false;
     s.rows = RS.rows;
-    s.trials_left = live ? n_trials : 0;
+    s.trials_left = (live && !(P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget)) ? n_trials : 0;
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
@@ -567,6 +567,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             }
             s.tt++;
             s.trials_left--;
+            if (P.steps_budget != 0u && (uint64_t)s.ss >= P.steps_budget) s.trials_left = 0;      // online_learning.cpp:154: `ss < steps_`
             s.ending = false;
           }
           if (between && s.trials_left > 0)

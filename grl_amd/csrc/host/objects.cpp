@@ -944,7 +944,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
       c->ac_decay_rate = pol->decay_rate; c->ac_decay_min = pol->decay_min;
       c->ac_update_method = ac->update_method[0] == 'p' ? 0 : 1;
       c->ac_step_limit = ac->step_limit.empty() ? -1. : ac->step_limit[0];
-      c->table_log2_capacity = 18;
+      c->table_log2_capacity = 16;                   // initial size: the tables grow between launches (grlx_config_cart_pole_ac)
       return;
     }
 

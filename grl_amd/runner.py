@@ -98,8 +98,16 @@ class Runner:
     def run(self, n_trials: int, stream: int = 0):
         capi.check(self.lib.grlx_run(self._ctx, int(n_trials), C.c_void_p(stream)))
 
+    def run_steps(self, max_trials: int, steps: int, stream: int = 0):
+        """The trial loop with both bounds (online_learning.cpp:154): at most max_trials further trials per replica, none started once
+        the replica's learning steps of the run have reached `steps`."""
+        capi.check(self.lib.grlx_run_steps(self._ctx, int(max_trials), int(steps), C.c_void_p(stream)))
+
     def sync(self, stream: int = 0):
         capi.check(self.lib.grlx_sync(self._ctx, C.c_void_p(stream)))
+
+    def replica_rows(self, replica: int) -> int:
+        return capi.check(self.lib.grlx_replica_rows(self._ctx, int(replica)))
 
     def set_diag(self, enable: bool = True):
         capi.check(self.lib.grlx_set_diag(self._ctx, int(enable)))
@@ -116,7 +124,7 @@ class Runner:
 
     def rows(self, replica: int, first: int = 0, count: int = None):
         if count is None:
-            count = self.n_rows() - first
+            count = self.replica_rows(replica) - first
         trial = np.zeros(count, np.int64)
         steps = np.zeros(count, np.int64)
         reward = np.zeros(count, np.float64)

@@ -253,6 +253,13 @@ int  grlx_table_load(grlx_ctx *ctx, int table, int replica, uint32_t *n_slots_us
  * work first; no-op if the tables are at least that large). */
 int  grlx_table_capacity(grlx_ctx *ctx, uint32_t *log2_entries);
 int  grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2);
+/* The trial loop of OnlineLearningExperiment::run with BOTH of its bounds (online_learning.cpp:154: `(!trials_ || tt < trials_) &&
+ * (!steps_ || ss < steps_)`): every replica runs at most max_trials further trials and starts none once its learning steps of the run
+ * (since grlx_create / grlx_reset_run) have reached `steps` (> 0).  Replicas stop at trials of their own, so their rows are ragged:
+ * grlx_replica_rows gives a replica's count, grlx_curve_stats counts per row.  One launch per call.  Built for SARSA / Q / Expected SARSA
+ * with the replacing trace and for the actor-critic agent; GRLX_ERR_INVALID otherwise. */
+int  grlx_run_steps(grlx_ctx *ctx, int max_trials, uint64_t steps, void *stream);
+int  grlx_replica_rows(grlx_ctx *ctx, int replica);          /* rows replica `replica` has written (grlx_rows: replica 0) */
 /* Experiment::reset() between two runs of `runs: N` (online_learning.cpp:307-308; Configurable::reset, configurable.h:770-776):
  * the representations' parameters are drawn again from the CONTINUING thread-local stream (linear.cpp:104-125), predictors clear
  * their traces (sarsa.cpp:60-66), epsilon-greedy and the action policy set decay_ = 1 (greedy.cpp:140-141, action.cpp:93-97); the

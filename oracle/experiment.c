@@ -683,6 +683,8 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
   return e;
 }
 
+void orc_set_steps_budget(orc_exp *e, uint64_t steps) { e->steps_budget = steps; }
+
 int orc_reset_run(orc_exp *e)
 { /* Experiment reset between runs (online_learning.cpp:307-308 -> Configurable::reset: {action: reset} walks the experiment's
    * subtree).  What the objects of this path do with it:
@@ -734,8 +736,8 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
   int nrows = 0, ntap = 0;
   int D = orc_env_obs_dims(s->env);
 
-  for (int t = 0; t < n_trials; ++t, ++e->tt)
-  {
+  for (int t = 0; t < n_trials && !(e->steps_budget && (uint64_t)e->ss >= e->steps_budget); ++t, ++e->tt)
+  { /* :154 `(!trials_ || tt < trials_) && (!steps_ || ss < steps_)` */
     int ti = s->test_interval;
     int test = (ti >= 0 && e->tt % (ti + 1) == ti);           /* :160 */
     double obs[ORC_MAX_DIMS], reward, total_reward = 0, total_time = 0;

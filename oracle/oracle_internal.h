@@ -45,6 +45,7 @@ struct orc_exp {
   double     ac_decay, ac_noise;        /* ActionPolicy::decay_, n_ */
   orc_trace  trace;                     /* predictor (critic) trace */
   int64_t    tt, ss;                    /* trial counter, learning steps */
+  uint64_t   steps_budget;              /* experiment/online_learning:steps (online_learning.cpp:154); 0 = none */
   orc_stats  stats;
 };
 

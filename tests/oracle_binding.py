@@ -105,6 +105,7 @@ def load():
     L.orc_get_stats.argtypes = [C.c_void_p, P(Stats)]
     L.orc_weights.argtypes = [C.c_void_p, C.c_int]; L.orc_weights.restype = P(C.c_double)
     L.orc_reset_run.argtypes = [C.c_void_p]; L.orc_reset_run.restype = C.c_int
+    L.orc_set_steps_budget.argtypes = [C.c_void_p, C.c_uint64]; L.orc_set_steps_budget.restype = None
     L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_double), C.c_size_t]; L.orc_set_weights.restype = C.c_int
     L.orc_target_syncs.argtypes = [C.c_void_p]; L.orc_target_syncs.restype = C.c_int64
     L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
@@ -177,6 +178,10 @@ class Experiment:
             self.L.orc_format_row(C.byref(r), buf, 128)
             out.append(buf.value.decode())
         return "".join(out)
+
+    def set_steps_budget(self, steps: int):
+        """experiment/online_learning:steps (online_learning.cpp:154); 0 = none."""
+        self.L.orc_set_steps_budget(self.h, int(steps))
 
     def reset_run(self):
         """Experiment::reset() between two runs (online_learning.cpp:307-308)."""

@@ -639,3 +639,50 @@ def test_deployer_two_runs_steps_budget_and_save_every(grlx, tmp_path):
     e.run(11)
     assert_bit_equal(np.fromfile(tmp_path / files[0], dtype="<f8"), e.all_weights(0), "policy saved after the first test trial")
     e.close()
+
+
+@pytest.mark.parametrize("graph,n,budgets", [("acrobot_q", 21, (700, 1500)), ("compass_walker_q", 13, (600, 1300)), ("cart_pole_ac", 9, (900, 2000)),
+                                             ("pendulum_sarsa", 6, (450, 1250))])
+@pytest.mark.parametrize("rpw", [4, 8])
+def test_steps_budget_stops_every_replica_at_its_own_trial(grlx, graph, n, budgets, rpw):
+    """experiment/online_learning:steps on the device (grlx_run_steps; online_learning.cpp:154): a replica starts no further trial once
+    its learning steps have reached the budget.  With absorbing environments the replicas of a wave stop at different trials; rows (ragged),
+    RNG positions, environment state and step counts equal the oracle's, in both wave layouts, over two successive budgets."""
+    from tests import configs
+    make = {"acrobot_q": configs.acrobot, "compass_walker_q": configs.compass_walker, "cart_pole_ac": configs.cart_pole_ac,
+            "pendulum_sarsa": lambda g, k, **o: configs.pendulum(g, k, agent=0, **o)}[graph]
+    over = dict(replicas_per_wave=rpw, max_rows=400)
+    if graph == "cart_pole_ac":
+        over["end_stop_penalty"] = 1                  # ragged episodes for the actor-critic graph too
+    cfg, spec = make(grlx, n, **over)
+    spec.math = ob.MATH_PORTABLE
+    seeds = np.arange(1, n + 1)
+    r = grlx.Runner(cfg, seeds)
+    assert r.replicas_per_wave() == rpw
+    oracles = [ob.Experiment(spec, seed=int(s)) for s in seeds]
+    orows = [[] for _ in seeds]
+    rows_seen = set()
+    for budget in budgets:
+        r.run_steps(100000, budget)
+        r.sync()
+        for k, e in enumerate(oracles):
+            e.set_steps_budget(budget)
+            orows[k] += e.run(100000)[0]
+    total_learn = 0
+    for k, e in enumerate(oracles):
+        st = e.stats()
+        total_learn += int(st.learn_steps)
+        assert st.learn_steps >= budgets[-1]
+        rows = orows[k]
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        n_streams = 2 if graph == "cart_pole_ac" else 4
+        assert list(r.rng(k))[:n_streams] == list(e.rng())[:n_streams], f"replica {k}"
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+        rows_seen.add(len(rows))
+        e.close()
+    assert r.step_counts()[0] == total_learn
+    if graph != "pendulum_sarsa":
+        assert len(rows_seen) > 1                     # the replicas did stop at different trials
+    r.close()
