@@ -50,8 +50,8 @@ F64_PEAK_TFLOPS = 78.6                    # MI355X f64 vector = matrix rate: hal
 ALGORITHMIC_BYTES = {
     "pendulum_sarsa": dict(learn=2228.0, test=384.0, reads_per_test=48, oracle_bench_regime=2629.8),
     "cart_pole_ac": dict(learn=3226.3, test=128.0, reads_per_test=16),
-    "acrobot_q": dict(learn=2113.3, test=384.0, reads_per_test=48),
-    "compass_walker_q": dict(learn=3434.8, test=384.0, reads_per_test=48),
+    "acrobot_q": dict(learn=2154.2, test=384.0, reads_per_test=48),
+    "compass_walker_q": dict(learn=3446.6, test=384.0, reads_per_test=48),
 }
 
 # experiment graph -> how one GPU runs it
@@ -62,10 +62,14 @@ GRAPHS = {
     "cart_pole_ac": dict(trials=11, want_kernel=2, pmc_key="cart_pole_ac",
                          kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>",
                          text="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml)"),
-    "acrobot_q": dict(trials=32, want_kernel=2, pmc_key="acrobot_q",
+    # absorbing environments: episodes of very different lengths, so a launch is bounded by a STEPS budget per replica -- the second bound
+    # of the reference's own trial loop (experiment/online_learning:steps, online_learning.cpp:154; grlx_run_steps) -- instead of by a
+    # trial count, which makes every launch wait for its slowest replica (A/B on one box, tools/steps_budget_ab.py: acrobot 246 -> 359 M,
+    # walker 181 -> 217 M env-steps/s over the same total)
+    "acrobot_q": dict(trials=0, budget=1100, want_kernel=2, pmc_key="acrobot_q",
                       kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ, deferred update>",
                       text="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml)"),
-    "compass_walker_q": dict(trials=32, want_kernel=2, pmc_key="compass_walker_q",
+    "compass_walker_q": dict(trials=0, budget=12200, want_kernel=2, pmc_key="compass_walker_q",
                              kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, SpecWalkerQ, deferred update>",
                              text="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml)"),
 }
@@ -148,14 +152,14 @@ def oracle_spec(graph):
 _ORACLE_RUNS = {}
 
 
-def oracle_cpu_baseline(graph, budget_s, trials_in_regime):
-    key = (graph, budget_s, trials_in_regime)
+def oracle_cpu_baseline(graph, budget_s, trials_in_regime, steps_in_regime=0):
+    key = (graph, budget_s, trials_in_regime, steps_in_regime)
     if key not in _ORACLE_RUNS:
-        _ORACLE_RUNS[key] = _oracle_cpu_baseline(graph, budget_s, trials_in_regime)
+        _ORACLE_RUNS[key] = _oracle_cpu_baseline(graph, budget_s, trials_in_regime, steps_in_regime)
     return _ORACLE_RUNS[key]
 
 
-def _oracle_cpu_baseline(graph, budget_s, trials_in_regime):
+def _oracle_cpu_baseline(graph, budget_s, trials_in_regime, steps_in_regime):
     """The oracle (validated against the reference's golden files) on ONE host core, libm arithmetic = the reference's own:
     replica seed 1 for about `budget_s` seconds.  Also counts the algorithmic bytes per step on the first
     `trials_in_regime` trials (the ones bench.py times on the GPU)."""
@@ -165,8 +169,14 @@ def _oracle_cpu_baseline(graph, budget_s, trials_in_regime):
     e = ob.Experiment(spec, seed=1)
     rpt = ALGORITHMIC_BYTES[graph]["reads_per_test"]
     t0 = time.perf_counter()
-    e.run(trials_in_regime)
+    if steps_in_regime:
+        e.set_steps_budget(steps_in_regime)
+        e.run(1 << 20)
+        e.set_steps_budget(0)
+    else:
+        e.run(trials_in_regime)
     st = e.stats()
+    trials_in_regime = trials_in_regime or e.trials_run()
     counted = dict(learn=(8.0 * (st.weight_reads - st.test_steps * rpt) + 16.0 * st.weight_rmws) / max(st.learn_steps, 1), test=8.0 * rpt,
                    source=f"oracle, seed 1, trials 1-{trials_in_regime} ({int(st.learn_steps)} learning steps)")
     trials = trials_in_regime
@@ -239,20 +249,29 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
     ctx = []
     for k, (graph, seeds) in enumerate(parts):
         g = GRAPHS[graph]
-        rows_total = ((steps + warmup) * g["trials"]) // TRIALS_PER_STEP          # test_interval 10: one row per 11 trials
+        # test_interval 10: one row per 11 trials; with a steps budget the replicas write rows at their own pace: the curve is reduced
+        # over the first 16 rows (every replica has them after the first launches), the row arrays hold up to 1024
+        rows_total = ((steps + warmup) * g["trials"]) // TRIALS_PER_STEP if g["trials"] else 16
         # (two contexts sharing the GPU keep the layout grlx_create picks for their batch: forcing 8 replicas per wave to make both
         # kernels resident at once -- 2 x 512 waves -- was measured: the launch lasts as long as the walkers' longest episodes either
         # way, so it only idles half the SIMDs; with 4 replicas per wave the hardware backfills SIMDs as the acrobot's waves retire)
-        cfg = graph_config(graph, len(seeds), rows_total + 1, table_log2)
+        cfg = graph_config(graph, len(seeds), rows_total + 1 if g["trials"] else 1024, table_log2)
         stream = main_stream if len(parts) == 1 else torch.cuda.Stream()
         ctx.append(dict(graph=graph, g=g, seeds=seeds, runner=grl_amd.Runner(cfg, seeds), stream=stream, rows=rows_total,
                         ev=[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]))
     rows_max = max(c["rows"] for c in ctx)
     curve = torch.zeros((len(ctx), rows_max, 3), dtype=torch.float64, device="cuda")
 
-    for c in ctx:
-        for _ in range(warmup):
+    def launch(c, k):
+        """launch k (0-based, warm-up included) of context c: g["trials"] further trials, or whole trials up to a cumulative steps budget"""
+        if c["g"]["trials"]:
             c["runner"].run(c["g"]["trials"], c["stream"].cuda_stream)
+        else:
+            c["runner"].run_steps(1 << 20, (k + 1) * c["g"]["budget"], c["stream"].cuda_stream)
+
+    for c in ctx:
+        for k in range(warmup):
+            launch(c, k)
     for c in ctx:
         c["runner"].sync(c["stream"].cuda_stream)
         c["count0"] = c["runner"].step_counts()
@@ -265,7 +284,7 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
     for k in range(steps):
         for c in ctx:
             c["ev"][k][0].record(c["stream"])
-            c["runner"].run(c["g"]["trials"], c["stream"].cuda_stream)
+            launch(c, warmup + k)
             c["ev"][k][1].record(c["stream"])
     # the job's only collective: learning-curve statistics over all replicas of all GPUs
     for i, c in enumerate(ctx):
@@ -305,11 +324,13 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
     for i, c in enumerate(ctx):
         g = c["g"]
         n = len(c["seeds"])
-        text.append(f"{g['text']}, {n} independent-seed replicas per GPU, {g['trials']} trials per replica per step")
+        per_step = f"{g['trials']} trials per replica per step" if g["trials"] else f"whole trials up to {g['budget']} further learning steps per replica per step (experiment/online_learning:steps)"
+        text.append(f"{g['text']}, {n} independent-seed replicas per GPU, {per_step}")
         bytes_ = dict(ALGORITHMIC_BYTES[c["graph"]], source="committed figure (bench.py ALGORITHMIC_BYTES; tools/algorithmic_bytes.py)")
         cpu = None
         if cpu_baseline:
-            cpu, counted = oracle_cpu_baseline(c["graph"], 12.0 if (full_cpu_baseline and i == 0) else 4.0, (steps + warmup) * g["trials"])
+            cpu, counted = oracle_cpu_baseline(c["graph"], 12.0 if (full_cpu_baseline and i == 0) else 4.0, (steps + warmup) * g["trials"],
+                                               (steps + warmup) * g.get("budget", 0))
             if c["graph"] != "pendulum_sarsa":                  # the headline keeps SURVEY's declared 2228 B
                 bytes_.update(counted)
             else:
@@ -321,9 +342,9 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
         avg_ms = sum(c["kernel_ms"]) / len(c["kernel_ms"])
         alg = (c["learn"] * bytes_["learn"] + c["test"] * bytes_["test"]) / steps
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        traffic, issue, src = measured_pmc(g["pmc_key"], n, g["trials"]) if len(ctx) == 1 else (None, None, "none: concurrent contexts are not profiled separately")
+        traffic, issue, src = measured_pmc(g["pmc_key"], n, g["trials"] or g["budget"]) if len(ctx) == 1 else (None, None, "none: concurrent contexts are not profiled separately")
         mean_curve = curve_host[i, :c["rows"], 0] / curve_host[i, :c["rows"], 2].clip(min=1)
-        c["report"] = {"graph": c["graph"], "replicas": n, "trials_per_step": g["trials"], "replicas_per_wave": c["rpw"],
+        c["report"] = {"graph": c["graph"], "replicas": n, "trials_per_step": g["trials"] or None, "steps_budget_per_step": g.get("budget"), "replicas_per_wave": c["rpw"],
                        "env_steps_per_step_this_rank": (c["learn"] + c["test"]) / steps,
                        "mean_test_return_first_last": [float(mean_curve[0]), float(mean_curve[-1])],
                        "curve_replicas": float(curve_host[i, 0, 2]),

@@ -684,6 +684,7 @@ orc_exp *orc_create(const orc_spec *spec, long seed)
 }
 
 void orc_set_steps_budget(orc_exp *e, uint64_t steps) { e->steps_budget = steps; }
+int64_t orc_trials(const orc_exp *e) { return e->tt; }
 
 int orc_reset_run(orc_exp *e)
 { /* Experiment reset between runs (online_learning.cpp:307-308 -> Configurable::reset: {action: reset} walks the experiment's

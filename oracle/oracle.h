@@ -214,6 +214,7 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
 int           orc_reset_run(orc_exp *e);
 /* experiment/online_learning:steps: orc_run starts no further trial once the learning steps of the run have reached `steps` (0: no budget) */
 void          orc_set_steps_budget(orc_exp *e, uint64_t steps);
+int64_t       orc_trials(const orc_exp *e);                    /* trials of the run so far (tt) */
 void          orc_get_stats(const orc_exp *e, orc_stats *out);
 const double *orc_weights(const orc_exp *e, int table);        /* table 0: Q/critic, 1: actor, 2: target network of table 0 */
 int64_t       orc_target_syncs(const orc_exp *e);              /* synchronisations of the target network so far */

@@ -106,6 +106,7 @@ def load():
     L.orc_weights.argtypes = [C.c_void_p, C.c_int]; L.orc_weights.restype = P(C.c_double)
     L.orc_reset_run.argtypes = [C.c_void_p]; L.orc_reset_run.restype = C.c_int
     L.orc_set_steps_budget.argtypes = [C.c_void_p, C.c_uint64]; L.orc_set_steps_budget.restype = None
+    L.orc_trials.argtypes = [C.c_void_p]; L.orc_trials.restype = C.c_int64
     L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_double), C.c_size_t]; L.orc_set_weights.restype = C.c_int
     L.orc_target_syncs.argtypes = [C.c_void_p]; L.orc_target_syncs.restype = C.c_int64
     L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
@@ -182,6 +183,9 @@ class Experiment:
     def set_steps_budget(self, steps: int):
         """experiment/online_learning:steps (online_learning.cpp:154); 0 = none."""
         self.L.orc_set_steps_budget(self.h, int(steps))
+
+    def trials_run(self) -> int:
+        return int(self.L.orc_trials(self.h))
 
     def reset_run(self):
         """Experiment::reset() between two runs (online_learning.cpp:307-308)."""

@@ -10,11 +10,12 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import configs, oracle_binding as ob  # noqa: E402
 
-# graph -> (oracle spec builder, trials bench.py runs (warm-up + timed), weights read per test step)
+# graph -> (oracle spec builder, what bench.py runs (warm-up + timed): trials, or -(learning steps) for the steps-budget launches,
+#           weights read per test step)
 GRAPHS = {"pendulum_sarsa": (lambda: configs.pendulum(None, 1)[1], 23 * 11, 48),
           "cart_pole_ac": (lambda: configs.cart_pole_ac(None, 1)[1], 6 * 11, 16),
-          "acrobot_q": (lambda: configs.acrobot(None, 1)[1], 6 * 32, 48),
-          "compass_walker_q": (lambda: configs.compass_walker(None, 1)[1], 6 * 32, 48)}
+          "acrobot_q": (lambda: configs.acrobot(None, 1)[1], -6 * 1100, 48),
+          "compass_walker_q": (lambda: configs.compass_walker(None, 1)[1], -6 * 12200, 48)}
 
 
 def measure(graph, seed, trials=None):
@@ -22,7 +23,12 @@ def measure(graph, seed, trials=None):
     spec = make()
     spec.math = ob.MATH_LIBM
     e = ob.Experiment(spec, seed=seed)
-    e.run(trials or t)
+    t = trials or t
+    if t < 0:
+        e.set_steps_budget(-t)
+        e.run(1 << 20)
+    else:
+        e.run(t)
     st = e.stats()
     e.close()
     learn_reads = st.weight_reads - st.test_steps * rpt

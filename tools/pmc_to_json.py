@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel-name fragment -> (bench.py workload key, replicas, trials per launch, timed launches)
 WORKLOADS = [("rollout_kernel<0, 3, false, grlx::SpecPendulumTcA<0>", "pendulum_sarsa", 4096, 11, 20),
              ("rollout_ac_wide_kernel<1, 2, grlx::SpecCartPoleAc>", "cart_pole_ac", 16384, 11, 5),
-             ("rollout_wide_kernel<2, 3, 2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 32, 5),
-             ("rollout_wide_kernel<3, 3, 2, grlx::SpecWalkerQ>", "compass_walker_q", 8192, 32, 5)]
+             ("rollout_wide_kernel<2, 3, 2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 1100, 5),          # (steps budget per launch)
+             ("rollout_wide_kernel<3, 3, 2, grlx::SpecWalkerQ>", "compass_walker_q", 8192, 12200, 5)]
 
 
 def workload_of(name):
