@@ -80,7 +80,11 @@ WORKLOADS = {
     "cart_pole_ac": dict(replicas=16384, steps=5, warmup=1, dominant="cart_pole_ac", baseline_config=2),
     "acrobot_q": dict(replicas=8192, steps=5, warmup=1, dominant="acrobot_q", baseline_config=3),
     "compass_walker_q": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
-    "acrobot_walker": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
+    # both halves on every rank, each as 512 waves of 8 replicas: together one wave per SIMD, both kernels resident for the whole launch.
+    # The acrobot's budget per launch is set so that its kernel lasts about as long as the walkers' (an acrobot step costs a twentieth of a
+    # launch's walker work): otherwise its half of the chip idles for 95 % of every launch.
+    "acrobot_walker": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=8,
+                           budget={"acrobot_q": 22000}),
 }
 SECONDARY_ORDER = ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker"]
 
@@ -248,14 +252,13 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
     main_stream = torch.cuda.current_stream()
     ctx = []
     for k, (graph, seeds) in enumerate(parts):
-        g = GRAPHS[graph]
+        g = dict(GRAPHS[graph])
+        if graph in w.get("budget", {}):
+            g["budget"] = w["budget"][graph]
         # test_interval 10: one row per 11 trials; with a steps budget the replicas write rows at their own pace: the curve is reduced
         # over the first 16 rows (every replica has them after the first launches), the row arrays hold up to 1024
         rows_total = ((steps + warmup) * g["trials"]) // TRIALS_PER_STEP if g["trials"] else 16
-        # (two contexts sharing the GPU keep the layout grlx_create picks for their batch: forcing 8 replicas per wave to make both
-        # kernels resident at once -- 2 x 512 waves -- was measured: the launch lasts as long as the walkers' longest episodes either
-        # way, so it only idles half the SIMDs; with 4 replicas per wave the hardware backfills SIMDs as the acrobot's waves retire)
-        cfg = graph_config(graph, len(seeds), rows_total + 1 if g["trials"] else 1024, table_log2)
+        cfg = graph_config(graph, len(seeds), rows_total + 1 if g["trials"] else 1024, table_log2, w.get("replicas_per_wave", 0) if len(seeds) >= 8 else 0)
         stream = main_stream if len(parts) == 1 else torch.cuda.Stream()
         ctx.append(dict(graph=graph, g=g, seeds=seeds, runner=grl_amd.Runner(cfg, seeds), stream=stream, rows=rows_total,
                         ev=[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]))
