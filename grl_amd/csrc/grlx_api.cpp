@@ -218,6 +218,12 @@ int make_params(const grlx_config &c, DevParams *P)
     P->ac_step_limit = c.ac_step_limit;
     P->ac_update_method = c.ac_update_method;
     if (c.ac_update_method != 0 && c.ac_update_method != 1) return fail(GRLX_ERR_INVALID, "predictor/ac/action:update_method");
+    { // equal tile codings (cfg/cart_pole/ac_tc.yaml: the critic's projector copies the actor's resolution and memory): twin tables
+      const TileParams &a = P->tile_actor, &b = P->tile;
+      bool same = a.T == b.T && a.D == b.D && a.memory == b.memory && c.actor_projector.safe == c.projector.safe;
+      for (int i = 0; i < a.D && same; ++i) same = a.scaling[i] == b.scaling[i] && a.wrap[i] == b.wrap[i];
+      P->twin_tables = same ? 1 : 0;
+    }
     if (!(c.action_min < c.action_max)) return fail(GRLX_ERR_INVALID, "policy/action:{output_min,output_max}");
   }
 
@@ -1052,7 +1058,10 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
   // re-created on first touch from the image
   const size_t per_replica = sizeof(Entry) << ctx->P.logC;
   Entry *base = ctx->tables + (((size_t)table * (size_t)N + (size_t)first_replica) << ctx->P.logC);
-  HIP_TRY(hipMemset(base, 0, per_replica * (size_t)n_replicas));
+  if (ctx->P.twin_tables)      // twin tables keep their common key layout: the entries stay and take their values from the image
+    HIP_TRY(launch_reload_entries(ctx->P, table, first_replica, n_replicas, img, nullptr));
+  else
+    HIP_TRY(hipMemset(base, 0, per_replica * (size_t)n_replicas));
   HIP_TRY(launch_set_lazy_base(ctx->P, table, first_replica, n_replicas, img, nullptr));
   HIP_TRY(hipDeviceSynchronize());
   // an earlier image that no replica of any table refers to any more goes now (repeated loads do not accumulate)

@@ -110,6 +110,10 @@ struct DevParams {
   // experiment/online_learning:steps (online_learning.cpp:154): a replica starts no further trial once its learning steps of the run
   // (ReplicaState::ss) have reached this budget; 0 = none.  Honoured by rollout_kernel, rollout_wide_kernel and the actor-critic kernels.
   uint64_t steps_budget;
+  // Actor-critic with EQUAL tile codings for actor and critic (cfg/cart_pole/ac_tc.yaml: the critic copies resolution and memory):
+  // both tables are looked up with the same slots at every step, so the two sparse tables are kept as TWINS -- the same slot at the
+  // same position in both, created together, re-hashed together -- and one key resolution / one creation path serves both.
+  int32_t  twin_tables;
   int32_t  tile_safe;           // projector/tile_coding:safe: 1 = claim table, single projections claim; 2 = batch projections claim too (plain kernel)
   int32_t  target_interval;     // > 0: the Q table has a target network synchronised every so many update() calls
   double   target_tau;          // synchronisation strength (representation.h:284-296)
@@ -144,6 +148,7 @@ hipError_t launch_get_weights(const DevParams &P, int table, int replica, const 
 hipError_t launch_math(int op, const double *x, const double *y, int n, double *out, hipStream_t stream);
 hipError_t launch_rand48_at(uint64_t x0, const uint64_t *skip, int n, double *out, hipStream_t stream);
 hipError_t launch_curve_stats(const DevParams &P, int first, int count, double *out_dev, hipStream_t stream);
+hipError_t launch_reload_entries(const DevParams &P, int table, int first_replica, int n_replicas, const double *image_dev, hipStream_t stream);
 hipError_t launch_step_counts(const DevParams &P, uint64_t *out_dev /*[3]: learn, test, status-or*/, hipStream_t stream);
 // sparse-table growth (grlx_api.cpp: grow_tables).  max over replicas and tables of the occupied slots; every entry of the
 // old tables re-inserted into tables of 2^new_logC entries per replica (remap_dev, optional: [replica][2^old logC] new position of

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
   __shared__ uint32_t shp[64];
   const int lane = threadIdx.x & 63;
   const int Tn = P.tile.T;
-  uint32_t status = 0, inserted = 0;
+  uint32_t status = 0, inserted = 0, inserted_twin = 0;
   for (int i = 0; i < n; ++i)
   {
     const int r = replica[i];
@@ -373,7 +373,14 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
     double w = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const LinearParams &lp = table == 1 ? P.lin_actor : P.lin;
-    table_probe(tab, lp, P.states[r], table, valid, slot, pos, w, status, inserted);
+    if (P.twin_tables)
+    {
+      const Table other = table_of(P, 1 - table, r);
+      const LinearParams &olp = table == 1 ? P.lin : P.lin_actor;
+      table_probe(tab, lp, P.states[r], table, valid, slot, pos, w, status, inserted, &other, &olp, &inserted_twin);
+    }
+    else
+      table_probe(tab, lp, P.states[r], table, valid, slot, pos, w, status, inserted);
     sh[lane] = w;
     shp[lane] = valid ? pos : kInvalidPos;
     wave_sync();
@@ -405,6 +412,13 @@ __global__ __launch_bounds__(64) void table_op_kernel(DevParams P, int table, in
     for (int off = 32; off > 0; off >>= 1) ins += __shfl_xor(ins, off, 64);
     if (lane == 0 && ins) P.states[r].n_slots[table] += ins;
     inserted = 0;
+    if (P.twin_tables)
+    {
+      uint32_t it = inserted_twin;
+      for (int off = 32; off > 0; off >>= 1) it += __shfl_xor(it, off, 64);
+      if (lane == 0 && it) P.states[r].n_slots[1 - table] += it;
+      inserted_twin = 0;
+    }
     // sticky status of the replica this row worked on (not of the first row's)
     uint32_t st = status;
     for (int off = 32; off > 0; off >>= 1) st |= __shfl_xor(st, off, 64);
@@ -647,7 +661,15 @@ __global__ __launch_bounds__(64) void rehash_kernel(DevParams P, int n_tables, E
 {
   const int r = blockIdx.x % P.n_replicas, table = blockIdx.x / P.n_replicas;
   if (table >= n_tables) return;
+  // twin tables keep the same slot at the same position: table 0's placement decides, table 1's entries follow it
+  const bool twin = P.twin_tables != 0 && n_tables == 2;
+  if (twin && table == 1) return;
   const Table ot = table_of(P, table, r);
+  const Table ot2 = table_of(P, twin ? 1 : table, r);
+  Table nt2 = ot2;
+  nt2.base = reinterpret_cast<Bucket *>(new_tables + ((((size_t)(twin ? 1 : table)) * (size_t)P.n_replicas + (size_t)r) << new_logC));
+  nt2.bmask = (1u << (new_logC - 2)) - 1u;
+  nt2.shift = 32u - (new_logC - 2);
   Table nt;
   nt.base = reinterpret_cast<Bucket *>(new_tables + (((size_t)table * (size_t)P.n_replicas + (size_t)r) << new_logC));
   nt.bmask = (1u << (new_logC - 2)) - 1u;
@@ -673,9 +695,36 @@ __global__ __launch_bounds__(64) void rehash_kernel(DevParams P, int n_tables, E
       if (at == kInvalidPos) { atomicOr(&P.states[r].status, ST_TABLE_FULL); continue; }
       nt.base[at >> 2].aux[at & 3u] = ob.aux[way];
       nt.base[at >> 2].val[at & 3u] = ob.val[way];
+      if (twin)
+      {
+        nt2.base[at >> 2].key[at & 3u] = kw;
+        nt2.base[at >> 2].aux[at & 3u] = ot2.base[b].aux[way];
+        nt2.base[at >> 2].val[at & 3u] = ot2.base[b].val[way];
+      }
       if (map) map[b * 4 + way] = at;
     }
   }
+}
+
+// setParams() on a table whose entries must stay where they are (twin tables): every existing entry takes the image's value of its slot
+__global__ __launch_bounds__(64) void reload_entries_kernel(DevParams P, int table, int first_replica, const double *image)
+{
+  const int r = first_replica + blockIdx.x;
+  const Table t = table_of(P, table, r);
+  const uint32_t n_buckets = 1u << (P.logC - 2);
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += 64)
+    for (int way = 0; way < 4; ++way)
+    {
+      const uint32_t kw = t.base[b].key[way] & kKeyMask;
+      if (kw != 0u) t.base[b].val[way] = image[kw - 1u];
+    }
+}
+
+hipError_t launch_reload_entries(const DevParams &P, int table, int first_replica, int n_replicas, const double *image_dev, hipStream_t stream)
+{
+  if (n_replicas <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reload_entries_kernel, dim3(n_replicas), dim3(64), 0, stream, P, table, first_replica, image_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_rehash(const DevParams &P, int n_tables, Entry *new_tables, uint32_t new_logC, uint32_t *remap_dev, hipStream_t stream)

@@ -217,7 +217,11 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         }
         // both tables' home buckets in flight together: one memory round trip for the two lookups
         if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
-        if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
+        if (need_critic)
+        {
+          if (P.twin_tables) bucket_load_vals(tabC, table_home(tabC, slotC[0]), brC[0]);     // same keys as the actor's bucket
+          else table_issue<1>(tabC, slotC, lkC, brC);
+        }
       }
 
       // -------- the PREVIOUS step's critic update, in the shadow of the loads just issued
@@ -245,22 +249,44 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         uint32_t posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
         double wA[1] = {0}, wC[1] = {0};
         bool shA[1] = {false}, shC[1] = {false};
-        if (has_next)
-        {
-          table_get_finish<1>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
-                              [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
+        if (P.twin_tables)
+        { // equal tile codings: one resolution, one creation path for both tables (table_get_finish_twin)
+          if (has_next)
+          {
+            bool shared_event = false;
+            table_get_finish_twin<1>(tabA, tabC, N.lin_actor, N.lin, RS, slotA, lkA, brA, brC, need_critic, posA, wA, wC[0], shA, g, j, gmask,
+                                     sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a, ins_c,
+                                     [&](uint32_t mp) {
+                                       if (ap_pos == mp) ap_sh = true;
+                                       if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);
+                                       trace_share_event(tr, tabC, mp);
+                                       if (p_pos == mp) p_sh = true;
+                                       shared_event = true;
+                                     });
+            posC[0] = posA[0];
+            shC[0] = shA[0];
+            if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, p_pos);
+          }
         }
-        if (need_critic)
+        else
         {
-          bool shared_event = false;
-          table_get_finish<1>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
-                       [&](uint32_t mp) {
-                         if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);
-                         trace_share_event(tr, tabC, mp);
-                         if (p_pos == mp) p_sh = true;
-                         shared_event = true;
-                       });
-          if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, p_pos);
+          if (has_next)
+          {
+            table_get_finish<1>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_a,
+                                [&](uint32_t mp) { if (ap_pos == mp) ap_sh = true; });
+          }
+          if (need_critic)
+          {
+            bool shared_event = false;
+            table_get_finish<1>(tabC, N.lin, RS, 0, slotC, lkC, brC, posC, wC, shC, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump, status, ins_c,
+                         [&](uint32_t mp) {
+                           if (DEFER && ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);
+                           trace_share_event(tr, tabC, mp);
+                           if (p_pos == mp) p_sh = true;
+                           shared_event = true;
+                         });
+            if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, p_pos);
+          }
         }
         if (DEFER)
         { // critic values loaded before the deferred update: reload where the update wrote the table, patch the held eviction

@@ -308,7 +308,11 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           wpc = c.wp_seen;
         }
         if (has_next) table_issue<1>(tabA, slotA, lkA, brA);
-        if (need_critic) table_issue<1>(tabC, slotC, lkC, brC);
+        if (need_critic)
+        {
+          if (P.twin_tables) bucket_load_vals(tabC, table_home(tabC, slotC[0]), brC[0]);     // same keys as the actor's bucket
+          else table_issue<1>(tabC, slotC, lkC, brC);
+        }
       }
 
       GRLX_AC_STAMP(3)
@@ -335,6 +339,27 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         uint32_t posA[1] = {kInvalidPos}, posC[1] = {kInvalidPos};
         double wA[1] = {0}, wC[1] = {0};
         bool shA[1] = {false}, shC[1] = {false};
+        if (P.twin_tables)
+        { // equal tile codings: one resolution, one creation path for both tables (table_get_finish_twin)
+          if (has_next)
+          {
+            bool shared_event = false;
+            table_get_finish_twin<2>(tabA, tabC, N.lin_actor, N.lin, RS, slotA, lkA, brA, brC, need_critic, posA, wA, wC[0], shA, g, j, gmask,
+                                     sh_mb, sh_ms, sh_mail, sh_jump6, c.status, c.inserted2, c.inserted,
+                                     [&](uint32_t mp) {
+                                       if (c.ap_pos == mp) c.ap_sh = true;
+                                       if (ev.pos != kInvalidPos && ev.pos == mp) value_store(tabC, mp, ev.val);
+                                       trace_share_event(c.tr, tabC, mp);
+                                       if (c.p_pos == mp) c.p_sh = true;
+                                       shared_event = true;
+                                     });
+            posC[0] = posA[0];
+            shC[0] = shA[0];
+            if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, c.p_pos);
+          }
+        }
+        else
+        {
         if (has_next)
         {
           table_get_finish<1, 2>(tabA, N.lin_actor, RS, 1, slotA, lkA, brA, posA, wA, shA, g, j, gmask, sh_mb, sh_ms, sh_mail, sh_jump6,
@@ -352,6 +377,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
                                        shared_event = true;
                                      });
           if (rarely(__any(shared_event)) && update) wpc = value_load(tabC, c.p_pos);
+        }
         }
         {
           const bool risky = ev.n > 1u || (update && c.p_sh) || (need_critic && shC[0]);

@@ -55,6 +55,15 @@ __device__ __forceinline__ BucketRegs bucket_load(const Table &t, uint32_t b)
   return r;
 }
 
+// the values of a bucket only (twin tables: the keys are the other table's)
+__device__ __forceinline__ void bucket_load_vals(const Table &t, uint32_t b, BucketRegs &r)
+{
+  const Bucket *bp = &t.base[b];
+  const double2 v01 = *reinterpret_cast<const double2 *>(&bp->val[0]);
+  const double2 v23 = *reinterpret_cast<const double2 *>(&bp->val[2]);
+  r.v[0] = v01.x; r.v[1] = v01.y; r.v[2] = v23.x; r.v[3] = v23.y;
+}
+
 __device__ __forceinline__ uint4 bucket_keys(const Table &t, uint32_t b)
 {
   return *reinterpret_cast<const uint4 *>(t.base[b].key);
@@ -280,8 +289,10 @@ __device__ __noinline__ void table_insert_serial(const Table &t, bool todo, uint
 }
 
 // single lookup-or-create (fine-grained operators): lane = tiling
+// twin (DevParams::twin_tables): the other table of the pair and its parameters -- an entry created in one is created in both
 __device__ inline void table_probe(const Table &t, const LinearParams &lp, const ReplicaState &rs, int table, bool active,
-                                   uint32_t slot, uint32_t &pos, double &val, uint32_t &status, uint32_t &inserted)
+                                   uint32_t slot, uint32_t &pos, double &val, uint32_t &status, uint32_t &inserted,
+                                   const Table *twin = nullptr, const LinearParams *twin_lp = nullptr, uint32_t *twin_inserted = nullptr)
 {
   uint32_t sl[1] = {slot};
   Lookup lk[1];
@@ -293,11 +304,21 @@ __device__ inline void table_probe(const Table &t, const LinearParams &lp, const
   if (__any(miss))
   {
     if (miss) w0 = initial_weight(rs, table, lp, slot);
+    const uint32_t before = inserted;
     table_insert_serial(t, miss, slot, (uint32_t)(threadIdx.x & 31), w0, lk[0], v[0], status, inserted);
+    if (twin && miss && inserted != before)
+    {
+      entry_create(*twin, lk[0].pos, slot, (uint32_t)(threadIdx.x & 31), initial_weight(rs, 1 - table, *twin_lp, slot));
+      (*twin_inserted)++;
+    }
+    if (twin) wave_sync();
   }
   // keep the "touched by a second tiling" bit current (the fused kernel relies on it)
   if (active && lk[0].kw != 0u && ((lk[0].kw >> kOwnerShift) & 31u) != (uint32_t)(threadIdx.x & 31) && !(lk[0].kw & kSharedBit))
+  {
     t.base[(lk[0].pos >> 2) & t.bmask].key[lk[0].pos & 3u] = lk[0].kw | kSharedBit;
+    if (twin) twin->base[(lk[0].pos >> 2) & twin->bmask].key[lk[0].pos & 3u] = lk[0].kw | kSharedBit;
+  }
   pos = lk[0].pos;
   val = v[0];
 }

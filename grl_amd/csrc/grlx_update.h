@@ -336,6 +336,140 @@ __device__ __forceinline__ void td_update_lane(TraceRegs &tr, const Table &tab, 
   }
 }
 
+// Twin tables (DevParams::twin_tables): ONE lookup-or-create of `slot` for the actor's table A and the critic's table C, whose keys
+// are identical by construction.  A's bucket (brA, loaded by table_issue) is resolved as in table_get_finish<1>; the critic's value is
+// taken from its own bucket brC at the same way (want_c: the caller loaded it and wants the value), or loaded from C where the entry
+// sits in an overflow bucket.  A missing slot is created in BOTH tables at the same position (each with its own lazy initial weight);
+// a new cross-tiling sharing event marks the key word in both and calls on_share once.  insA / insC count the entries created.
+template <int LDSJ, typename OnShare>
+__device__ __forceinline__ void table_get_finish_twin(const Table &tabA, const Table &tabC, const LinearParams &lpA, const LinearParams &lpC,
+                                                      const ReplicaState &rs, const uint32_t (&slot)[1], Lookup (&lk)[1], const BucketRegs (&brA)[1],
+                                                      const BucketRegs (&brC)[1], bool want_c, uint32_t (&pos)[1], double (&wA)[1], double &wC, bool (&sh)[1],
+                                                      int g, int j, unsigned long long gmask, uint32_t *sh_mb, uint32_t *sh_ms, uint32_t *sh_mail,
+                                                      const uint64_t *sh_jump, uint32_t &status, uint32_t &insA, uint32_t &insC, OnShare on_share)
+{
+  const int lane = threadIdx.x & 63;
+  const uint32_t home = lk[0].bucket;
+  table_resolve<1>(tabA, slot, lk, brA, wA, status);
+  bool created = false;
+  double w0C = 0;
+  if (rarely(__any(lk[0].miss)))
+  { // (the claim protocol of table_get_finish, for one slot per lane; both tables have the same empty ways)
+    sh_mb[g * 16 + j] = lk[0].miss ? lk[0].bucket : 0xFFFFFFFFu;
+    sh_ms[g * 16 + j] = slot[0];
+    const uint32_t claims = (uint32_t)((__ballot(lk[0].miss) >> (16 * g)) & 0xFFFFull);
+    double w0A;
+    if constexpr (LDSJ == 1) { w0A = lazy_weight_lds(sh_jump, rs.TL0, lpA, slot[0]); w0C = lazy_weight_lds(sh_jump, rs.TL0, lpC, slot[0]); }
+    else if constexpr (LDSJ == 2) { w0A = lazy_weight_lds6(sh_jump, rs.TL0, lpA, slot[0]); w0C = lazy_weight_lds6(sh_jump, rs.TL0, lpC, slot[0]); }
+    else { w0A = lazy_weight(rs.TL0, lpA, slot[0]); w0C = lazy_weight(rs.TL0, lpC, slot[0]); }
+    {
+      const double *imgA = rs.lazy_base[1], *imgC = rs.lazy_base[0];
+      if (rarely(imgA != nullptr) && lk[0].miss) w0A = imgA[slot[0]];
+      if (rarely(imgC != nullptr) && lk[0].miss) w0C = imgC[slot[0]];
+    }
+    wave_sync();
+    uint32_t rank = 0u;
+    bool dup = false;
+    for (uint32_t mm = claims; mm != 0u; mm &= mm - 1u)
+    {
+      const int k = __builtin_ctz(mm);
+      const uint32_t ob = sh_mb[g * 16 + k], os = sh_ms[g * 16 + k];
+      const bool same_bucket = lk[0].miss && ob == lk[0].bucket && k != j;
+      dup = dup || (same_bucket && os == slot[0]);
+      rank += (same_bucket && os != slot[0] && k < j) ? 1u : 0u;
+    }
+    bool slow = false;
+    if (lk[0].miss)
+    {
+      uint32_t e = lk[0].empty;
+      for (uint32_t c = 0; c < rank; ++c) e &= e - 1u;
+      if (dup || e == 0u)
+        slow = true;
+      else
+      {
+        lk[0].pos = (lk[0].bucket << 2) | (uint32_t)__builtin_ctz(e);
+        lk[0].kw = 0u;
+        entry_create(tabA, lk[0].pos, slot[0], (uint32_t)j, w0A);
+        entry_create(tabC, lk[0].pos, slot[0], (uint32_t)j, w0C);
+        wA[0] = w0A;
+        insA++;
+        insC++;
+        created = true;
+      }
+    }
+    wave_sync();
+    if (rarely(__any(slow)))
+    { // out of line and rare: the serialised insert works on table A; whoever creates there creates the twin entry too
+      Lookup tmp = lk[0];
+      double tv = wA[0];
+      uint32_t tst = 0, tins = 0;
+      table_insert_serial(tabA, slow, slot[0], (uint32_t)j, w0A, tmp, tv, tst, tins);
+      if (slow && tins != 0u)
+      {
+        entry_create(tabC, tmp.pos, slot[0], (uint32_t)j, w0C);
+        insC++;
+        created = true;
+      }
+      wave_sync();
+      lk[0] = tmp;
+      wA[0] = tv;
+      status |= tst;
+      insA += tins;
+    }
+  }
+  pos[0] = lk[0].pos;
+  if (want_c)
+  { // the critic's value: its bucket holds the same keys, so the way is the one found in A
+    const uint32_t way = pos[0] & 3u;
+    const double v = (way == 0u) ? brC[0].v[0] : (way == 1u) ? brC[0].v[1] : (way == 2u) ? brC[0].v[2] : brC[0].v[3];
+    const bool at_home = (pos[0] >> 2) == home;
+    wC = created ? w0C : v;
+    if (rarely(__any(!created && !at_home)))
+      if (!created && !at_home) wC = value_load(tabC, pos[0]);       // overflow chain: the entry is not in the bucket that was loaded
+  }
+  // ---- slots shared between tilings: as in table_get_finish, the mark goes into both key words
+  const bool found = lk[0].kw != 0u;
+  const bool foreign = found && ((lk[0].kw >> kOwnerShift) & 31u) != (uint32_t)j;
+  sh[0] = found && (foreign || (lk[0].kw & kSharedBit) != 0u);
+  const bool fresh = foreign && (lk[0].kw & kSharedBit) == 0u;
+  if (rarely(__any(fresh)))
+  {
+    if (fresh)
+    {
+      tabA.base[(pos[0] >> 2) & tabA.bmask].key[pos[0] & 3u] = lk[0].kw | kSharedBit;
+      tabC.base[(pos[0] >> 2) & tabC.bmask].key[pos[0] & 3u] = lk[0].kw | kSharedBit;
+    }
+    unsigned long long pend = __ballot(fresh);
+    while (pend != 0ull)
+    { // one event per 16-lane group at a time
+      unsigned long long sel = 0ull;
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)
+      {
+        unsigned long long grp = pend & (0xFFFFull << (16 * gg));
+        sel |= grp & (~grp + 1ull);
+      }
+      const bool mine = ((sel >> lane) & 1ull) != 0ull;
+      const bool grp_has = (sel & gmask) != 0ull;
+      if (mine) sh_mail[g] = pos[0];
+      wave_sync();
+      if (grp_has)
+      {
+        const uint32_t mp = sh_mail[g];
+        on_share(mp);                                     // owner side: write back, switch to write-through
+        if (pos[0] == mp) sh[0] = true;
+      }
+      wave_sync();
+      if (mine)
+      { // the values the owner just wrote back
+        wA[0] = value_load(tabA, pos[0]);
+        if (want_c) wC = value_load(tabC, pos[0]);
+      }
+      pend &= ~sel;
+    }
+  }
+}
+
 // Lookup-or-create of NP slots of one lane in one table, all first-round loads in flight
 // together; creates missing slots (parallel LDS-ranked claims, serialised fallback) and
 // resolves new cross-tiling sharing events.  sh[i]: the slot is shared between tilings.

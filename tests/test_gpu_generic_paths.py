@@ -686,3 +686,33 @@ def test_steps_budget_stops_every_replica_at_its_own_trial(grlx, graph, n, budge
     if graph != "pendulum_sarsa":
         assert len(rows_seen) > 1                     # the replicas did stop at different trials
     r.close()
+
+
+@pytest.mark.parametrize("rpw", [4, 8])
+def test_actor_critic_with_different_tile_codings(grlx, rpw):
+    """cfg/cart_pole/ac_tc.yaml gives actor and critic the same tile coding, which the kernels exploit (twin tables: one key
+    resolution and one creation path for both).  With DIFFERENT tile codings -- another resolution and memory for the critic --
+    the two tables are independent again; rows, streams, states and both dense tables against the oracle, both wave layouts."""
+    from tests import configs
+    n, trials = 11, 23
+    cfg, spec = configs.cart_pole_ac(grlx, n, replicas_per_wave=rpw, end_stop_penalty=1)
+    for obj in (cfg, spec):
+        obj.projector.memory = 4194304
+        obj.projector.resolution[0] = 1.25
+        obj.projector.resolution[2] = 5.0
+    spec.math = ob.MATH_PORTABLE
+    seeds = np.arange(3, 3 + n)
+    r = grlx.Runner(cfg, seeds)
+    r.run(12); r.run(trials - 12); r.sync()
+    for k in (0, 5, 10):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+        assert_bit_equal(r.export_weights(k, 0), e.all_weights(0), f"critic table of replica {k}")
+        assert_bit_equal(r.export_weights(k, 1), e.all_weights(1), f"actor table of replica {k}")
+        e.close()
+    r.close()
