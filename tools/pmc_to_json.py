@@ -14,6 +14,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_hash  # noqa: E402  (identifies the device code the passes ran on)
 # kernel-name fragment -> (bench.py workload key, replicas, trials per launch, timed launches)
 WORKLOADS = [("rollout_kernel<0, 3, false, grlx::SpecPendulumTcA<0>", "pendulum_sarsa", 4096, 11, 20),
              ("rollout_ac_wide_kernel<1, 2, grlx::SpecCartPoleAc>", "cart_pole_ac", 16384, 11, 5),
@@ -26,6 +28,48 @@ def workload_of(name):
         if frag in name:
             return key, n, trials, timed
     return None
+
+
+def fqi_entry(out):
+    """The batch path (bench.py --workload pendulum_fqi_ann: one warm-up batch, one timed batch).  A "launch" of bench.py's roofline
+    object is the whole timed batch: per kernel name the second half of its launches, summed over all fqi kernels."""
+    def timed_sum(vals):
+        return sum(vals[len(vals) // 2:])
+    dur = defaultdict(list)
+    for path in sorted(glob.glob(os.path.join(out, "fqi_stats", "**", "*kernel_trace.csv"), recursive=True)):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if "fqi_" in row.get("Kernel_Name", ""):
+                    dur[row["Kernel_Name"].split("(")[0]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6)
+    for name, v in sorted(dur.items()):
+        print(f"fqi trace: {name}: launches={len(v)} timed batch: {len(v) - len(v) // 2} launches, {timed_sum(v):.3f} ms, mean {timed_sum(v) / max(len(v) - len(v) // 2, 1):.4f} ms")
+    counters = defaultdict(lambda: defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(out, "fqi_pmc*"))):
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if "fqi_" in row.get("Kernel_Name", ""):
+                        counters[row["Counter_Name"]][row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+    tot = {}
+    for cname, per_kernel in counters.items():
+        tot[cname] = sum(timed_sum(v) for v in per_kernel.values())
+        for kname, v in sorted(per_kernel.items()):
+            print(f"fqi pmc {cname} {kname}: launches={len(v)} timed-batch sum={timed_sum(v):.6g}")
+    if "FETCH_SIZE" not in tot or "WRITE_SIZE" not in tot:
+        return None
+    e = {"kernel": "fqi_epochs_kernel<20> (+ the other fqi kernels of one batch)", "replicas": 16, "trials_per_launch": 200000,
+         "hbm_bytes_per_launch": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, "fetch_bytes": tot["FETCH_SIZE"] * 1024.0,
+         "write_bytes": tot["WRITE_SIZE"] * 1024.0, "source": os.path.basename(out.rstrip("/")),
+         "note": "per timed batch (all kernels of the second grlx_fqi_run_batch); trials_per_launch holds the stored transitions"}
+    if all(k in tot for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES")) and tot["SQ_WAVE_CYCLES"]:
+        e["issue"] = (tot["SQ_ACTIVE_INST_VALU"] + tot["SQ_ACTIVE_INST_SCA"]) / tot["SQ_WAVE_CYCLES"]
+    if "SQ_WAIT_ANY" in tot and tot.get("SQ_WAVE_CYCLES"):
+        e["wait_any"] = tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"]
+    ek = [v for k, v in dur.items() if "fqi_epochs_kernel" in k]
+    if ek:
+        e["kernel_ms_trace"] = sum(timed_sum(v) for v in dur.values())
+        e["epochs_kernel_ms_per_launch"] = timed_sum(ek[0]) / max(len(ek[0]) - len(ek[0]) // 2, 1)
+    return e
 
 
 def main():
@@ -68,7 +112,8 @@ def main():
                     timed = v[-w[3]:]
                     means[w[0]][name] = sum(timed) / len(timed)
                     print(f"{os.path.basename(d)} {w[0]} {name}: launches={len(v)} mean_timed={means[w[0]][name]:.6g} last={v[-1]:.6g}")
-    doc = {"format": "per workload key of bench.py: HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE in KB x 1024, separate rocprofv3 --pmc "
+    doc = {"csrc_sha256": csrc_hash(), "source": os.path.basename(out.rstrip("/")),
+           "format": "per workload key of bench.py: HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE in KB x 1024, separate rocprofv3 --pmc "
                      "passes, mean of the timed launches; 64-B requests of 16-B loads: the gfx950 x2 correction for wide streaming reads is "
                      "not applied, MI355X_MICROARCH.md calls other widths uncalibrated) and issue = (SQ_ACTIVE_INST_VALU + SQ_ACTIVE_INST_SCA) "
                      "/ SQ_WAVE_CYCLES, all in quad-cycles; written by tools/pmc_to_json.py", "workloads": {}}
@@ -85,7 +130,12 @@ def main():
         if key in stats and "timed_ms" in stats[key]:
             e["kernel_ms_trace"] = stats[key]["timed_ms"]
         doc["workloads"][key] = e
+    fqi = fqi_entry(out)
+    if fqi:
+        doc["workloads"]["pendulum_fqi_ann"] = fqi
     print(json.dumps(doc, indent=1))
+    with open(os.path.join(out, "pmc_traffic.json"), "w") as f:      # (gpurun merges gpurun_out/ back: copy this one to profiles/)
+        json.dump(doc, f, indent=1)
     if write:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
             json.dump(doc, f, indent=1)
