@@ -136,8 +136,8 @@ def graph_config(graph, n, max_rows, table_log2=None, replicas_per_wave=0):
     make = {"pendulum_sarsa": grl_amd.pendulum_sarsa_config, "cart_pole_ac": grl_amd.cart_pole_ac_config,
             "acrobot_q": grl_amd.acrobot_q_config, "compass_walker_q": grl_amd.compass_walker_q_config}[graph]
     cfg = make(n)
-    if graph == "cart_pole_ac":
-        cfg.table_log2_capacity = 18      # pre-sized for the 66 trials of the run: no re-hash between the timed launches (the default, 2^16, grows)
+    if graph in ("cart_pole_ac", "compass_walker_q"):
+        cfg.table_log2_capacity = 18      # pre-sized for the whole run: no re-hash between the timed launches (the defaults, 2^16 / 2^17, grow)
     cfg.max_rows = max_rows
     if table_log2:
         cfg.table_log2_capacity = table_log2
@@ -448,6 +448,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: skip the other BASELINE.json configurations")
     ap.add_argument("--no-fqi", action="store_true", help="skip the batch-path entry among the secondaries")
+    ap.add_argument("--no-composite", action="store_true", help="profiling: skip acrobot_walker, whose two kernels are the ones of acrobot_q and compass_walker_q")
     ap.add_argument("--only", default="", help="synonym of --workload (kept for the profiling scripts)")
     ap.add_argument("--secondary-replicas", type=int, default=0, help="tests: replicas per GPU of the secondary workloads")
     ap.add_argument("--fqi-replicas", type=int, default=0, help="tests: replicas per GPU of the batch path")
@@ -493,6 +494,8 @@ def main():
         # the other configurations BASELINE.json names, each sharded over the same ranks and timed the same way
         sec = []
         for name in SECONDARY_ORDER:
+            if name == "acrobot_walker" and args.no_composite:
+                continue
             w = WORKLOADS[name]
             sec.append(run_rollout_workload(name, D, torch, w["steps"], w["warmup"], args.secondary_replicas or None, None, cpu))
         if not args.no_fqi:

@@ -9,11 +9,13 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-fqi"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-fqi --no-composite"
 FQI="python3 $ROOT/bench.py --no-cpu-baseline --workload pendulum_fqi_ann"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_under_stats.json 2> $OUT/stats.err
 echo "stats pass done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fqi_stats -- $FQI > $OUT/fqi_under_stats.json 2> $OUT/fqi_stats.err
+# (rocprofv3 of this image can crash in its own exit handler after a process that made cooperative launches: the trace and the
+#  bench line are complete by then, so a non-zero exit of these passes is noted, not fatal)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fqi_stats -- $FQI > $OUT/fqi_under_stats.json 2> $OUT/fqi_stats.err || echo "fqi stats pass: rocprofv3 exit code $?" >> $OUT/failed.txt
 echo "fqi stats pass done"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64"; do
