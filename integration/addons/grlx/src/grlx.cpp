@@ -269,15 +269,15 @@ LargeVector GrlxOnlineLearningExperiment::run()
   lower(&c);
 
   std::vector<double> curve;
+  // ONE instantiation for all runs, as in the reference: between two runs the experiment is reset, not re-created
+  // (online_learning.cpp:307-308 -> grlx_reset_run: parameters re-drawn from the continuing thread-local stream, traces cleared,
+  // decay back to 1, counters restart; no stream is reseeded).  Replica i is seeded seed + i.
+  std::vector<int64_t> seeds(replicas_);
+  for (int i = 0; i < replicas_; ++i) seeds[i] = (int64_t)seed_ + i;
+  grlx_ctx *ctx = NULL;
+  check(grlx_create(&c, &seeds[0], &ctx));
   for (int rr = 0; rr < runs_; ++rr)
   {
-    // Every run is a fresh instantiation: replica i of run rr is seeded seed + i + rr*replicas, i.e. what separate
-    // `grld -s <seed>` processes would do.  (The reference's own multi-run loop instead CONTINUES its RNG streams
-    // through reset(), online_learning.cpp:304-311 -- a difference that only shows for runs > 1.)
-    std::vector<int64_t> seeds(replicas_);
-    for (int i = 0; i < replicas_; ++i) seeds[i] = (int64_t)seed_ + i + (int64_t)rr * replicas_;
-    grlx_ctx *ctx = NULL;
-    check(grlx_create(&c, &seeds[0], &ctx));
     try
     {
       // load_file: the .dat parameter files a (CPU or GPU) grl saved; names as ParameterizedRepresentation builds them
@@ -329,8 +329,14 @@ LargeVector GrlxOnlineLearningExperiment::run()
       grlx_destroy(ctx);
       throw;
     }
-    grlx_destroy(ctx);
+    if (rr < runs_ - 1 && grlx_reset_run(ctx) != GRLX_OK)
+    {
+      const std::string e = grlx_last_error();
+      grlx_destroy(ctx);
+      throw Exception(e);
+    }
   }
+  grlx_destroy(ctx);
 
   LargeVector result;
   toVector(curve, result);
