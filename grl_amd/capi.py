@@ -45,7 +45,8 @@ class Config(C.Structure):
                 ("force_generic", C.c_int32),
                 ("slope_angle", C.c_double), ("initial_state_variation", C.c_double), ("negative_reward", C.c_double),
                 ("kappa", C.c_double), ("beta", C.c_double), ("replicas_per_wave", C.c_int32), ("tap_deferred", C.c_int32),
-                ("target_interval", C.c_int32), ("wave_limit", C.c_int32), ("table_log2_max", C.c_int32), ("target_tau", C.c_double)]
+                ("target_interval", C.c_int32), ("wave_limit", C.c_int32), ("table_log2_max", C.c_int32), ("target_tau", C.c_double),
+                ("test_trials", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class FqiConfig(C.Structure):

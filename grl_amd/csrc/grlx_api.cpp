@@ -259,6 +259,15 @@ int make_params(const grlx_config &c, DevParams *P)
     P->target_tau = c.target_tau;
     P->lin.draws_before = (uint64_t)c.projector.memory;     // the target is instantiated -- and draws -- first (representation.h:186-190)
   }
+  if (c.test_trials < 0) return fail(GRLX_ERR_INVALID, "experiment/online_learning:test_trials");
+  P->test_trials = c.test_trials > 1 ? c.test_trials : 1;
+  if (P->test_trials > 1)
+  {
+    const bool plain_q = !ac && !qv && c.target_interval == 0 && c.projector.safe == 0 && c.trace != GRLX_TRACE_ACCUMULATING && c.agent != GRLX_AGENT_ADVANTAGE;
+    if (!plain_q && !ac)
+      return fail(GRLX_ERR_INVALID, "experiment/online_learning:test_trials > 1 is built for SARSA / Q / Expected SARSA with the replacing trace and for the actor-critic agent");
+    if (c.tap_capacity > 0) return fail(GRLX_ERR_INVALID, "test_trials > 1 is not available with taps");
+  }
   P->epsilon = c.epsilon;
   P->decay_rate = c.decay_rate;
   P->decay_min = c.decay_min;

@@ -110,6 +110,7 @@ struct DevParams {
   // experiment/online_learning:steps (online_learning.cpp:154): a replica starts no further trial once its learning steps of the run
   // (ReplicaState::ss) have reached this budget; 0 = none.  Honoured by rollout_kernel, rollout_wide_kernel and the actor-critic kernels.
   uint64_t steps_budget;
+  int32_t  test_trials;         // experiment/online_learning:test_trials (>= 1): greedy episodes per test trial, averaged in the row
   // Actor-critic with EQUAL tile codings for actor and critic (cfg/cart_pole/ac_tc.yaml: the critic copies resolution and memory):
   // both tables are looked up with the same slots at every step, so the two sparse tables are kept as TWINS -- the same slot at the
   // same position in both, created together, re-hashed together -- and one key resolution / one creation path serves both.

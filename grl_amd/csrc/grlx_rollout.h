@@ -281,19 +281,27 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
     if (!__any(act)) break;
     const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;        // online_learning.cpp:160
-    double obs[D], reward = 0, total_reward = 0;
+    // a test trial is test_trials greedy episodes (online_learning.cpp:161-170): each starts the environment and the agent anew, while
+    // reward and time keep adding up (:202-203); a learning trial is one episode.  `time` doubles as the agent's episode time, which
+    // only learning episodes read (the sampler's decay at time 0).
+    double total_reward = 0, time = 0;
+    const int subtrials = (test && P.test_trials > 1) ? P.test_trials : 1;
+    for (int st = 0; st < P.test_trials; ++st)
+    {
+    const bool episode = act && st < subtrials;
+    if (!__any(episode)) break;
+    double obs[D], reward = 0;
     int terminal = 0;
-    bool running = act;
+    bool running = episode;
 
     // environment_->start (modeled.cpp:132-158)
-    if (act)
+    if (episode)
     {
       Env<ENV>::start(N, test, TL, G, x);
       Env<ENV>::observe(N, x, obs);
     }
     // agent->start: TDAgent::start clears the trace (td.cpp:50-61, sarsa.cpp:126-132); the
     // trace was written back at the end of the previous learning trial, so it is empty here
-    double time = 0;
     double action = 0;
     int    action_index = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0;
@@ -669,6 +677,7 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
     // end of the trial: the trace is cleared by the next TDAgent::start (td.cpp:54); write the
     // cached weights back now so that test trials and the host see them
     if (!test) trace_flush(tr, tab, true);
+    }   // episodes of the trial
 
     // row of a test trial (online_learning.cpp:238-262) -- or of every trial when test_interval < 0
     if (act && (ti >= 0 ? test : 1))
@@ -678,8 +687,8 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
         if (j == 0)
         {
           size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
-          P.row_reward[at] = total_reward;
-          P.row_time[at] = time;
+          P.row_reward[at] = total_reward / (double)subtrials;              // :224-225
+          P.row_time[at] = time / (double)subtrials;
           P.row_steps[at] = ss;
           P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
         }

@@ -169,15 +169,23 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     if (!__any(act)) break;
     const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
-    double obs[D], reward = 0, total_reward = 0;
+    // a test trial is test_trials greedy episodes (online_learning.cpp:161-170), reward and time adding up across them; `time` doubles
+    // as the agent's episode time, which only learning episodes read (noise reset and decay at time 0)
+    double total_reward = 0, time = 0;
+    const int subtrials = (test && P.test_trials > 1) ? P.test_trials : 1;
+    for (int st = 0; st < P.test_trials; ++st)
+    {
+    const bool episode = act && st < subtrials;
+    if (!__any(episode)) break;
+    double obs[D], reward = 0;
     int terminal = 0;
-    bool running = act;
-    if (act)
+    bool running = episode;
+    if (episode)
     {
       Env<ENV>::start(N, test, TL, G, x);
       Env<ENV>::observe(N, x, obs);
     }
-    double time = 0, action = 0;
+    double action = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0, ap_pos = kInvalidPos, ap_slot = 0;
     bool p_sh = false, ap_sh = false;
     double wap_seen = 0, wpc_seen = 0;
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
     // end of a learning trial: make the table current (test trials and the host read it); the
     // entries themselves stay -- the reference never clears the critic's trace
     if (!test) trace_flush(tr, tabC, false);
+    }   // episodes of the trial
 
     if (act && (ti >= 0 ? test : 1))
     {
@@ -458,8 +467,8 @@ __global__ __launch_bounds__(64) void rollout_ac_kernel(DevParams P, int n_trial
         if (j == 0)
         {
           size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
-          P.row_reward[at] = total_reward;
-          P.row_time[at] = time;
+          P.row_reward[at] = total_reward / (double)subtrials;              // online_learning.cpp:224-225
+          P.row_time[at] = time / (double)subtrials;
           P.row_steps[at] = ss;
           P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
         }

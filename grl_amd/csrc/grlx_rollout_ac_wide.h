@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     s.ending = false;
     s.rows = RS.rows;
     s.trials_left = (P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget) ? 0 : n_trials;
+    s.sub_left = 0;
   };
   // ... and back: the critic's trace is persisted (its weights go to the table), the counters and streams to the replica
   // (the environment state follows from the env lanes, see sh_xwb)
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     s.ending = false;
     s.rows = 0;
     s.trials_left = 0;
+    s.sub_left = 0;
   };
   // the env lanes of a retired slot still hold its last state (and status bits of its steps): to its replica, before the
   // slot's next replica starts
@@ -498,6 +500,13 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       if (__any(at_rest))
       {
         bool between = at_rest && s.trials_left > 0;
+        bool again = false;                                 // another greedy episode of the same test trial follows (test_trials)
+        if (between && s.ending && s.test && s.sub_left > 0)
+        {
+          s.sub_left--;
+          s.ending = false;
+          again = true;
+        }
         if (between && s.ending)
         { // end of a learning trial: make the table current; the entries stay -- the reference never clears the critic's trace
           if (!s.test) trace_flush(c.tr, tabC, false);
@@ -509,8 +518,9 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
               if (j == 0)
               {
                 const size_t at = (size_t)s.rows * (size_t)P.n_replicas + (size_t)r;
-                P.row_reward[at] = s.total_reward;
-                P.row_time[at] = s.time;
+                const double sub = (s.test && P.test_trials > 1) ? (double)P.test_trials : 1.;     // online_learning.cpp:224-225
+                P.row_reward[at] = s.total_reward / sub;
+                P.row_time[at] = s.time / sub;
                 P.row_steps[at] = s.ss;
                 P.row_trial[at] = (ti >= 0) ? (s.tt + 1 - (s.tt + 1) / (ti + 1)) : s.tt;
               }
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           if (P.steps_budget != 0u && (uint64_t)s.ss >= P.steps_budget) s.trials_left = 0;        // online_learning.cpp:154: `ss < steps_`
           s.ending = false;
         }
-        if (at_rest && s.trials_left == 0)
+        if (at_rest && s.trials_left == 0 && !again)
         { // this replica is done: back to HBM, and the next one from the queue (group-uniform: all 16 lanes are here)
           slot_store(r, q, c, s);
           uint32_t nr = 0u;
@@ -540,10 +550,14 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           else { slot_empty(c, s); now_live = false; }
           between = now_live && s.trials_left > 0;
         }
-        if (between && s.trials_left > 0)
+        if (between && (s.trials_left > 0 || again))
         {
           const int ti = N.test_interval;
-          s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;
+          if (!again)
+          {
+            s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;
+            s.sub_left = s.test ? P.test_trials - 1 : 0;
+          }
           double xs[S], ob0[D];
           Env<ENV>::start(N, s.test, s.TL, s.G, xs);
           Env<ENV>::observe(N, xs, ob0);
@@ -551,8 +565,11 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
 #pragma unroll
           for (int i = 0; i < D; ++i) sh_obs[i * R + q] = ob0[i];
-          s.total_reward = 0;
-          s.time = 0;
+          if (!again)
+          { // (reward and time keep adding up across the episodes of one test trial)
+            s.total_reward = 0;
+            s.time = 0;
+          }
           s.action = 0;
           s.running = true;
           s.first = true;

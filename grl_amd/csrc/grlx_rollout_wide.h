@@ -111,7 +111,7 @@ __device__ __forceinline__ void wide_unpark(WideLane &c, const uint4 *sh_ctx, co
 
 // per-replica scalars of the table role, parked as a structure of arrays [field][replica in wave]
 enum { WR_G = 0, WR_TL, WR_S1, WR_EPS, WR_TT, WR_SS, WR_TSTEPS, WR_TOTAL, WR_TIME, WR_ACTION, WR_FIELDS64 };
-enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_LEFT, WR_FIELDS32 };
+enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_LEFT, WR_SUB, WR_FIELDS32 };
 enum : uint32_t { WF_RUNNING = 1u, WF_FIRST = 2u, WF_TEST = 4u, WF_ENDING = 8u };
 
 struct WideRep {
@@ -126,6 +126,7 @@ struct WideRep {
   int      test;
   uint32_t rows;
   int      trials_left;         // trials of this launch the replica has not finished yet
+  int      sub_left;            // greedy episodes the running test trial still has to run after this one (test_trials, online_learning.cpp:161-170)
 };
 
 template <int R>
@@ -145,6 +146,7 @@ __device__ __forceinline__ void wide_rep_store(const WideRep &s, uint64_t *sh64,
   sh32[WR_FLAGS * R + q] = (s.running ? WF_RUNNING : 0u) | (s.first ? WF_FIRST : 0u) | (s.test ? WF_TEST : 0u) | (s.ending ? WF_ENDING : 0u);
   sh32[WR_ROWS * R + q] = s.rows;
   sh32[WR_LEFT * R + q] = (uint32_t)s.trials_left;
+  sh32[WR_SUB * R + q] = (uint32_t)s.sub_left;
 }
 
 template <int R>
@@ -168,6 +170,7 @@ __device__ __forceinline__ void wide_rep_load(WideRep &s, const uint64_t *sh64, 
   s.ending = (f & WF_ENDING) != 0u;
   s.rows = sh32[WR_ROWS * R + q];
   s.trials_left = (int)sh32[WR_LEFT * R + q];
+  s.sub_left = (int)sh32[WR_SUB * R + q];
 }
 
 // B sub-batches of four replicas per wave.  Production ordering only (deferred TD update, no taps, no stamps): the
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     s.ending = false;
     s.rows = RS.rows;
     s.trials_left = (live && !(P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget)) ? n_trials : 0;
+    s.sub_left = 0;
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
@@ -544,6 +548,13 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
         const bool between = !s.running && !c.pd && s.trials_left > 0;
         if (__any(between))
         {
+          bool again = false;                                 // another greedy episode of the same test trial follows (test_trials)
+          if (between && s.ending && s.test && s.sub_left > 0)
+          {
+            s.sub_left--;
+            s.ending = false;
+            again = true;
+          }
           if (between && s.ending)
           { // end of the trial: write the cached weights back (test trials and the host read the table); the row
             if (!s.test) trace_flush(c.tr, tab, true);       // the next TDAgent::start clears the trace (td.cpp:54)
@@ -555,8 +566,9 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
                 if (j == 0)
                 {
                   const size_t at = (size_t)s.rows * (size_t)P.n_replicas + (size_t)r;
-                  P.row_reward[at] = s.total_reward;
-                  P.row_time[at] = s.time;
+                  const double sub = (s.test && P.test_trials > 1) ? (double)P.test_trials : 1.;     // :224-225
+                  P.row_reward[at] = s.total_reward / sub;
+                  P.row_time[at] = s.time / sub;
                   P.row_steps[at] = s.ss;
                   P.row_trial[at] = (ti >= 0) ? (s.tt + 1 - (s.tt + 1) / (ti + 1)) : s.tt;
                 }
@@ -570,10 +582,14 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             if (P.steps_budget != 0u && (uint64_t)s.ss >= P.steps_budget) s.trials_left = 0;      // online_learning.cpp:154: `ss < steps_`
             s.ending = false;
           }
-          if (between && s.trials_left > 0)
+          if (between && (s.trials_left > 0 || again))
           { // start of the next trial (the start state may draw from the replica's RNG streams)
             const int ti = N.test_interval;
-            s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;             // online_learning.cpp:160
+            if (!again)
+            {
+              s.test = (ti >= 0 && s.tt % (ti + 1) == ti) ? 1 : 0;           // online_learning.cpp:160
+              s.sub_left = s.test ? P.test_trials - 1 : 0;
+            }
             double xs[S], ob0[D];
             Env<ENV>::start(N, s.test, s.TL, s.G, xs);                       // modeled.cpp:132-158
             Env<ENV>::observe(N, xs, ob0);
@@ -581,8 +597,11 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
 #pragma unroll
             for (int i = 0; i < D; ++i) sh_obs[i * R + q] = ob0[i];
-            s.total_reward = 0;
-            s.time = 0;
+            if (!again)
+            { // (reward and time keep adding up across the episodes of one test trial, :202-203)
+              s.total_reward = 0;
+              s.time = 0;
+            }
             s.action = 0;
             s.action_index = 0;
             s.running = true;

@@ -874,8 +874,9 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     if (save_every != "never" && save_every != "run" && save_every != "test" && save_every != "trial")
       throw bad_param("experiment/online_learning:save_every");
     if (steps < 0) throw bad_param("experiment/online_learning:steps");
-    if ((int)config["rate"] != 0 || test_trials != 1)
-      throw Exception(path() + ": rate / test_trials are outside the accelerated path");
+    if (test_trials < 1) throw bad_param("experiment/online_learning:test_trials");
+    if ((int)config["rate"] != 0)
+      throw Exception(path() + ": rate (wall-clock pacing) is outside the accelerated path");
     exporter = dynamic_cast<CSVExporter *>(config["exporter"].ptr());
     if (config["exporter"].ptr() && !exporter) throw Exception(path() + ": only exporter/csv is available on the accelerated path");
     if (exporter) exporter->init({"time", "observation", "action", "reward", "terminal"});      // online_learning.cpp:74-75
@@ -912,6 +913,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
   {
     grlx_config_pendulum_sarsa(c);
     c->test_interval = test_interval;
+    c->test_trials = test_trials;
     environment->lower_env(c);
 
     if (const ActionACPredictor *ac = dynamic_cast<const ActionACPredictor *>(agent->predictor))

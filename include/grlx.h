@@ -154,6 +154,11 @@ typedef struct {
    * to the initial size = fixed tables, overflow is then the sticky error GRLX_ERR_TABLE_FULL, as within one launch. */
   int32_t  table_log2_max;
   double   target_tau;
+  /* experiment/online_learning:test_trials (online_learning.cpp:160-225): a test trial is `test_trials` greedy episodes, each begun with
+   * environment start and agent start; reward and time keep adding up across them and the row holds their means.  0 and 1 = one episode.
+   * Built for SARSA / Q / Expected SARSA with the replacing trace and for the actor-critic agent. */
+  int32_t  test_trials;
+  int32_t  reserved0;
 } grlx_config;
 
 typedef struct grlx_ctx grlx_ctx;

@@ -744,7 +744,10 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
     double obs[ORC_MAX_DIMS], reward, total_reward = 0, total_time = 0;
     int terminal;
     act_t act;
+    const int subtrials = (test && s->test_trials > 1) ? s->test_trials : 1;     /* :161 */
 
+    for (int st = 0; st < subtrials; ++st)
+    { /* :170-222: every sub-trial starts the environment and the agent; reward and time keep adding up */
     /* environment_->start, modeled.cpp:132-158 */
     orc_env_start(s, e, test, e->state);
     orc_env_observe(s, e->state, obs);
@@ -875,6 +878,9 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
         for (int j = 0; j < ap.n && j < 16; ++j) tp->p_idx[16 + j] = (uint32_t)ap.idx[j];   /* actor projection (AC) */
       }
     } while (!terminal);
+    } /* sub-trials */
+    total_reward /= subtrials;                                  /* :224-225 */
+    total_time /= subtrials;
 
     if (ti >= 0 ? test : 1)
     { /* :238-262 */

@@ -141,6 +141,8 @@ typedef struct {
    * of the first projection that is written through it (single projections claim, the policy's batch projections do
    * not); a later projection with another hash sum that lands on a claimed slot moves on to the next free one */
   int    safe;
+  /* experiment/online_learning:test_trials (online_learning.cpp:160-225): greedy episodes per test trial, averaged in the row; 0, 1 = one */
+  int    test_trials;
 } orc_spec;
 
 /* fill with the values of the reference's tests/pendulum-sarsa-tc.yaml */

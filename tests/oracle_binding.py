@@ -44,7 +44,7 @@ class Spec(C.Structure):
                 ("ac_decay_rate", C.c_double), ("ac_decay_min", C.c_double),
                 ("ac_update_method", C.c_int), ("ac_step_limit", C.c_double), ("math", C.c_int), ("tap_starts", C.c_int), ("kappa", C.c_double), ("beta", C.c_double),
                 ("pid_p", C.c_double * MAX_DIMS), ("pid_setpoint", C.c_double * MAX_DIMS),
-                ("target_interval", C.c_int), ("target_tau", C.c_double), ("safe", C.c_int)]
+                ("target_interval", C.c_int), ("target_tau", C.c_double), ("safe", C.c_int), ("test_trials", C.c_int)]
 
 
 class FqiSpec(C.Structure):

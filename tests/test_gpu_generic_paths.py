@@ -716,3 +716,66 @@ def test_actor_critic_with_different_tile_codings(grlx, rpw):
         assert_bit_equal(r.export_weights(k, 1), e.all_weights(1), f"actor table of replica {k}")
         e.close()
     r.close()
+
+
+@pytest.mark.parametrize("graph,n", [("pendulum_sarsa", 6), ("acrobot_q", 13), ("compass_walker_q", 9), ("cart_pole_ac", 9)])
+@pytest.mark.parametrize("rpw", [4, 8])
+def test_test_trials_runs_several_greedy_episodes_per_test_trial(grlx, graph, n, rpw):
+    """experiment/online_learning:test_trials = 3 (online_learning.cpp:160-225): a test trial is three greedy episodes, each begun with
+    environment start and agent start; reward and time keep adding up across them and the row holds their means (one running sum,
+    then one division -- not the mean of three sums).  Rows (reward AND time), streams, states, step counts against the oracle, both wave
+    layouts; the second half of the run under a steps budget."""
+    from tests import configs
+    make = {"acrobot_q": configs.acrobot, "compass_walker_q": configs.compass_walker, "cart_pole_ac": configs.cart_pole_ac,
+            "pendulum_sarsa": lambda g, k, **o: configs.pendulum(g, k, agent=0, **o)}[graph]
+    over = dict(replicas_per_wave=rpw, max_rows=200, test_trials=3)
+    if graph == "cart_pole_ac":
+        over["end_stop_penalty"] = 1
+    cfg, spec = make(grlx, n, **over)
+    spec.test_trials = 3
+    spec.math = ob.MATH_PORTABLE
+    seeds = np.arange(11, 11 + n)
+    r = grlx.Runner(cfg, seeds)
+    r.run(23)
+    r.run_steps(1000, 3000)
+    r.sync()
+    learn = test = 0
+    for k in range(n):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows = e.run(23)[0]
+        e.set_steps_budget(3000)
+        rows += e.run(1000)[0]
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows] and list(s) == [x.steps for x in rows], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"mean returns of replica {k}")
+        assert_bit_equal(r.row_times(k, 0, len(rows)), [x.time for x in rows], f"mean episode times of replica {k}")
+        n_streams = 2 if graph == "cart_pole_ac" else 4
+        assert list(r.rng(k))[:n_streams] == list(e.rng())[:n_streams], f"replica {k}"
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+        st = e.stats()
+        learn += int(st.learn_steps); test += int(st.test_steps)
+        e.close()
+    assert r.step_counts() == (learn, test)
+    r.close()
+
+
+def test_deployer_test_trials(grlx, tmp_path):
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    text = _golden_yaml()
+    assert "test_interval: 10" in text
+    y = tmp_path / "tt.yaml"
+    y.write_text(text.replace("test_interval: 10", "test_interval: 10\n  test_trials: 2").replace("trials: 2000", "trials: 33"))
+    res = subprocess.run([grlxd, "-s", "9", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    spec = ob.pendulum_sarsa_spec()
+    spec.test_trials = 2
+    e = ob.Experiment(spec, seed=9)
+    rows, _ = e.run(33)
+    got = (tmp_path / "pendulum-sarsa-tc-0.txt").read_text().split("\n")
+    assert len(got) == 4 and got[3] == ""
+    for line, row in zip(got, rows):      # online_learning.cpp:243: trial, steps, reward, episode time (both means), reward / time, wall time
+        f = line.split()
+        assert int(f[0]) == row.trial and int(f[1]) == row.steps and f[2] == "%.3f" % row.reward and f[3] == "%.3f" % row.time
+    e.close()
