@@ -26,11 +26,11 @@ class GrlxOnlineLearningExperiment : public Experiment
 
   protected:
     Configurable *agent_, *test_agent_, *environment_;
-    int runs_, trials_, test_interval_, replicas_, seed_, table_log2_capacity_;
+    int runs_, trials_, steps_, test_interval_, test_trials_, replicas_, seed_, table_log2_capacity_;
     std::string output_, load_file_, save_every_;
 
   public:
-    GrlxOnlineLearningExperiment() : agent_(NULL), test_agent_(NULL), environment_(NULL), runs_(1), trials_(0), test_interval_(-1),
+    GrlxOnlineLearningExperiment() : agent_(NULL), test_agent_(NULL), environment_(NULL), runs_(1), trials_(0), steps_(0), test_interval_(-1), test_trials_(1),
                                      replicas_(1), seed_(1), table_log2_capacity_(0), save_every_("never") { }
 
     // From Configurable

@@ -42,11 +42,13 @@ void check(int rc)
 // ---------------------------------------------------------------------------------------------------------------
 
 void GrlxOnlineLearningExperiment::request(ConfigurationRequest *config)
-{ // mirrors OnlineLearningExperiment::request (online_learning.cpp:39-67); `steps`, `rate`, `test_trials`, signals and
-  // the exporter have no counterpart on the fused path
+{ // mirrors OnlineLearningExperiment::request (online_learning.cpp:39-67); `rate`, signals and the exporter have no counterpart
+  // on the fused path
   config->push_back(CRP("runs", "Number of separate learning runs to perform", runs_, CRP::Configuration, 1));
-  config->push_back(CRP("trials", "Number of episodes per learning run", trials_, CRP::Configuration, 1));
+  config->push_back(CRP("trials", "Number of episodes per learning run (0 = bounded by steps)", trials_, CRP::Configuration, 0));
+  config->push_back(CRP("steps", "Number of steps per learning run (0 = bounded by trials)", steps_, CRP::Configuration, 0));
   config->push_back(CRP("test_interval", "Number of episodes in between test trials", test_interval_, CRP::Configuration, -1));
+  config->push_back(CRP("test_trials", "Number of test trials per interval", test_trials_, CRP::Configuration, 1));
   config->push_back(CRP("output", "Output base filename", output_));
   config->push_back(CRP("replicas", "Independent-seed replicas run side by side on the GPU (experiment/multi analogue)", replicas_, CRP::Configuration, 1));
   config->push_back(CRP("seed", "Seed of replica 0 (replica i uses seed+i, as `grld -s` would for separate processes)", seed_));
@@ -83,6 +85,9 @@ void GrlxOnlineLearningExperiment::configure(Configuration &config)
   runs_ = config["runs"];
   trials_ = config["trials"];
   test_interval_ = config["test_interval"];
+  steps_ = config["steps"];
+  test_trials_ = config["test_trials"];
+  if (!trials_ && !steps_) throw bad_param("experiment/online_learning/grlx:{trials,steps} (one of them must bound the run)");
   output_ = config["output"].str();
   replicas_ = config["replicas"];
   seed_ = config["seed"];
@@ -140,8 +145,13 @@ void GrlxOnlineLearningExperiment::lower(grlx_config *c) const
   grlx_config_pendulum_sarsa(c);                                    // defaults of every field, then the tree's values
   c->n_replicas = replicas_;
   c->test_interval = test_interval_;
+  c->test_trials = test_trials_;
   c->table_log2_capacity = table_log2_capacity_;
-  c->max_rows = test_interval_ >= 0 ? trials_ / (test_interval_ + 1) + 1 : trials_ + 1;
+  {
+    // rows a run can write: with a steps budget alone a trial has at least one learning step
+    const int trial_cap = trials_ ? trials_ : steps_ * (test_interval_ >= 0 ? 2 : 1) + 1;
+    c->max_rows = test_interval_ >= 0 ? trial_cap / (test_interval_ + 1) + 1 : trial_cap + 1;
+  }
 
   // ---- environment/modeled { model, task }
   const Configurable *model = (*environment_)["model"].ptr(), *task = (*environment_)["task"].ptr();
@@ -285,14 +295,16 @@ LargeVector GrlxOnlineLearningExperiment::run()
       // ... one grlx_load_weights(ctx, table, 0, replicas_, data, count) per representation of the agent (table 0 =
       // Q / critic, table 1 = actor / V) exactly as grl_amd/csrc/host/objects.cpp does; omitted when load_file is empty.
 
-      check(grlx_run(ctx, trials_, NULL));
+      // the trial loop with both of its bounds (online_learning.cpp:154); with a steps budget the clones stop at trials of their own
+      if (steps_) check(grlx_run_steps(ctx, trials_ ? trials_ : (1 << 30), (uint64_t)steps_, NULL));
+      else check(grlx_run(ctx, trials_, NULL));
       check(grlx_sync(ctx, NULL));
 
-      const int n = grlx_rows(ctx);
-      std::vector<int64_t> trial(n), steps(n);
-      std::vector<double> reward(n), time(n);
       for (int i = 0; i < replicas_; ++i)
       { // `<output>-<run>@<i>.txt` as experiment/multi names its clones' files (multi.cpp:52-56); single replica: `<output>-<run>.txt`
+        const int n = grlx_replica_rows(ctx, i);
+        std::vector<int64_t> trial(n), steps(n);
+        std::vector<double> reward(n), time(n);
         check(grlx_read_rows(ctx, i, 0, n, &trial[0], &steps[0], &reward[0]));
         check(grlx_read_row_times(ctx, i, 0, n, &time[0]));
         if (!output_.empty())
