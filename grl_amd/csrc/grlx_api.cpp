@@ -239,11 +239,10 @@ int make_params(const grlx_config &c, DevParams *P)
 
   if (c.projector.safe >= 1)
   { // claim table of the tile coding: its own (plain) kernel
-    if ((c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q) || (c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) ||
+    if ((c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q) || c.env == GRLX_ENV_CART_POLE_BALANCING ||
         c.action_steps != 3 || c.trace == GRLX_TRACE_ACCUMULATING)
-      return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe >= 1 is built for predictor/critic/sarsa and predictor/critic/q on the pendulum and the "
-                                    "acrobot with 3 actions, replacing or no trace");
-    if (c.env == GRLX_ENV_ACROBOT && c.target_interval > 0) return fail(GRLX_ERR_INVALID, "safe >= 1 together with a target network is built for the pendulum");
+      return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe >= 1 is built for predictor/critic/sarsa and predictor/critic/q with 3 actions, replacing or no trace");
+    if (c.env != GRLX_ENV_PENDULUM && c.target_interval > 0) return fail(GRLX_ERR_INVALID, "safe >= 1 together with a target network is built for the pendulum");
     P->tile_safe = c.projector.safe;         // 2: the policy's batch projections claim too
   }
   if ((ac || qv) && c.actor_projector.safe != 0) return fail(GRLX_ERR_INVALID, "projector/tile_coding:safe on the second table");
@@ -252,8 +251,8 @@ int make_params(const grlx_config &c, DevParams *P)
   { // target network of the Q table: its own (plain) kernel
     if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q)
       return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:interval (a target network is built for predictor/critic/sarsa and predictor/critic/q)");
-    if ((c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) || c.action_steps != 3 || c.trace == GRLX_TRACE_ACCUMULATING)
-      return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:interval (built for the pendulum and the acrobot with 3 actions, replacing or no trace)");
+    if (c.env == GRLX_ENV_CART_POLE_BALANCING || c.action_steps != 3 || c.trace == GRLX_TRACE_ACCUMULATING)
+      return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:interval (built for 3 actions, replacing or no trace)");
     if (c.target_tau < 0 || c.target_tau > 1) return fail(GRLX_ERR_INVALID, "representation/parameterized/linear:tau");
     P->target_interval = c.target_interval;
     P->target_tau = c.target_tau;

@@ -605,6 +605,11 @@ hipError_t launch_rollout_tgt(const DevParams &P, int n_trials, hipStream_t stre
   GRLX_LAUNCH_PLAIN(GRLX_ENV_PENDULUM, true, true)
   GRLX_LAUNCH_PLAIN(GRLX_ENV_ACROBOT, true, false)
   GRLX_LAUNCH_PLAIN(GRLX_ENV_ACROBOT, false, true)
+  // round 3: the other two environments of the path (a discretised cart-pole; cfg/compass_walker/qlearning_walk.yaml)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_CART_POLE, true, false)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_CART_POLE, false, true)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_COMPASS_WALKER, true, false)
+  GRLX_LAUNCH_PLAIN(GRLX_ENV_COMPASS_WALKER, false, true)
 #undef GRLX_LAUNCH_PLAIN
   return hipErrorInvalidValue;
 }

@@ -105,3 +105,24 @@ def pendulum_qv(grlx, n, **over):
         cr = cfg.actor_representation
         cr.init_min, cr.init_max, cr.output_min, cr.output_max, cr.limit = 0.0, 1.0, -DBL_MAX, DBL_MAX, 1
     return cfg, spec
+
+
+def cart_pole_q(grlx, n, agent=1, **over):
+    """dynamics/cart_pole + task/cart_pole/swingup (cfg/cart_pole/ac_tc.yaml's environment block) under the TD agent block of
+    cfg/pendulum/q_tc.yaml: 3 forces over [-15, 15], the actor-critic yaml's state resolution plus one action coordinate."""
+    res = [2.5, 0.157075, 2.5, 1.57075, 15.0]
+    wrap = [0, 6.283, 0, 0, 0]
+    cfg = None
+    if grlx is not None:
+        cfg = grlx.pendulum_sarsa_config(n, agent=agent, **over)
+        cfg.env = 1
+        cfg.control_step, cfg.integration_steps, cfg.timeout, cfg.randomization = 0.05, 5, 9.99, 0.0
+        cfg.action_min, cfg.action_max, cfg.action_steps = -15.0, 15.0, 3
+        _set_tile(cfg.projector, 16, 8388608, res, wrap)
+    spec = _spec(agent=agent)
+    spec.env = 1
+    spec.control_step, spec.integration_steps, spec.timeout, spec.randomization = 0.05, 5, 9.99, 0.0
+    spec.end_stop_penalty, spec.action_penalty = (cfg.end_stop_penalty, cfg.action_penalty) if cfg is not None else (0, 0)
+    spec.action_min, spec.action_max, spec.action_steps = -15.0, 15.0, 3
+    _set_tile(spec.projector, 16, 8388608, res, wrap)
+    return cfg, spec

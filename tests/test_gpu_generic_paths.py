@@ -779,3 +779,30 @@ def test_deployer_test_trials(grlx, tmp_path):
         f = line.split()
         assert int(f[0]) == row.trial and int(f[1]) == row.steps and f[2] == "%.3f" % row.reward and f[3] == "%.3f" % row.time
     e.close()
+
+
+@pytest.mark.parametrize("agent", [0, 1, 3])
+def test_discrete_actions_on_the_cart_pole(grlx, agent):
+    """The fused Q kernels on the fourth environment of the path with DISCRETE actions (SARSA / Q / Expected SARSA over 3 forces on the
+    cart-pole swing-up task): an instantiation no other test reaches.  Rows, streams, state, weights against the oracle, both layouts."""
+    from tests import configs
+    n, trials = 9, 23
+    seeds = np.arange(41, 41 + n)
+    rng = np.random.default_rng(7)
+    slots = rng.integers(0, 8388608, 1500).astype(np.uint32)
+    for rpw in (4, 8):
+        cfg, spec = configs.cart_pole_q(grlx, n, agent=agent, replicas_per_wave=rpw, end_stop_penalty=1)
+        spec.math = ob.MATH_PORTABLE
+        r = grlx.Runner(cfg, seeds)
+        r.run(11); r.run(trials - 11); r.sync()
+        for k in (0, 4, 8):
+            e = ob.Experiment(spec, seed=int(seeds[k]))
+            rows, _ = e.run(trials)
+            t, s, rew = r.rows(k)
+            assert list(s) == [x.steps for x in rows], f"rpw {rpw} replica {k}"
+            assert_bit_equal(rew, [x.reward for x in rows], f"rpw {rpw}: returns of replica {k}")
+            assert list(r.rng(k))[:3] == list(e.rng())[:3]
+            assert_bit_equal(r.env_state(k), e.state(), f"rpw {rpw}: env state of replica {k}")
+            assert_bit_equal(r.weights(k, slots), e.weights(slots), f"rpw {rpw}: weights of replica {k}")
+            e.close()
+        r.close()

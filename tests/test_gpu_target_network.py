@@ -27,11 +27,14 @@ def assert_bit_equal(a, b, what=""):
     ("pendulum", 1, 64, 0.5, 0, 8388608),         # no trace: one update() call per step
     ("pendulum", 0, 300, 0.3, 1, 2048),           # tiny hash memory: nearly every slot shared between tilings
     ("acrobot", 1, 200, 0.1, 1, 8388608),
+    ("cart_pole", 1, 250, 0.2, 1, 8388608),       # round 3: the other two environments of the path
+    ("cart_pole", 0, 400, 0.0, 1, 8388608),
+    ("compass_walker", 1, 150, 0.3, 1, 8388608),
 ])
 def test_target_network_bit_exact(grlx, env, agent, interval, tau, trace, memory):
     from tests import configs
     from tests.test_gpu_parity import _compare_taps
-    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot}[env]
+    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot, "cart_pole": configs.cart_pole_q, "compass_walker": configs.compass_walker}[env]
     seeds, trials, cap = [71, 72, 73, 74, 75, 76, 77], 24, 2600
     cfg, spec = make(grlx, len(seeds), agent=agent, tap_replica=5, tap_capacity=cap)
     for obj in (cfg, spec):
@@ -41,7 +44,7 @@ def test_target_network_bit_exact(grlx, env, agent, interval, tau, trace, memory
     r.run(7); r.run(9); r.run(8); r.sync()                    # three launches: count_ and the synchronisation number persist
     rng = np.random.default_rng(23)
     slots = np.unique(np.concatenate([rng.integers(0, memory, 1500), np.arange(0, min(memory, 4096))])).astype(np.uint32)
-    D = 2 if env == "pendulum" else 4
+    D = {"pendulum": 2, "acrobot": 4, "cart_pole": 4, "compass_walker": 5}[env]
     for k, seed in enumerate(seeds):
         e = ob.Experiment(spec, seed=int(seed))
         rows, otaps = e.run(trials, tap_cap=cap)
@@ -112,6 +115,8 @@ def test_deployer_target_network(grlx, tmp_path):
     ("pendulum", 1, 32768, 1, 0, 2),       # ... and so do Q-learning's second batch projections inside criticize
     ("pendulum", 1, 8388608, 0, 0, 2),
     ("acrobot", 1, 65536, 1, 0, 2),
+    ("cart_pole", 1, 65536, 1, 0, 1),      # round 3: the other two environments of the path
+    ("compass_walker", 1, 65536, 1, 0, 2),
     ("pendulum", 1, 32768, 1, 300, 2),
 ])
 def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target, safe):
@@ -120,7 +125,7 @@ def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target, saf
     (the slot indices in them are the CLAIMED locations), rows, RNG, weights.  parity unpinned by reference tests."""
     from tests import configs
     from tests.test_gpu_parity import _compare_taps
-    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot}[env]
+    make = {"pendulum": configs.pendulum, "acrobot": configs.acrobot, "cart_pole": configs.cart_pole_q, "compass_walker": configs.compass_walker}[env]
     seeds, trials, cap = [81, 82, 83, 84, 85, 86], 24, 2600
     cfg, spec = make(grlx, len(seeds), agent=agent, tap_replica=3, tap_capacity=cap)
     for obj in (cfg, spec):
@@ -133,7 +138,7 @@ def test_safe_tile_coding_bit_exact(grlx, env, agent, memory, trace, target, saf
     r.run(7); r.run(9); r.run(8); r.sync()
     rng = np.random.default_rng(29)
     slots = np.unique(np.concatenate([rng.integers(0, memory, 1500), np.arange(0, 4096)])).astype(np.uint32)
-    D = 2 if env == "pendulum" else 4
+    D = {"pendulum": 2, "acrobot": 4, "cart_pole": 4, "compass_walker": 5}[env]
     for k, seed in enumerate(seeds):
         e = ob.Experiment(spec, seed=int(seed))
         rows, otaps = e.run(trials, tap_cap=cap)
