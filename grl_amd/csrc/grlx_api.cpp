@@ -323,6 +323,11 @@ struct grlx_ctx {
   int          last_kernel = GRLX_KERNEL_NONE;
   bool         poison = false;            // GRLX_POISON_REGISTERS=<pattern>: diagnostic, see launch_poison_registers
   uint32_t     poison_pattern = 0;
+  // the environment server of the pendulum rollout kernels (grlx_env_server.h): mailboxes, its stream, and the fork / join events
+  int          env_server = 1;            // GRLX_ENV_SERVER=0 turns it off
+  EnvMail      *env_mail = nullptr;
+  hipStream_t  srv_stream = nullptr;
+  hipEvent_t   srv_go = nullptr, srv_done = nullptr;
 };
 
 // small RAII helper for the copy-in / copy-out entry points
@@ -494,6 +499,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
 
   grlx_ctx *ctx = new grlx_ctx();
   ctx->cfg = *cfg;
+  if (const char *es = getenv("GRLX_ENV_SERVER")) ctx->env_server = atoi(es) != 0;
   if (const char *pz = getenv("GRLX_POISON_REGISTERS"))
   { // diagnostic (tests): every rollout launch is preceded by a kernel that fills the register files with this pattern
     ctx->poison = pz[0] != 0;
@@ -640,6 +646,10 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->tap_count);
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->queue);
+  if (ctx->env_mail) (void)hipFree(ctx->env_mail);
+  if (ctx->srv_go) (void)hipEventDestroy(ctx->srv_go);
+  if (ctx->srv_done) (void)hipEventDestroy(ctx->srv_done);
+  if (ctx->srv_stream) (void)hipStreamDestroy(ctx->srv_stream);
   (void)hipFree(ctx->max_load);
   (void)hipFree(ctx->diag);
   (void)hipFree(ctx->trace_state);
@@ -834,11 +844,61 @@ static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *
       HIP_TRY(launch_rollout_tgt(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
       HIP_TRY(launch_rollout_acc(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
+    else if (ctx->env_server && env_server_serves(Pb) && (size_t)ctx->P.n_replicas * kEnvMailBytes < (1ull << 31))
+    { // the server's launch forks off the caller's stream and joins it again: for the caller, still one stream-ordered operation
+      if (!ctx->env_mail)
+      {
+        HIP_TRY(hipMalloc((void **)&ctx->env_mail, (size_t)ctx->P.n_replicas * kEnvMailBytes));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->srv_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->srv_go, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->srv_done, hipEventDisableTiming));
+      }
+      Pb.env_mail = ctx->env_mail;
+      if (const char *tune = getenv("GRLX_ENV_SERVER_TUNE")) Pb.env_tune = (uint32_t)strtoul(tune, nullptr, 0);
+      HIP_TRY(hipMemsetAsync(ctx->env_mail, 0, (size_t)ctx->P.n_replicas * kEnvMailBytes, (hipStream_t)stream));
+      HIP_TRY(hipEventRecord(ctx->srv_go, (hipStream_t)stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->srv_stream, ctx->srv_go, 0));
+      HIP_TRY(launch_env_server(Pb, ctx->srv_stream));
+      HIP_TRY(launch_rollout(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
+      HIP_TRY(hipEventRecord(ctx->srv_done, ctx->srv_stream));
+      HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ctx->srv_done, 0));
+    }
     else
       HIP_TRY(launch_rollout(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
   }
   HIP_TRY(launch_max_load(ctx->P, ctx->n_tables, ctx->max_load, (hipStream_t)stream));
   ctx->trials_run += n_trials;
+  return GRLX_OK;
+}
+
+// diagnostic (not part of include/grlx.h): the mailboxes of the environment server after the last launch (GRLX_ENV_SERVER_STATS builds
+// leave cycle counts in EnvMail::stats)
+int grlx_env_server_debug(grlx_ctx *ctx, void *out, size_t bytes)
+{
+  if (!ctx || !out) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (!ctx->env_mail) return fail(GRLX_ERR_INVALID, "the environment server has not run in this context");
+  DRAIN(ctx);
+  const size_t have = (size_t)ctx->P.n_replicas * kEnvMailBytes;
+  HIP_TRY(hipMemcpy(out, ctx->env_mail, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+// diagnostic (not part of include/grlx.h): in the last launch that had the environment server, how many replicas took every step from it
+// and how many gave up waiting and integrated themselves; both 0 when no launch of this context had it
+int grlx_env_server_counts(grlx_ctx *ctx, int *served, int *fell_back)
+{
+  if (!ctx || !served || !fell_back) return fail(GRLX_ERR_INVALID, "bad argument");
+  *served = *fell_back = 0;
+  if (!ctx->env_mail) return GRLX_OK;
+  DRAIN(ctx);
+  std::vector<unsigned long long> flag((size_t)ctx->P.n_replicas);
+  HIP_TRY(hipMemcpy2D(flag.data(), sizeof(unsigned long long), (const char *)ctx->env_mail + 128 + 15 * sizeof(unsigned long long), kEnvMailBytes,
+                      sizeof(unsigned long long), (size_t)ctx->P.n_replicas, hipMemcpyDeviceToHost));
+  for (unsigned long long f : flag)
+  {
+    if (f == 1u) ++*served;
+    if (f == 2u) ++*fell_back;
+  }
   return GRLX_OK;
 }
 

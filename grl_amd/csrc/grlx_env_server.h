@@ -1,0 +1,271 @@
+// grlx_env_server.h -- the environment step of the 4-replicas-per-wave pendulum kernels, moved to a SECOND kernel that shares the SIMDs.
+// Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
+//
+// Why.  At 4096 replicas the rollout kernel runs exactly one wave per SIMD and issues on 0.64 of its cycles; the rest is latency of its
+// own dependent instructions (f64 chains of the sine, LDS round trips), which only another wave on the SIMD could fill -- and a second
+// 379-register wave does not fit.  But the RK4 integration (40 % of a pass) needs few registers, reads no table, and its inputs are known
+// early: the next step is taken from the state this pass started in, with one of NA known torques.  So a small kernel -- one 64-thread
+// block per rollout wave, under 128 registers, resident on the same SIMDs (tools/microbench/coresident.hip: both kernels stay resident,
+// a round trip between them through device memory costs 3.8 k cycles) -- integrates that step for EVERY action as soon as the rollout
+// wave has said which action it took for the previous one, while the rollout wave works through its table phase; the rollout wave then
+// only fetches the result of the action its sampler chose.  Same operations on the same arguments (env_step is the same code): same bits.
+//
+// Protocol, one 1-KB mailbox per replica (EnvMail).  Every payload word travels in a 16-byte UNIT {value, seq} written by one lane with one
+// 16-byte store and read with one 16-byte load (device scope, sc1: served by memory that every XCD sees): a unit is either the old or the
+// new one, and says which -- no ordering between accesses is needed, a reader that finds a wrong seq reads again.
+//   rollout wave -> server: cmd[seq & 3] = seq << 8 | op, seq = 1, 2, ...;  op 0..NA-1: "the step was taken with action op",
+//                           op kReset: "a trial starts in reset[]" (units tagged seq), op kExit: "no further command".
+//   server -> rollout wave: cand[seq & 1][a] = units {x0, x1, x2, obs0, reward} after command seq, stepped with action a (obs1 = x1;
+//                           terminal and the domain check are comparisons on x the rollout wave redoes).  Two buffers: the server writes
+//                           the candidates of command seq + 1 while the rollout wave may still be reading those of command seq.
+// The rollout wave never depends on the server: a fetch that does not arrive within kFetchPolls polls is computed locally (it has the state
+// and the action), the replica tells the server to stop and integrates by itself for the rest of the launch.  The server leaves when every
+// replica of its block has sent kExit, or after kServerIdlePolls polls without any command.  Neither side can hang the other.
+#pragma once
+
+namespace grlx {
+
+struct __attribute__((aligned(16))) MailUnit { double v; unsigned long long seq; };
+constexpr int kCandUnits = 5;
+struct __attribute__((aligned(1024))) EnvMail {
+  unsigned long long cmd[4];                    //   0
+  MailUnit reset[3];                            //  32
+  unsigned long long pad0[6];                   //  80
+  unsigned long long stats[16];                 // 128  (GRLX_ENV_SERVER_STATS builds)
+  MailUnit cand[2][3][kCandUnits];              // 256 .. 736
+  unsigned long long pad1[36];
+};
+static_assert(sizeof(EnvMail) == kEnvMailBytes, "one mailbox = kEnvMailBytes");
+
+typedef __attribute__((address_space(1))) unsigned long long env_gu64;
+typedef unsigned int mail_u32x4 __attribute__((ext_vector_type(4)));
+#define GRLX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr unsigned kMailReset = 3u, kMailExit = 4u;
+constexpr unsigned kFetchPolls = 400u;              // x (one round trip through memory) = ~0.5 ms: the server is not there
+constexpr unsigned kServerIdlePolls = 4000000u;     // x (s_sleep + one round trip): seconds
+
+__device__ __forceinline__ void mail_store(void *p, unsigned long long v) { __hip_atomic_store((env_gu64 *)p, v, GRLX_RLX_AGENT); }
+__device__ __forceinline__ unsigned long long mail_load(const void *p) { return __hip_atomic_load((env_gu64 *)p, GRLX_RLX_AGENT); }
+__device__ __forceinline__ void mail_setprio(unsigned p)
+{
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 3) __builtin_amdgcn_s_setprio(3);
+}
+__device__ __forceinline__ unsigned long long mail_clock()
+{
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+// one unit, one access
+__device__ __forceinline__ void unit_store(MailUnit *p, double v, unsigned long long seq)
+{
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  mail_u32x4 d;
+  d.x = (unsigned)b; d.y = (unsigned)(b >> 32); d.z = (unsigned)seq; d.w = (unsigned)(seq >> 32);
+  // (s_nop: a store of more than 8 bytes reads its data registers a cycle late, and the assembler does not see into this string)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+// N units starting at p, all loads in flight together, then ONE wait: true when every unit carries `seq`
+template <int N>
+__device__ __forceinline__ bool units_load(const MailUnit *p, unsigned long long seq, double *v)
+{
+  static_assert(N == 3 || N == 5, "");
+  mail_u32x4 d[5];
+  if constexpr (N == 5)
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %5, off offset:64 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4])
+                 : "v"(p)
+                 : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2])
+                 : "v"(p)
+                 : "memory");
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+  {
+    ok = ok && (((unsigned long long)d[i].w << 32) | d[i].z) == seq;
+    v[i] = __longlong_as_double((long long)(((unsigned long long)d[i].y << 32) | d[i].x));
+  }
+  return ok;
+}
+
+// rollout side, ONE lane of the replica's group
+__device__ __forceinline__ void mail_send(EnvMail *m, unsigned long long seq, unsigned op) { mail_store(&m->cmd[seq & 3u], (seq << 8) | op); }
+__device__ __forceinline__ void mail_send_reset(EnvMail *m, unsigned long long seq, const double *x)
+{
+  unit_store(&m->reset[0], x[0], seq);
+  unit_store(&m->reset[1], x[1], seq);
+  unit_store(&m->reset[2], x[2], seq);
+  mail_send(m, seq, kMailReset);
+}
+
+// rollout side, all 16 lanes of the replica's group: what command `seq` followed by action `a` leaves.  Lane j < 5 loads unit j (4 registers
+// instead of 20), the group agrees on whether all five were the ones of `seq`, and the values are handed round.  The load is a buffer
+// load the compiler schedules and waits for itself, so that it can be issued early (mail_prefetch, right after the action is chosen: one
+// trip through memory, 2.3 k cycles, hidden behind the rest of the pass) and looked at late (mail_take, when the next pass starts).
+struct MailBox {
+  __amdgpu_buffer_rsrc_t rs;      // all mailboxes of the launch
+  unsigned at;                    // this lane's byte offset: its replica's mailbox + the unit it loads
+};
+__device__ __forceinline__ MailBox mailbox_of(const DevParams &P, int r, int j)
+{
+  MailBox b;
+  b.rs = __builtin_amdgcn_make_buffer_rsrc((void *)P.env_mail, 0, (int)((size_t)P.n_replicas * kEnvMailBytes), 0x00020000);
+  b.at = (unsigned)r * (unsigned)kEnvMailBytes + (unsigned)offsetof(EnvMail, cand) + (unsigned)(j < kCandUnits ? j : 0) * (unsigned)sizeof(MailUnit);
+  return b;
+}
+__device__ __forceinline__ mail_u32x4 mail_prefetch(const MailBox &b, unsigned long long seq, int a)
+{
+  const unsigned off = b.at + (((unsigned)seq & 1u) * 3u + (unsigned)a) * (unsigned)(kCandUnits * sizeof(MailUnit));
+  return __builtin_amdgcn_raw_buffer_load_b128(b.rs, off, 0, 16);         // 16 = sc1: device scope
+}
+template <int ENV>
+__device__ __forceinline__ bool mail_take(const DevParams &N, const MailBox &b, mail_u32x4 d, unsigned long long seq, int a, int g,
+                                          unsigned long long gmask, double *x, double *obs, double &reward, int &terminal, uint32_t &status,
+                                          unsigned long long *polled = nullptr)
+{
+  static_assert(ENV == GRLX_ENV_PENDULUM, "the pendulum's mailbox");
+  bool ok = false;
+  unsigned polls = 0;
+  for (;;)
+  {
+    const bool mine = (((unsigned long long)d.w << 32) | d.z) == seq;
+    if ((__ballot(mine) & gmask) == gmask) { ok = true; break; }
+    if (++polls > kFetchPolls) break;
+    d = mail_prefetch(b, seq, a);
+  }
+  if (polled) *polled += polls;
+  if (!ok) return false;
+  const double v = __longlong_as_double((long long)(((unsigned long long)d.y << 32) | d.x));
+  const int base = g * 16;
+  x[0] = lane_fetch(v, base + 0);
+  x[1] = lane_fetch(v, base + 1);
+  x[2] = lane_fetch(v, base + 2);
+  obs[0] = lane_fetch(v, base + 3);
+  obs[1] = x[1];
+  reward = lane_fetch(v, base + 4);
+  terminal = x[2] > N.timeout ? 1 : 0;                            // Env::observe
+  if (!Env<ENV>::in_domain(x)) status |= ST_DOMAIN;             // env_step
+  return true;
+}
+
+// The server: block b serves the replicas 4b .. 4b+3 of rollout wave b; lane l < 16 = (replica l / 4, action l % 4), action 3 idle.
+// Registers: 48 (x 2: vector + accumulation) = 96 of a SIMD's 512, beside the 416 of rollout_served_kernel.  The constants of the dynamics
+// stay literals here (PIN = false: 91 registers used).
+template <int ENV, int NA, typename SPEC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_server_kernel(DevParams P)
+{
+  static_assert(NA == 3, "four lanes per replica: three candidates");
+  constexpr int S = Env<ENV>::S, D = Env<ENV>::D;
+  static_assert(S == 3 && D == 2, "the pendulum's mailbox");
+  const DevParams &N = SPEC::numeric(P);
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 2, a = lane & 3;
+  const int r = blockIdx.x * kReplicasPerWave + q;
+  bool done = lane >= 4 * kReplicasPerWave || r >= P.n_replicas || (P.env_tune & 64u) != 0;   // (64: tests -- a server that is not there)
+  EnvMail *m = P.env_mail + (done ? 0 : r);
+  const double act = N.actions[a < NA ? a : 0];
+  unsigned long long expect = 1;
+  double cx[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) cx[i] = 0;
+  unsigned idle = 0;
+  mail_setprio((P.env_tune >> 2) & 3u);
+#ifdef GRLX_ENV_SERVER_STATS
+  unsigned long long t_begin = mail_clock(), t_busy = 0, n_cmd = 0, n_idle = 0;
+#endif
+  for (;;)
+  {
+    if (__all(done)) break;
+    unsigned long long word = 0;
+    bool ready = false;
+    if (!done)
+    {
+      word = mail_load(&m->cmd[expect & 3u]);
+      ready = (word >> 8) == expect;
+      if ((word >> 8) > expect) done = true;          // the replica went on without the server (its later commands overwrote this one)
+    }
+    if (!__any(ready))
+    {
+      __builtin_amdgcn_s_sleep(1);
+#ifdef GRLX_ENV_SERVER_STATS
+      ++n_idle;
+#endif
+      if (++idle > kServerIdlePolls) break;
+      continue;
+    }
+    idle = 0;
+#ifdef GRLX_ENV_SERVER_STATS
+    const unsigned long long t0 = mail_clock();
+#endif
+    if (ready)
+    {
+      const unsigned op = (unsigned)(word & 0xFFu);
+      if (op == kMailExit)
+        done = true;
+      else
+      { // the state this command leaves the replica in: the start state of a trial, or the candidate of the action that was taken
+        double x[S];
+        bool have = true;
+        if (op == kMailReset)
+          have = units_load<3>(&m->reset[0], expect, x);      // (not there yet: the command is looked at again)
+        else
+        {
+          const int src = (lane & ~3) | (int)op;
+#pragma unroll
+          for (int i = 0; i < S; ++i) x[i] = lane_fetch(cx[i], src);
+        }
+        if (have)
+        {
+          if (a < NA)
+          {
+            double obs[D], reward = 0;
+            int terminal = 0;
+            uint32_t st = 0;
+#pragma unroll
+            for (int i = 0; i < S; ++i) cx[i] = x[i];
+            env_step<ENV, false>(N, cx, act, obs, reward, terminal, st);
+            MailUnit *c = &m->cand[expect & 1u][a][0];
+            unit_store(c + 0, cx[0], expect);
+            unit_store(c + 1, cx[1], expect);
+            unit_store(c + 2, cx[2], expect);
+            unit_store(c + 3, obs[0], expect);
+            unit_store(c + 4, reward, expect);
+          }
+          ++expect;
+#ifdef GRLX_ENV_SERVER_STATS
+          ++n_cmd;
+#endif
+        }
+      }
+    }
+#ifdef GRLX_ENV_SERVER_STATS
+    t_busy += mail_clock() - t0;
+#endif
+  }
+#ifdef GRLX_ENV_SERVER_STATS
+  if (lane < 4 * kReplicasPerWave && a == 0 && r < P.n_replicas)
+  {
+    EnvMail *mm = P.env_mail + r;
+    mm->stats[0] = mail_clock() - t_begin;
+    mm->stats[1] = t_busy;
+    mm->stats[2] = n_cmd;
+    mm->stats[3] = n_idle;
+  }
+#endif
+}
+
+} // namespace grlx

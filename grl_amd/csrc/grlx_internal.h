@@ -7,6 +7,7 @@
 namespace grlx {
 
 constexpr int kLanesPerReplica = 16;     // one lane per tiling
+constexpr size_t kEnvMailBytes = 1024;    // sizeof(EnvMail), grlx_env_server.h
 constexpr int kReplicasPerWave = 4;      // per sub-batch; a wide wave carries 4*B (grlx_rollout_wide.h)
 constexpr int kMaxTrace = 10;            // replacing trace: (gamma*lambda)^n < 0.01 must hold for n <= 10
 constexpr int kMaxActions = GRLX_MAX_ACTIONS;
@@ -110,6 +111,9 @@ struct DevParams {
   // experiment/online_learning:steps (online_learning.cpp:154): a replica starts no further trial once its learning steps of the run
   // (ReplicaState::ss) have reached this budget; 0 = none.  Honoured by rollout_kernel, rollout_wide_kernel and the actor-critic kernels.
   uint64_t steps_budget;
+  uint32_t env_tune;            // experiments (GRLX_ENV_SERVER_TUNE): bits 0-1 s_setprio of the rollout wave, 2-3 of the server wave, 4 no prefetch;
+                                // tests: bit 6 the server leaves at once (every replica falls back to integrating itself)
+  struct EnvMail *env_mail;     // mailboxes of the environment server ([replica], grlx_env_server.h); null = the rollout kernel integrates itself
   int32_t  test_trials;         // experiment/online_learning:test_trials (>= 1): greedy episodes per test trial, averaged in the row
   // Actor-critic with EQUAL tile codings for actor and critic (cfg/cart_pole/ac_tc.yaml: the critic copies resolution and memory):
   // both tables are looked up with the same slots at every step, so the two sparse tables are kept as TWINS -- the same slot at the
@@ -129,6 +133,8 @@ struct DevParams {
 // launchers implemented in grlx_kernels.hip
 // *variant (optional) receives the GRLX_KERNEL_* instantiation that was launched
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
+bool       env_server_serves(const DevParams &P);                                   // is this context's rollout kernel one the environment server works for?
+hipError_t launch_env_server(const DevParams &P, hipStream_t stream);
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_qv(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_acc(const DevParams &P, int n_trials, hipStream_t stream, int *variant);

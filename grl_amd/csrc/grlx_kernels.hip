@@ -40,6 +40,7 @@ namespace grlx {
 } // namespace grlx
 
 #include "grlx_update.h"
+#include "grlx_env_server.h"
 #include "grlx_rollout.h"
 #include "grlx_rollout_wide.h"
 #include "grlx_rollout_ac.h"
@@ -153,10 +154,53 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
   return hipGetLastError();
 }
 
+// The environment server works for the deferred-update pendulum instantiations of rollout_kernel with three actions (EXT in grlx_rollout.h).
+bool env_server_serves(const DevParams &P)
+{
+  const bool inplace = P.diag_out != nullptr || (P.tap_replica >= 0 && P.tap_capacity > 0);
+  return !inplace && P.replicas_per_wave != 8 && P.env == GRLX_ENV_PENDULUM && P.A == 3 && P.agent != GRLX_AGENT_ADVANTAGE;
+}
+
+// One block per rollout wave, with the numeric parameters of the instantiation launch_rollout picks (same constants, same folding).
+hipError_t launch_env_server(const DevParams &P, hipStream_t stream)
+{
+  if (!P.env_mail || !env_server_serves(P)) return hipErrorInvalidValue;
+  const int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+#define GRLX_LAUNCH_SERVER(AGENT)                                                                                      \
+  if (!P.no_specialisation && SpecPendulumTcA<AGENT>::matches(P))                                                    \
+  {                                                                                                                  \
+    hipLaunchKernelGGL((env_server_kernel<GRLX_ENV_PENDULUM, 3, SpecPendulumTcA<AGENT>>), dim3(waves), dim3(64), 0, stream, P); \
+    return hipGetLastError();                                                                                        \
+  }
+  GRLX_LAUNCH_SERVER(GRLX_AGENT_SARSA)
+  GRLX_LAUNCH_SERVER(GRLX_AGENT_Q)
+  GRLX_LAUNCH_SERVER(GRLX_AGENT_EXPECTED_SARSA)
+#undef GRLX_LAUNCH_SERVER
+  hipLaunchKernelGGL((env_server_kernel<GRLX_ENV_PENDULUM, 3, SpecNone>), dim3(waves), dim3(64), 0, stream, P);
+  return hipGetLastError();
+}
+
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant)
 {
   if (variant) *variant = GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (P.env_mail)
+  { // with the environment server (launch_env_server picks the same numeric parameters)
+    if (!env_server_serves(P)) return hipErrorInvalidValue;
+#define GRLX_LAUNCH_SERVED(AGENT)                                                                                      \
+    if (!P.no_specialisation && SpecPendulumTcA<AGENT>::matches(P))                                                  \
+    {                                                                                                                \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                               \
+      hipLaunchKernelGGL((rollout_served_kernel<3, SpecPendulumTcA<AGENT>>), dim3(waves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                      \
+    }
+    GRLX_LAUNCH_SERVED(GRLX_AGENT_SARSA)
+    GRLX_LAUNCH_SERVED(GRLX_AGENT_Q)
+    GRLX_LAUNCH_SERVED(GRLX_AGENT_EXPECTED_SARSA)
+#undef GRLX_LAUNCH_SERVED
+    hipLaunchKernelGGL((rollout_served_kernel<3, SpecNone>), dim3(waves), dim3(64), 0, stream, P, n_trials);
+    return hipGetLastError();
+  }
   // stamps and per-step taps are recorded by the instantiation that updates in place
 #ifdef GRLX_WIDE_STAMPS
   const bool inplace = P.tap_replica >= 0 && P.tap_capacity > 0;      // stamped wide build: diag_out feeds the wide kernel

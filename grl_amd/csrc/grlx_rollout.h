@@ -192,8 +192,9 @@ struct SpecNone {
 #else
 #define GRLX_ROLLOUT_OCCUPANCY
 #endif
-template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG, bool ADV = false, bool TAP = !DEFER>
-__global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevParams P, int n_trials)
+// SERVED: the environment steps come from the environment server (grlx_env_server.h) -- its own kernel, rollout_served_kernel below.
+template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER, bool ADV, bool TAP, bool SERVED>
+__device__ __forceinline__ void rollout_body(const DevParams &P, int n_trials)
 {
   static_assert(!(ADV && DEFER), "the advantage-learning instantiation updates in place");
   constexpr int NROWS = ADV ? 2 * NA : NA + 1;      // LDS rows of weights summed per pass
@@ -261,6 +262,25 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
   lshare.src[0] = g * 16; lshare.src[1] = g * 16 + 1; lshare.src[2] = g * 16 + 2;
   lshare.role3 = j % 3; lshare.role2 = j & 1;
 
+  // the environment server (grlx_env_server.h): this replica's mailbox, the number of commands sent, and whether the server still answers
+  constexpr bool EXT = SERVED;
+  static_assert(!SERVED || (DEFER && !DIAG && !TAP && !ADV && ENV == GRLX_ENV_PENDULUM && NA == 3), "what the environment server works for");
+  EnvMail *mail = nullptr;
+  unsigned long long mseq = 0;
+  bool srv = false;
+#ifdef GRLX_ENV_SERVER_STATS
+  unsigned long long st_wait = 0, st_polls = 0, st_fetch = 0, st_begin = mail_clock();
+#endif
+  MailBox mbox;
+  mail_u32x4 mpre = {0u, 0u, 0u, 0u};      // the unit this lane loaded ahead
+  if constexpr (EXT)
+  {
+    srv = live && P.env_mail != nullptr;
+    mail = P.env_mail + r;
+    mbox = mailbox_of(P, r, j);
+    mail_setprio(P.env_tune & 3u);
+  }
+
   TraceRegs tr;
   trace_init(tr);
   int tr_len_ref = 0;           // length as the reference reports it (its trace survives test trials)
@@ -299,6 +319,12 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
     {
       Env<ENV>::start(N, test, TL, G, x);
       Env<ENV>::observe(N, x, obs);
+      if constexpr (EXT)
+        if (srv)
+        { // the server starts on the first step of this episode, for every action, while this wave looks up Q(s0, .)
+          ++mseq;
+          if (j == 0) mail_send_reset(mail, mseq, x);
+        }
     }
     // agent->start: TDAgent::start clears the trace (td.cpp:50-61, sarsa.cpp:126-132); the
     // trace was written back at the end of the previous learning trial, so it is empty here
@@ -332,6 +358,26 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
         // -------- environment step (skipped on the start() pass)
         if (!first)
         {
+          bool stepped = false;
+          if constexpr (EXT)
+            if (srv)
+            { // the step was integrated by the server while this wave updated its table: the candidate of the action taken
+#ifdef GRLX_ENV_SERVER_STATS
+              const unsigned long long tf0 = mail_clock();
+              stepped = mail_take<ENV>(N, mbox, mpre, mseq - 1, action_index, g, gmask, x, obs, reward, terminal, status, &st_polls);
+              st_wait += mail_clock() - tf0;
+              ++st_fetch;
+#else
+              stepped = mail_take<ENV>(N, mbox, mpre, mseq - 1, action_index, g, gmask, x, obs, reward, terminal, status);
+#endif
+              if (!stepped)
+              { // no answer: integrate here, from now on (the server is told to stop waiting for this replica)
+                srv = false;
+                ++mseq;
+                if (j == 0) mail_send(mail, mseq, kMailExit);
+              }
+            }
+          if (!stepped)
           env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, status, lshare);   // online_learning.cpp:196
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
@@ -537,6 +583,14 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
               a_next = (man > 1) ? tie_break<NA>(q, best, man, G) : mai;
           }
         }
+        if constexpr (EXT)
+          if (srv && running && has_next && !(!first && terminal))
+          { // the action of the step this pass looked ahead to: the server moves on to the step after it
+            ++mseq;
+            if (j == 0) mail_send(mail, mseq, (unsigned)a_next);
+            if (!(P.env_tune & 16u))
+            mpre = mail_prefetch(mbox, mseq - 1, a_next);        // what the next pass starts from: ready unless the server is late
+          }
 
         DIAG_STAMP(4)
         // -------- predictor update (sarsa.cpp:98-124 / advantage.cpp:71-110)
@@ -703,6 +757,26 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
   if (DIAG && P.diag_out && lane == 0)
     for (int k = 0; k < 8; ++k) P.diag_out[(size_t)blockIdx.x * 8 + k] = diag_sum[k];
 
+  if constexpr (EXT)
+  {
+#ifdef GRLX_ENV_SERVER_STATS
+    if (live && j == 0 && P.env_mail)
+    {
+      mail->stats[4] = mail_clock() - st_begin;
+      mail->stats[5] = st_wait;
+      mail->stats[6] = st_fetch;
+      mail->stats[7] = st_polls;
+      mail->stats[8] = srv ? 1 : 0;
+    }
+#endif
+    if (live && j == 0 && P.env_mail) mail->stats[15] = srv ? 1u : 2u;     // (grlx_env_server_counts: served to the end / fell back)
+    if (srv)
+    { // no further command in this launch
+      ++mseq;
+      if (j == 0) mail_send(mail, mseq, kMailExit);
+    }
+  }
+
   // write the replica back
   uint32_t ins = inserted;
 #pragma unroll
@@ -726,6 +800,20 @@ __global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevP
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
   if (live && j == 0) RS.status = st;
+}
+
+template <int ENV, int NA, bool DIAG, typename SPEC, bool DEFER = !DIAG, bool ADV = false, bool TAP = !DEFER>
+__global__ __launch_bounds__(64) GRLX_ROLLOUT_OCCUPANCY void rollout_kernel(DevParams P, int n_trials)
+{
+  rollout_body<ENV, NA, DIAG, SPEC, DEFER, ADV, TAP, false>(P, n_trials);
+}
+
+// The instantiation the environment server works for.  208 (x 2: vector + accumulation registers) = 416 of the SIMD's 512 registers,
+// so that the server's wave (96) fits beside it.
+template <int NA, typename SPEC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(208))) void rollout_served_kernel(DevParams P, int n_trials)
+{
+  rollout_body<GRLX_ENV_PENDULUM, NA, false, SPEC, true, false, false, true>(P, n_trials);
 }
 
 // cfg/cart_pole/ac_tc.yaml as compile-time constants (see SpecPendulumTcA): every field the actor-critic

@@ -136,6 +136,16 @@ class Runner:
         """capi GRLX_KERNEL_*: 1 generic, 2 specialised (compile-time instantiation), 3 diagnostic in-place."""
         return self.lib.grlx_last_kernel(self._ctx)
 
+    def env_server_counts(self):
+        """(replicas served by the environment server to the end of the last launch that had it, replicas that fell back to integrating
+        themselves); (0, 0) when no launch of this context had it -- diagnostic export, not part of include/grlx.h"""
+        fn = self.lib.grlx_env_server_counts
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        fn.restype = C.c_int
+        a, b = C.c_int(0), C.c_int(0)
+        capi.check(fn(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def replicas_per_wave(self) -> int:
         """4: one replica per 16 lanes; 8: two sub-batches per wave sharing the environment phase (wide kernels)."""
         return self.lib.grlx_replicas_per_wave(self._ctx)
