@@ -20,7 +20,7 @@
 //                           the candidates of command seq + 1 while the rollout wave may still be reading those of command seq.
 // The rollout wave never depends on the server: a fetch that does not arrive within kFetchPolls polls is computed locally (it has the state
 // and the action), the replica tells the server to stop and integrates by itself for the rest of the launch.  The server leaves when every
-// replica of its block has sent kExit, or after kServerIdlePolls polls without any command.  Neither side can hang the other.
+// replica of its block has sent kExit, or after kServerStartPolls polls without a first command / kServerIdlePolls polls without a further one.  Neither side can hang the other.
 #pragma once
 
 namespace grlx {
@@ -42,7 +42,9 @@ typedef unsigned int mail_u32x4 __attribute__((ext_vector_type(4)));
 #define GRLX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr unsigned kMailReset = 3u, kMailExit = 4u;
 constexpr unsigned kFetchPolls = 400u;              // x (one round trip through memory) = ~0.5 ms: the server is not there
-constexpr unsigned kServerIdlePolls = 4000000u;     // x (s_sleep + one round trip): seconds
+constexpr unsigned kServerStartPolls = 20000u;      // x (s_sleep + one round trip) = tens of ms without a first command: the rollout kernel is
+                                                    //   not running beside this one (a profiler that serialises kernels, a busy device)
+constexpr unsigned kServerIdlePolls = 400000u;      // ... = half a second without a further command
 
 __device__ __forceinline__ void mail_store(void *p, unsigned long long v) { __hip_atomic_store((env_gu64 *)p, v, GRLX_RLX_AGENT); }
 __device__ __forceinline__ unsigned long long mail_load(const void *p) { return __hip_atomic_load((env_gu64 *)p, GRLX_RLX_AGENT); }
@@ -162,27 +164,35 @@ __device__ __forceinline__ bool mail_take(const DevParams &N, const MailBox &b, 
   return true;
 }
 
-// The server: block b serves the replicas 4b .. 4b+3 of rollout wave b; lane l < 16 = (replica l / 4, action l % 4), action 3 idle.
+// The server: block b serves the replicas 4b .. 4b+3 of rollout wave b.  It looks TWO steps ahead: lane 16 q + 3 a + a2 (a, a2 < NA) of
+// replica q holds the state after the actions (a, a2) applied to the replica's last confirmed state -- nine per replica, one instruction
+// stream.  When the command "the step was taken with action a*" arrives, the three lanes (a*, .) hold what the rollout wave asks for next and
+// store it at once; only then do all nine integrate the level after it, each from the state lane (a*, its a) held.  The integration is off
+// the path between a command and its answer (two trips through memory), at the same number of instructions per step.
 // Registers: 48 (x 2: vector + accumulation) = 96 of a SIMD's 512, beside the 416 of rollout_served_kernel.  The constants of the dynamics
-// stay literals here (PIN = false: 91 registers used).
+// stay literals here (PIN = false).
 template <int ENV, int NA, typename SPEC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_server_kernel(DevParams P)
 {
-  static_assert(NA == 3, "four lanes per replica: three candidates");
+  static_assert(NA == 3, "sixteen lanes per replica: nine pairs of actions");
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D;
   static_assert(S == 3 && D == 2, "the pendulum's mailbox");
   const DevParams &N = SPEC::numeric(P);
   const int lane = threadIdx.x & 63;
-  const int q = lane >> 2, a = lane & 3;
+  const int q = lane >> 4, c = lane & 15;
+  const int a = c / NA, a2 = c % NA;                     // (c >= 9: idle lanes, kept in step for the shuffles)
+  const bool worker = c < NA * NA;
   const int r = blockIdx.x * kReplicasPerWave + q;
-  bool done = lane >= 4 * kReplicasPerWave || r >= P.n_replicas || (P.env_tune & 64u) != 0;   // (64: tests -- a server that is not there)
+  bool done = r >= P.n_replicas || (P.env_tune & 64u) != 0;   // (64: tests -- a server that is not there)
   EnvMail *m = P.env_mail + (done ? 0 : r);
-  const double act = N.actions[a < NA ? a : 0];
+  const double act = N.actions[a2];
   unsigned long long expect = 1;
-  double cx[S];
+  // this lane's candidate: state, observed angle and reward after (a, a2)
+  double cx[S], cobs0 = 0, creward = 0;
 #pragma unroll
   for (int i = 0; i < S; ++i) cx[i] = 0;
   unsigned idle = 0;
+  bool seen = false;
   mail_setprio((P.env_tune >> 2) & 3u);
 #ifdef GRLX_ENV_SERVER_STATS
   unsigned long long t_begin = mail_clock(), t_busy = 0, n_cmd = 0, n_idle = 0;
@@ -204,47 +214,63 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
 #ifdef GRLX_ENV_SERVER_STATS
       ++n_idle;
 #endif
-      if (++idle > kServerIdlePolls) break;
+      if (++idle > (seen ? kServerIdlePolls : kServerStartPolls)) break;
       continue;
     }
     idle = 0;
+    seen = true;
 #ifdef GRLX_ENV_SERVER_STATS
     const unsigned long long t0 = mail_clock();
 #endif
     if (ready)
     {
-      const unsigned op = (unsigned)(word & 0xFFu);
+      unsigned op = (unsigned)(word & 0xFFu);
       if (op == kMailExit)
         done = true;
       else
-      { // the state this command leaves the replica in: the start state of a trial, or the candidate of the action that was taken
-        double x[S];
+      {
         bool have = true;
         if (op == kMailReset)
+        { // a trial starts: the first level is integrated here, from the start state (every lane (., a2) the same f(start, a2));
+          // the lanes (0, .) then stand for "the action taken".  (A second copy of the integration: folding both levels into one loop
+          // costs registers the kernel does not have -- 102 and scratch, and with scratch the two kernels no longer share the SIMDs.)
+          double x[S];
           have = units_load<3>(&m->reset[0], expect, x);      // (not there yet: the command is looked at again)
-        else
-        {
-          const int src = (lane & ~3) | (int)op;
-#pragma unroll
-          for (int i = 0; i < S; ++i) x[i] = lane_fetch(cx[i], src);
-        }
-        if (have)
-        {
-          if (a < NA)
+          if (have)
           {
-            double obs[D], reward = 0;
+            double obs[D];
             int terminal = 0;
             uint32_t st = 0;
 #pragma unroll
             for (int i = 0; i < S; ++i) cx[i] = x[i];
-            env_step<ENV, false>(N, cx, act, obs, reward, terminal, st);
-            MailUnit *c = &m->cand[expect & 1u][a][0];
-            unit_store(c + 0, cx[0], expect);
-            unit_store(c + 1, cx[1], expect);
-            unit_store(c + 2, cx[2], expect);
-            unit_store(c + 3, obs[0], expect);
-            unit_store(c + 4, reward, expect);
+            env_step<ENV, false>(N, cx, act, obs, creward, terminal, st);
+            cobs0 = obs[0];
+            op = 0u;
           }
+        }
+        if (have)
+        { // the answer: what the action taken leaves, for every next action
+          if (worker && a == (int)op)
+          {
+            MailUnit *u = &m->cand[expect & 1u][a2][0];
+            unit_store(u + 0, cx[0], expect);
+            unit_store(u + 1, cx[1], expect);
+            unit_store(u + 2, cx[2], expect);
+            unit_store(u + 3, cobs0, expect);
+            unit_store(u + 4, creward, expect);
+          }
+          // the level after it: lane (a, a2) continues from the state the lane (action taken, a) holds
+          const int src = (lane & ~15) + (int)op * NA + (worker ? a : 0);
+          double x[S];
+#pragma unroll
+          for (int i = 0; i < S; ++i) x[i] = lane_fetch(cx[i], src);
+          double obs[D];
+          int terminal = 0;
+          uint32_t st = 0;
+#pragma unroll
+          for (int i = 0; i < S; ++i) cx[i] = x[i];
+          env_step<ENV, false>(N, cx, act, obs, creward, terminal, st);
+          cobs0 = obs[0];
           ++expect;
 #ifdef GRLX_ENV_SERVER_STATS
           ++n_cmd;
@@ -257,7 +283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
 #endif
   }
 #ifdef GRLX_ENV_SERVER_STATS
-  if (lane < 4 * kReplicasPerWave && a == 0 && r < P.n_replicas)
+  if (c == 0 && r < P.n_replicas)
   {
     EnvMail *mm = P.env_mail + r;
     mm->stats[0] = mail_clock() - t_begin;
