@@ -57,7 +57,8 @@ ALGORITHMIC_BYTES = {
 # experiment graph -> how one GPU runs it
 GRAPHS = {
     "pendulum_sarsa": dict(trials=TRIALS_PER_STEP, want_kernel=2, pmc_key="pendulum_sarsa",
-                           kernel="rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update>",
+                           kernel="rollout_served_kernel<3 actions, SpecPendulumTc(SARSA)> + env_server_kernel (co-resident pair, one timed launch; "
+                                  "rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update> with GRLX_ENV_SERVER=0)",
                            text="pendulum swing-up SARSA(lambda) hashed tile coding (cfg/pendulum/sarsa_tc.yaml semantics)"),
     "cart_pole_ac": dict(trials=11, want_kernel=2, pmc_key="cart_pole_ac",
                          kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>",
@@ -311,6 +312,7 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
         test += c["test"]
         c["kernel_ms"] = [a.elapsed_time(b) for a, b in c["ev"]]
         c["rpw"] = c["runner"].replicas_per_wave()
+        c["env_server"] = c["runner"].env_server_counts()       # (replicas served to the end of the last launch, replicas that fell back)
     all_learn, all_test = parallel.sum_over_ranks([learn, test], D.world, device="cuda")
     curve_host = curve.cpu().numpy()
     for c in ctx:
@@ -357,6 +359,11 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
                                     "algorithmic_bytes_per_test_step": bytes_["test"], "algorithmic_bytes_source": bytes_["source"]}}
         if "oracle_this_run" in bytes_:
             c["report"]["roofline"]["oracle_bytes_per_learn_step_on_these_trials"] = bytes_["oracle_this_run"]
+        if c["env_server"] != (0, 0):
+            # the pendulum kernels take their RK4 steps from a second, co-resident kernel (grl_amd/csrc/grlx_env_server.h); kernel_ms_avg spans
+            # the pair.  Its mailboxes add ~0.4 KB per env-step of device-scope traffic (240 B of candidates stored, 80 B loaded, 8 B of command, the polls) that the counters of `traffic` (collected with the
+            # server off: rocprofv3 serialises kernels while it reads counters) do not hold.
+            c["report"]["env_server"] = {"replicas_served": c["env_server"][0], "replicas_fell_back": c["env_server"][1]}
         if cpu:
             c["report"]["cpu_baseline"] = cpu
     out["config"] = {"workload": "; ".join(text), "replicas_per_gpu": n_rank, "parallelism": out["parallelism"]}
@@ -367,6 +374,8 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
     out["mean_test_return_first_last"] = dom["report"]["mean_test_return_first_last"]
     out["curve_replicas"] = dom["report"]["curve_replicas"]
     out["replicas_per_wave"] = dom["report"]["replicas_per_wave"]
+    if "env_server" in dom["report"]:
+        out["env_server"] = dom["report"]["env_server"]
     if len(ctx) > 1:
         out["parts"] = [c["report"] for c in ctx]
     return out
