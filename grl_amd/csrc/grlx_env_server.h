@@ -3,12 +3,13 @@
 //
 // Why.  At 4096 replicas the rollout kernel runs exactly one wave per SIMD and issues on 0.64 of its cycles; the rest is latency of its
 // own dependent instructions (f64 chains of the sine, LDS round trips), which only another wave on the SIMD could fill -- and a second
-// 379-register wave does not fit.  But the RK4 integration (40 % of a pass) needs few registers, reads no table, and its inputs are known
+// 384-register wave does not fit.  But the RK4 integration (40 % of a pass) needs few registers, reads no table, and its inputs are known
 // early: the next step is taken from the state this pass started in, with one of NA known torques.  So a small kernel -- one 64-thread
-// block per rollout wave, under 128 registers, resident on the same SIMDs (tools/microbench/coresident.hip: both kernels stay resident,
-// a round trip between them through device memory costs 3.8 k cycles) -- integrates that step for EVERY action as soon as the rollout
-// wave has said which action it took for the previous one, while the rollout wave works through its table phase; the rollout wave then
-// only fetches the result of the action its sampler chose.  Same operations on the same arguments (env_step is the same code): same bits.
+// block per rollout wave, 96 registers beside the 416 of rollout_served_kernel, resident on the same SIMDs (tools/microbench/coresident.hip:
+// both kernels stay resident, a round trip between them through device memory costs 3.8 k cycles) -- integrates the steps AHEAD of the
+// rollout wave, for every action it can choose (two levels: see env_server_kernel), while the rollout wave works through its table
+// phase; the rollout wave then only fetches the result of the action its sampler chose.  Same operations on the same arguments (env_step
+// is the same code): same bits.  DESIGN.md section 4.1g has the measurements.
 //
 // Protocol, one 1-KB mailbox per replica (EnvMail).  Every payload word travels in a 16-byte UNIT {value, seq} written by one lane with one
 // 16-byte store and read with one 16-byte load (device scope, sc1: served by memory that every XCD sees): a unit is either the old or the
@@ -20,7 +21,8 @@
 //                           the candidates of command seq + 1 while the rollout wave may still be reading those of command seq.
 // The rollout wave never depends on the server: a fetch that does not arrive within kFetchPolls polls is computed locally (it has the state
 // and the action), the replica tells the server to stop and integrates by itself for the rest of the launch.  The server leaves when every
-// replica of its block has sent kExit, or after kServerStartPolls polls without a first command / kServerIdlePolls polls without a further one.  Neither side can hang the other.
+// replica of its block has sent kExit (or has gone on without it), or after kServerStartPolls polls without a first command /
+// kServerIdlePolls polls without a further one.  Neither side can hang the other.
 #pragma once
 
 namespace grlx {
@@ -31,7 +33,7 @@ struct __attribute__((aligned(1024))) EnvMail {
   unsigned long long cmd[4];                    //   0
   MailUnit reset[3];                            //  32
   unsigned long long pad0[6];                   //  80
-  unsigned long long stats[16];                 // 128  (GRLX_ENV_SERVER_STATS builds)
+  unsigned long long stats[16];                 // 128  ([15]: served to the end 1 / fell back 2; the rest: GRLX_ENV_SERVER_STATS builds)
   MailUnit cand[2][3][kCandUnits];              // 256 .. 736
   unsigned long long pad1[36];
 };
@@ -70,30 +72,20 @@ __device__ __forceinline__ void unit_store(MailUnit *p, double v, unsigned long 
   // (s_nop: a store of more than 8 bytes reads its data registers a cycle late, and the assembler does not see into this string)
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
-// N units starting at p, all loads in flight together, then ONE wait: true when every unit carries `seq`
+// server side: the three units of a start state, all loads in flight together, then ONE wait; true when every unit carries `seq`
+// (inline assembly, waited for on the spot: nothing else is in flight in the server when it reads a start state)
 template <int N>
 __device__ __forceinline__ bool units_load(const MailUnit *p, unsigned long long seq, double *v)
 {
-  static_assert(N == 3 || N == 5, "");
-  mail_u32x4 d[5];
-  if constexpr (N == 5)
-    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
-                 "global_load_dwordx4 %4, %5, off offset:64 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4])
-                 : "v"(p)
-                 : "memory");
-  else
-    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
-                 "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2])
-                 : "v"(p)
-                 : "memory");
+  static_assert(N == 3, "");
+  mail_u32x4 d[N];
+  asm volatile("global_load_dwordx4 %0, %3, off sc1\n\t"
+               "global_load_dwordx4 %1, %3, off offset:16 sc1\n\t"
+               "global_load_dwordx4 %2, %3, off offset:32 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2])
+               : "v"(p)
+               : "memory");
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < N; ++i)
