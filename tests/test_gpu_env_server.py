@@ -102,3 +102,18 @@ def test_not_served_where_it_is_not_built(grlx):
     r = grlx.Runner(cfg, np.arange(1, 5)); r.run(5); r.sync()
     assert r.env_server_counts() == (0, 0)
     r.close()
+
+
+def test_every_replica_is_served_at_the_bench_size(grlx):
+    """4096 replicas = one rollout wave AND one server wave per SIMD: the two kernels must fit a SIMD's register file together
+    (416 + 96 of 512, grlx_rollout.h / grlx_env_server.h), or the server's waves wait for the rollout waves to finish and every
+    replica falls back -- same results, none of the speed."""
+    n = 4096
+    cfg = grlx.pendulum_sarsa_config(n, max_rows=16)
+    r = grlx.Runner(cfg, np.arange(1, n + 1))
+    for _ in range(3):
+        r.run(11)
+    r.sync()
+    assert r.last_kernel() == 2
+    assert r.env_server_counts() == (n, 0), r.env_server_counts()
+    r.close()
