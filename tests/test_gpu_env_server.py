@@ -119,3 +119,36 @@ def test_every_replica_is_served_at_the_bench_size(grlx):
     assert served + fell_back == n
     assert served >= n - n // 100, (served, fell_back)      # (a replica that waited 400 polls for one answer falls back: rare, and harmless)
     r.close()
+
+
+def test_full_size_batches_server_on_equals_off(grlx, monkeypatch):
+    """BASELINE configs[1] at its full size (4096 replicas) over more trials than the bench times, in the bench's launches of 11: every
+    sampled replica's rows, streams, state and weights with the server equal those without it."""
+    n, launches = 4096, 28                                   # 308 trials
+    picks = [0, 1, 2, 3, 4, 1023, 1024, 2047, 2048, 3000, 4093, 4094, 4095]
+
+    def run():
+        cfg = grlx.pendulum_sarsa_config(n, max_rows=64)
+        r = grlx.Runner(cfg, np.arange(1, n + 1))
+        for _ in range(launches):
+            r.run(11)
+        r.sync()
+        rng = np.random.default_rng(17)
+        slots = rng.integers(0, cfg.projector.memory, 3000).astype(np.uint32)
+        out = {"counts": r.env_server_counts(), "steps": r.step_counts()}
+        for k in picks:
+            t, s, rew = r.rows(k)
+            out[k] = (list(t), list(s), np.asarray(rew, dtype=np.float64).view(np.uint64).tolist(),
+                      np.asarray(r.env_state(k), dtype=np.float64).view(np.uint64).tolist(), list(r.rng(k)),
+                      np.asarray(r.weights(k, slots), dtype=np.float64).view(np.uint64).tolist())
+        r.close()
+        return out
+
+    monkeypatch.setenv("GRLX_ENV_SERVER", "0")
+    off = run()
+    monkeypatch.delenv("GRLX_ENV_SERVER")
+    on = run()
+    assert off["counts"] == (0, 0) and on["counts"][0] >= n - n // 100, on["counts"]
+    assert on["steps"] == off["steps"]                       # learning and test steps summed over ALL replicas
+    for k in picks:
+        assert on[k] == off[k], f"replica {k}"
