@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
   bool seen = false;
   mail_setprio((P.env_tune >> 2) & 3u);
 #ifdef GRLX_ENV_SERVER_STATS
-  unsigned long long t_begin = mail_clock(), t_busy = 0, n_cmd = 0, n_idle = 0;
+  unsigned long long t_begin = mail_clock(), t_busy = 0, n_cmd = 0, n_idle = 0, n_split = 0, n_batch = 0;
 #endif
   for (;;)
   {
@@ -213,6 +213,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
     seen = true;
 #ifdef GRLX_ENV_SERVER_STATS
     const unsigned long long t0 = mail_clock();
+    if (!__all(ready || done)) ++n_split;
+    ++n_batch;
 #endif
     if (ready)
     {
@@ -282,6 +284,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
     mm->stats[1] = t_busy;
     mm->stats[2] = n_cmd;
     mm->stats[3] = n_idle;
+    mm->stats[9] = n_split;
+    mm->stats[10] = n_batch;
   }
 #endif
 }

@@ -22,7 +22,8 @@ st = mail[:, 16:32].astype(np.float64)
 steps = (l1 - l0) + (t1 - t0)
 print(f"{n} replicas, {trials} trials: {steps} env-steps, {steps / n:.0f} per replica")
 print(f"server : kernel {st[:,0].mean():.0f} cycles, busy (command seen -> candidates stored) {st[:,1].mean():.0f} = {st[:,1].sum()/st[:,0].sum():.2f}, "
-      f"{st[:,2].mean():.0f} commands, {st[:,1].sum()/max(st[:,2].sum(),1):.0f} cycles per command, {st[:,3].mean():.0f} idle polls")
+      f"{st[:,2].mean():.0f} commands, {st[:,1].sum()/max(st[:,2].sum(),1):.0f} cycles per command, {st[:,3].mean():.0f} idle polls, "
+      f"{st[:,10].mean():.0f} batches of which {st[:,9].mean():.0f} without all four replicas of the wave")
 print(f"rollout: kernel {st[:,4].mean():.0f} cycles, waiting for candidates {st[:,5].mean():.0f} = {st[:,5].sum()/st[:,4].sum():.2f}, "
       f"{st[:,6].mean():.0f} fetches, {st[:,5].sum()/max(st[:,6].sum(),1):.0f} cycles per fetch, {st[:,7].sum()/max(st[:,6].sum(),1):.2f} extra polls per fetch, "
       f"{int(st[:,8].sum())} of {n} replicas still served at the end")
