@@ -783,6 +783,26 @@ int grlx_reset_run(grlx_ctx *ctx)
   return GRLX_OK;
 }
 
+// Mailboxes, stream and events of the environment server, created at the first launch that wants them.  The server is an optimisation: when
+// its 1 KB per replica (or a stream, or an event) cannot be had, the context goes on without it.
+static bool env_server_ready(grlx_ctx *ctx)
+{
+  if (ctx->env_mail) return true;
+  bool ok = hipMalloc((void **)&ctx->env_mail, (size_t)ctx->P.n_replicas * kEnvMailBytes) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&ctx->srv_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->srv_go, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->srv_done, hipEventDisableTiming) == hipSuccess;
+  if (ok) return true;
+  (void)hipGetLastError();
+  if (ctx->env_mail) (void)hipFree(ctx->env_mail);
+  if (ctx->srv_go) (void)hipEventDestroy(ctx->srv_go);
+  if (ctx->srv_done) (void)hipEventDestroy(ctx->srv_done);
+  if (ctx->srv_stream) (void)hipStreamDestroy(ctx->srv_stream);
+  ctx->env_mail = nullptr; ctx->srv_go = ctx->srv_done = nullptr; ctx->srv_stream = nullptr;
+  ctx->env_server = 0;
+  return false;
+}
+
 static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
@@ -844,15 +864,8 @@ static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *
       HIP_TRY(launch_rollout_tgt(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
       HIP_TRY(launch_rollout_acc(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
-    else if (ctx->env_server && env_server_serves(Pb) && (size_t)ctx->P.n_replicas * kEnvMailBytes < (1ull << 31))
+    else if (ctx->env_server && env_server_serves(Pb) && (size_t)ctx->P.n_replicas * kEnvMailBytes < (1ull << 31) && env_server_ready(ctx))
     { // the server's launch forks off the caller's stream and joins it again: for the caller, still one stream-ordered operation
-      if (!ctx->env_mail)
-      {
-        HIP_TRY(hipMalloc((void **)&ctx->env_mail, (size_t)ctx->P.n_replicas * kEnvMailBytes));
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->srv_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->srv_go, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->srv_done, hipEventDisableTiming));
-      }
       Pb.env_mail = ctx->env_mail;
       Pb.env_tune = 3u;        // the rollout wave is the critical path: it issues first, the server fills its gaps (+0.7 %)
       if (const char *tune = getenv("GRLX_ENV_SERVER_TUNE")) Pb.env_tune = (uint32_t)strtoul(tune, nullptr, 0);
@@ -893,7 +906,7 @@ int grlx_env_server_counts(grlx_ctx *ctx, int *served, int *fell_back)
   if (!ctx->env_mail) return GRLX_OK;
   DRAIN(ctx);
   std::vector<unsigned long long> flag((size_t)ctx->P.n_replicas);
-  HIP_TRY(hipMemcpy2D(flag.data(), sizeof(unsigned long long), (const char *)ctx->env_mail + 128 + 15 * sizeof(unsigned long long), kEnvMailBytes,
+  HIP_TRY(hipMemcpy2D(flag.data(), sizeof(unsigned long long), (const char *)ctx->env_mail + kEnvMailFlagOffset, kEnvMailBytes,
                       sizeof(unsigned long long), (size_t)ctx->P.n_replicas, hipMemcpyDeviceToHost));
   for (unsigned long long f : flag)
   {

@@ -38,6 +38,7 @@ struct __attribute__((aligned(1024))) EnvMail {
   unsigned long long pad1[36];
 };
 static_assert(sizeof(EnvMail) == kEnvMailBytes, "one mailbox = kEnvMailBytes");
+static_assert(offsetof(EnvMail, stats) + 15 * sizeof(unsigned long long) == kEnvMailFlagOffset, "the flag grlx_env_server_counts reads");
 
 typedef __attribute__((address_space(1))) unsigned long long env_gu64;
 typedef unsigned int mail_u32x4 __attribute__((ext_vector_type(4)));

@@ -8,6 +8,7 @@ namespace grlx {
 
 constexpr int kLanesPerReplica = 16;     // one lane per tiling
 constexpr size_t kEnvMailBytes = 1024;    // sizeof(EnvMail), grlx_env_server.h
+constexpr size_t kEnvMailFlagOffset = 128 + 15 * 8;   // offsetof(EnvMail, stats[15]): served to the end 1 / fell back 2
 constexpr int kReplicasPerWave = 4;      // per sub-batch; a wide wave carries 4*B (grlx_rollout_wide.h)
 constexpr int kMaxTrace = 10;            // replacing trace: (gamma*lambda)^n < 0.01 must hold for n <= 10
 constexpr int kMaxActions = GRLX_MAX_ACTIONS;
