@@ -45,6 +45,8 @@ typedef unsigned int mail_u32x4 __attribute__((ext_vector_type(4)));
 #define GRLX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr unsigned kMailReset = 3u, kMailExit = 4u;
 constexpr unsigned kFetchPolls = 400u;              // x (one round trip through memory) = ~0.5 ms: the server is not there
+constexpr unsigned kFirstFetchPolls = 8000u;        // the first answer of a launch: the two kernels start on two streams, and the first
+                                                    //   launch of a kernel in a process may wait for its scratch to be set up
 constexpr unsigned kServerStartPolls = 20000u;      // x (s_sleep + one round trip) = tens of ms without a first command: the rollout kernel is
                                                     //   not running beside this one (a profiler that serialises kernels, a busy device)
 constexpr unsigned kServerIdlePolls = 400000u;      // ... = half a second without a further command
@@ -139,7 +141,7 @@ __device__ __forceinline__ bool mail_take(const DevParams &N, const MailBox &b, 
   {
     const bool mine = (((unsigned long long)d.w << 32) | d.z) == seq;
     if ((__ballot(mine) & gmask) == gmask) { ok = true; break; }
-    if (++polls > kFetchPolls) break;
+    if (++polls > (seq <= 1u ? kFirstFetchPolls : kFetchPolls)) break;
     d = mail_prefetch(b, seq, a);
   }
   if (polled) *polled += polls;

@@ -52,9 +52,9 @@ def test_server_on_equals_server_off(grlx, monkeypatch, agent, n):
 def test_generic_instantiation_is_served_too(grlx, monkeypatch):
     seeds = np.arange(11, 19)
     monkeypatch.setenv("GRLX_ENV_SERVER", "0")
-    off = _snapshot(grlx, seeds, [30], force_generic=1)
+    off = _snapshot(grlx, seeds, [5, 25], force_generic=1)
     monkeypatch.delenv("GRLX_ENV_SERVER")
-    on = _snapshot(grlx, seeds, [30], force_generic=1)
+    on = _snapshot(grlx, seeds, [5, 25], force_generic=1)
     assert on["counts"][0] > 0
     _same(on, off)
 
