@@ -28,3 +28,8 @@ print(f"whole run: {(learn + test) / 1e6:.1f} M env-steps in {dt:.2f} s -> {(lea
       f"table load {r.table_load(0)} slots of {1 << cfg.table_log2_capacity if cfg.table_log2_capacity else 131072}")
 rows = r.rows(0)
 print("replica 0 first/last test returns:", rows[2][0], rows[2][-1])
+import hashlib
+h = hashlib.sha256()
+for k in range(0, n, max(n // 64, 1)):                # 64 replicas' complete learning curves: compare two builds / GRLX_ENV_SERVER settings
+    h.update(np.ascontiguousarray(r.rows(k)[2]).tobytes())
+print("sha256 of 64 replicas' returns:", h.hexdigest()[:16], " environment server (served, fell back in the last launch):", r.env_server_counts())
