@@ -152,3 +152,17 @@ def test_full_size_batches_server_on_equals_off(grlx, monkeypatch):
     assert on["steps"] == off["steps"]                       # learning and test steps summed over ALL replicas
     for k in picks:
         assert on[k] == off[k], f"replica {k}"
+
+
+@pytest.mark.parametrize("over", [dict(timeout=0.05), dict(timeout=0.1, test_interval=0), dict(timeout=0.31, test_interval=-1, randomization=1.0),
+                                  dict(timeout=0.2, test_interval=2, test_trials=3)])
+def test_short_episodes_stress_the_start_of_trial_hand_off(grlx, monkeypatch, over):
+    """Episodes of 2-11 steps: a RESET command every few passes, the last step of an episode without a command, test trials every trial
+    / never / as several episodes -- the corners of the command sequence (grlx_rollout.h: mail_send_reset, the terminal pass)."""
+    seeds = np.arange(21, 30)
+    monkeypatch.setenv("GRLX_ENV_SERVER", "0")
+    off = _snapshot(grlx, seeds, [40, 23], **over)
+    monkeypatch.delenv("GRLX_ENV_SERVER")
+    on = _snapshot(grlx, seeds, [40, 23], **over)
+    assert on["counts"][0] > 0
+    _same(on, off)
