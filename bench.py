@@ -129,6 +129,8 @@ def measured_pmc(key: str, n_replicas: int, trials_per_launch: int):
         return None, None, f"stale, refused ({tag}; this build is csrc {csrc_hash()}): rerun tools/profile_passes.sh"
     if t.get("replicas") != n_replicas or t.get("trials_per_launch") != trials_per_launch:
         return None, None, f"other configuration, refused ({tag}: {t.get('replicas')} replicas x {t.get('trials_per_launch')} trials)"
+    if t.get("note"):
+        tag += "; " + t["note"]
     return float(t["hbm_bytes_per_launch"]), t.get("issue"), tag
 
 
