@@ -14,8 +14,14 @@ __device__ __forceinline__ unsigned long long stamp()
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+// (GRLX_ENV_SERVER_STATS builds: the served kernel stamps too, and leaves its sums in its mailboxes -- tools/env_server_stats.py)
+#ifdef GRLX_ENV_SERVER_STATS
+#define GRLX_STAMPED (DIAG || SERVED)
+#else
+#define GRLX_STAMPED DIAG
+#endif
 #define DIAG_STAMP(slot)                                   \
-  if (DIAG)                                                \
+  if (GRLX_STAMPED)                                        \
   {                                                        \
     unsigned long long now__ = stamp();                    \
     diag_sum[slot] += now__ - diag_last;                   \
@@ -292,7 +298,7 @@ __device__ __forceinline__ void rollout_body(const DevParams &P, int n_trials)
   double pd_dW = 0, pd_dT = 0, pd_wp = 0;
   uint32_t pd_pos = kInvalidPos;
   unsigned long long diag_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, diag_last = 0;
-  if (DIAG) diag_last = stamp();
+  if (GRLX_STAMPED) diag_last = stamp();
 
   for (int trial = 0; trial < n_trials; ++trial)
   {
@@ -767,6 +773,7 @@ __device__ __forceinline__ void rollout_body(const DevParams &P, int n_trials)
       mail->stats[6] = st_fetch;
       mail->stats[7] = st_polls;
       mail->stats[8] = srv ? 1 : 0;
+      for (int k = 0; k < 8; ++k) mail->pad1[k] = diag_sum[k];
     }
 #endif
     if (live && j == 0 && P.env_mail) mail->stats[15] = srv ? 1u : 2u;     // (grlx_env_server_counts: served to the end / fell back)

@@ -28,4 +28,12 @@ print(f"rollout: kernel {st[:,4].mean():.0f} cycles, waiting for candidates {st[
       f"{st[:,6].mean():.0f} fetches, {st[:,5].sum()/max(st[:,6].sum(),1):.0f} cycles per fetch, {st[:,7].sum()/max(st[:,6].sum(),1):.2f} extra polls per fetch, "
       f"{int(st[:,8].sum())} of {n} replicas still served at the end")
 print(f"cycles per pass (rollout kernel / fetches): {st[:,4].sum()/max(st[:,6].sum(),1):.0f}   (s_memtime ticks = shader cycles)")
+ph = mail[:, 92:100].astype(np.float64)       # EnvMail::pad1[0..7]: the rollout wave's stamps (same slots as tools/diag_phases.py)
+names = ["loop/bookkeeping", "environment step: taking the server's answer", "tile hashing", "inserts + LDS writes", "LDS sums + sampler (+ command, load ahead)",
+         "TD update + trace", "wait for previous stores", "table lookup (loads)"]
+tot = ph.sum()
+if tot > 0:
+    print("rollout wave, share of the stamped cycles per phase (%.0f cycles per pass):" % (tot / max(st[:, 6].sum(), 1)))
+    for k, nm in enumerate(names):
+        print(f"  {nm:46s} {ph[:, k].sum() / tot:6.3f}   {ph[:, k].sum() / max(st[:, 6].sum(), 1):8.0f} cycles per pass")
 r.close()
