@@ -61,7 +61,7 @@ GRAPHS = {
                                   "rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update> with GRLX_ENV_SERVER=0)",
                            text="pendulum swing-up SARSA(lambda) hashed tile coding (cfg/pendulum/sarsa_tc.yaml semantics)"),
     "cart_pole_ac": dict(trials=11, want_kernel=2, pmc_key="cart_pole_ac",
-                         kernel="rollout_ac_wide_kernel<cart_pole, 8 replicas per wave, SpecCartPoleAc, deferred update>",
+                         kernel="rollout_ac_wide_kernel<cart_pole, 12 slots per wave rotated over 16 replicas, SpecCartPoleAc, deferred update>",
                          text="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml)"),
     # absorbing environments: episodes of very different lengths, so a launch is bounded by a STEPS budget per replica -- the second bound
     # of the reference's own trial loop (experiment/online_learning:steps, online_learning.cpp:154; grlx_run_steps) -- instead of by a
@@ -466,8 +466,11 @@ def main():
     ap.add_argument("--fqi-batch-size", type=int, default=0, help="tests: transitions per batch of the batch path")
     ap.add_argument("--fqi-epochs", type=int, default=0)
     ap.add_argument("--table-log2", type=int, default=0)
+    ap.add_argument("--replicas-per-wave", type=int, default=0, help="experiments: force the wave layout of the chosen workload (grlx_config.replicas_per_wave)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
+    if args.replicas_per_wave:
+        WORKLOADS[args.only or args.workload]["replicas_per_wave"] = args.replicas_per_wave
     if args.only:
         args.workload = args.only
         args.no_secondary = True

@@ -325,6 +325,7 @@ struct grlx_ctx {
   uint32_t     poison_pattern = 0;
   // the environment server of the pendulum rollout kernels (grlx_env_server.h): mailboxes, its stream, and the fork / join events
   int          env_server = 1;            // GRLX_ENV_SERVER=0 turns it off
+  void         *park = nullptr;           // rotating actor-critic kernel: parked lane state of the third sub-batch, per wave
   EnvMail      *env_mail = nullptr;
   hipStream_t  srv_stream = nullptr;
   hipEvent_t   srv_go = nullptr, srv_done = nullptr;
@@ -480,8 +481,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   if (cfg->n_replicas < 1) return fail(GRLX_ERR_INVALID, "n_replicas must be >= 1");
   if (cfg->max_rows < 1) return fail(GRLX_ERR_INVALID, "max_rows must be >= 1");
   if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8 &&
-      !(cfg->replicas_per_wave == 16 && cfg->agent == GRLX_AGENT_AC))
-    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8 (16: actor-critic only)");
+      !((cfg->replicas_per_wave == 12 || cfg->replicas_per_wave == 16) && cfg->agent == GRLX_AGENT_AC))
+    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8 (12, 16: actor-critic only)");
   if (cfg->wave_limit < 0) return fail(GRLX_ERR_INVALID, "wave_limit must be 0 (automatic) or positive");
   if (cfg->tap_deferred && cfg->tap_replica >= 0 && cfg->tap_capacity > 0)
   {
@@ -532,6 +533,11 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
     // parked state of four sub-batches is 48 KB of LDS, two waves per CU instead of four -- measured 213 M vs 329 M env-steps/s
     // at 16384 cart-pole replicas
     if (rpw == 0) rpw = ((N + kReplicasPerWave - 1) / kReplicasPerWave > simds) ? 8 : 4;
+    // actor-critic, more than 8 replicas per SIMD: 12 slots per wave, rotated trial by trial over the wave's own replicas
+    // (grlx_rollout_ac_wide.h; 16384 cart-pole replicas: 373 -> 405 M env-steps/s)
+    if (cfg->replicas_per_wave == 0 && cfg->agent == GRLX_AGENT_AC && rpw == 8 && N > 8 * simds && (N + simds - 1) / simds <= 64 &&
+        cfg->wave_limit == 0)
+      rpw = 12;
     if (!has_wide || P.tap_capacity > 0) rpw = 4;
     P.replicas_per_wave = rpw;
     P.wave_limit = cfg->wave_limit > 0 ? cfg->wave_limit : simds;      // these kernels hold a SIMD's whole register file: one wave per SIMD
@@ -563,6 +569,11 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMemset(ctx->row_time, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->queue, sizeof(uint32_t)));
+  if (cfg->agent == GRLX_AGENT_AC && P.replicas_per_wave == 12)
+  {
+    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * (size_t)P.wave_limit));
+    P.park = ctx->park;
+  }
   CTX_TRY(hipMalloc((void **)&ctx->max_load, sizeof(uint32_t)));
   CTX_TRY(hipMemset(ctx->max_load, 0, sizeof(uint32_t)));
   CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));
@@ -647,6 +658,7 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->scratch);
   (void)hipFree(ctx->queue);
   if (ctx->env_mail) (void)hipFree(ctx->env_mail);
+  if (ctx->park) (void)hipFree(ctx->park);
   if (ctx->srv_go) (void)hipEventDestroy(ctx->srv_go);
   if (ctx->srv_done) (void)hipEventDestroy(ctx->srv_done);
   if (ctx->srv_stream) (void)hipStreamDestroy(ctx->srv_stream);

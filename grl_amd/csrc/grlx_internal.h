@@ -9,6 +9,7 @@ namespace grlx {
 constexpr int kLanesPerReplica = 16;     // one lane per tiling
 constexpr size_t kEnvMailBytes = 1024;    // sizeof(EnvMail), grlx_env_server.h
 constexpr size_t kEnvMailFlagOffset = 128 + 15 * 8;   // offsetof(EnvMail, stats[15]): served to the end 1 / fell back 2
+constexpr size_t kAcParkBytes = 12 * 64 * 16 + 3 * 64 * 4;     // grlx_rollout_ac_wide.h: kWideQuads quads + three counters per lane
 constexpr int kReplicasPerWave = 4;      // per sub-batch; a wide wave carries 4*B (grlx_rollout_wide.h)
 constexpr int kMaxTrace = 10;            // replacing trace: (gamma*lambda)^n < 0.01 must hold for n <= 10
 constexpr int kMaxActions = GRLX_MAX_ACTIONS;
@@ -114,6 +115,7 @@ struct DevParams {
   uint64_t steps_budget;
   uint32_t env_tune;            // experiments (GRLX_ENV_SERVER_TUNE): bits 0-1 s_setprio of the rollout wave, 2-3 of the server wave, 4 no prefetch;
                                 // tests: bit 6 the server leaves at once (every replica falls back to integrating itself)
+  void    *park;                // rotating actor-critic kernel (12 slots): lane state of the third sub-batch, kAcParkBytes per wave
   struct EnvMail *env_mail;     // mailboxes of the environment server ([replica], grlx_env_server.h); null = the rollout kernel integrates itself
   int32_t  test_trials;         // experiment/online_learning:test_trials (>= 1): greedy episodes per test trial, averaged in the row
   // Actor-critic with EQUAL tile codings for actor and critic (cfg/cart_pole/ac_tc.yaml: the critic copies resolution and memory):

@@ -108,9 +108,22 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
   if (!taps && P.replicas_per_wave >= 8)
   { // two (four) sub-batches per wave share one environment phase (grlx_rollout_ac_wide.h); at most wave_limit waves, the
     // replicas beyond their first load are handed out by a device-side counter as slots fall idle
-    const int R = P.replicas_per_wave;
-    const int all_waves = (P.n_replicas + R - 1) / R;
-    const int wwaves = all_waves < P.wave_limit ? all_waves : P.wave_limit;
+    int R = P.replicas_per_wave;
+    int all_waves = (P.n_replicas + R - 1) / R;
+    int wwaves = all_waves < P.wave_limit ? all_waves : P.wave_limit;
+    // 12 slots: every wave owns ceil(n / waves) consecutive replicas and rotates them through its slots (no device-wide queue); a batch
+    // that would give a wave more than kAcOwnedMax runs in the 8-slot kernel
+    if (R == 12 && (P.n_replicas + wwaves - 1) / wwaves > kAcOwnedMax)
+    {
+      R = 8;
+      all_waves = (P.n_replicas + R - 1) / R;
+      wwaves = all_waves < P.wave_limit ? all_waves : P.wave_limit;
+    }
+    if (R == 12)
+    { // (with K = ceil(n / waves) replicas per wave the last waves may own none: launch only the ones that own some)
+      const int k = (P.n_replicas + wwaves - 1) / wwaves;
+      wwaves = (P.n_replicas + k - 1) / k;
+    }
     hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, P.queue, (uint32_t)wwaves * (uint32_t)R);
 #define GRLX_LAUNCH_AC_WIDE(NB)                                                                                                  \
     if (P.env == GRLX_ENV_CART_POLE && !P.no_specialisation && SpecCartPoleAc::matches(P))                                       \
@@ -125,6 +138,7 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
     else                                                                                                                         \
       return hipErrorInvalidValue;
     if (R == 16) { GRLX_LAUNCH_AC_WIDE(4) }
+    else if (R == 12) { GRLX_LAUNCH_AC_WIDE(3) }
     else { GRLX_LAUNCH_AC_WIDE(2) }
 #undef GRLX_LAUNCH_AC_WIDE
     return hipGetLastError();

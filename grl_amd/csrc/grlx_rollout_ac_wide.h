@@ -4,10 +4,22 @@
 // writes it back and takes the next unstarted replica from the counter P.queue (set to gridDim*R by the launcher), until the
 // counter passes n_replicas.  Episodes of a learning batch are ragged, so this is what keeps the 8 slots of a wave busy;
 // every replica still runs its own trials in order with its own tables and streams: results do not depend on who runs it.
+// B = 3 (12 slots): the environment phase is one instruction stream however many lanes it serves, so a third sub-batch makes a replica-step
+// cheaper (20.8 + 3 x 20.3 k cycles for 12 instead of 20.8 + 2 x 20.3 k for 8).  Two things make it fit and pay:
+//  * the LAST sub-batch's lane state is parked in device memory (P.park: 13 KB per wave, rewritten every pass: it lives in the L2)
+//    instead of LDS: 39 KB instead of 52 KB of LDS, four waves per CU as before.  (Keeping it in registers was tried first: the
+//    copies in and out of the accumulation registers and 24 more scratch accesses per sub-batch made EVERY sub-batch 15 % slower.)
+//  * ROTATION: a wave owns K = ceil(n / waves) consecutive replicas (K <= kAcOwnedMax) and passes its slots round per TRIAL, not per
+//    launch -- a slot whose replica has finished a trial queues it behind the waiting ones (a ring in LDS) and takes the one that has
+//    waited longest; remaining trials of the launch live in LDS.  16 replicas on 12 slots then keep all slots busy to the last round,
+//    where a per-launch hand-over would leave the last four alone in a second round.  Who runs a replica when does not matter (own tables,
+//    own streams; the critic's trace persists through slot_store / slot_load as it does between launches).
 // Part of the single translation unit grlx_kernels.hip (included there, in order; not self-contained).
 #pragma once
 
 namespace grlx {
+
+constexpr int kAcOwnedMax = 64;      // replicas a wave of the rotating (B = 3) kernel can own
 
 // WideRep slots reused: S1 holds the bits of ActionPolicy::n_ (ac_noise), eps_decay holds ActionPolicy::decay_ (ac_decay).
 template <int ENV, int B, typename SPEC>
@@ -15,6 +27,8 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
 {
   static_assert(B >= 2 && B <= 4, "sub-batches per wave");
   constexpr int R = 4 * B;
+  constexpr bool ROT = B == 3;               // rotation per trial over an owned set of replicas; last sub-batch parked in device memory
+  constexpr int BP = ROT ? B - 1 : B;        // sub-batches parked in LDS
   const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
   __shared__ double   sh_w[4 * 16 * 4];        // rows: actor(s'), critic(s'), actor(s), critic(s)
@@ -26,8 +40,11 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   __shared__ uint32_t sh_ms[4 * 16];
   __shared__ uint32_t sh_mail[4];
   __shared__ double   sh_res[4 * 16];
-  __shared__ uint4    sh_ctx[B * kWideQuads * 64];
-  __shared__ uint32_t sh_ins[B * 3 * 64];
+  __shared__ uint4    sh_ctx[BP * kWideQuads * 64];
+  __shared__ uint32_t sh_ins[BP * 3 * 64];
+  __shared__ uint32_t sh_left[ROT ? kAcOwnedMax : 1];     // ROT: trials of this launch the owned replica i still has to run
+  __shared__ uint32_t sh_ring[ROT ? kAcOwnedMax : 1];     //      owned replicas waiting for a slot, oldest first
+  __shared__ uint32_t sh_ring_ht[2];                      //      ring: pops so far, pushes so far
   __shared__ uint64_t sh_r64[WR_FIELDS64 * R];
   __shared__ uint32_t sh_r32[WR_FIELDS32 * R];
   __shared__ double   sh_x[S * R];
@@ -46,19 +63,31 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   const unsigned long long gmask = 0xFFFFull << (16 * g);
-  const int wave0 = blockIdx.x * R;
+  // ROT: the wave's own replicas wave0 .. wave0 + own - 1, the first R of them in its slots
+  const int owned_k = ROT ? (P.n_replicas + (int)gridDim.x - 1) / (int)gridDim.x : R;
+  const int wave0 = blockIdx.x * owned_k;
+  const int own = (P.n_replicas - wave0 < owned_k) ? ((P.n_replicas - wave0 > 0) ? P.n_replicas - wave0 : 0) : owned_k;
 
   // ---- environment role
   const int eq = lane % R;
   double x[S];
 #pragma unroll
-  for (int i = 0; i < S; ++i) x[i] = P.states[(wave0 + eq < P.n_replicas) ? wave0 + eq : 0].x[i];
+  for (int i = 0; i < S; ++i) x[i] = P.states[(eq < own) ? wave0 + eq : 0].x[i];
   uint32_t estatus = 0;
   if (lane < R)
   {
     sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0;
-    sh_rid[lane] = (wave0 + lane < P.n_replicas) ? (uint32_t)(wave0 + lane) : kNoReplica;
+    sh_rid[lane] = (lane < own) ? (uint32_t)(wave0 + lane) : kNoReplica;
     sh_xwb[lane] = kNoReplica;
+  }
+  if constexpr (ROT)
+  {
+    if (lane < kAcOwnedMax)
+    {
+      sh_left[lane] = (lane < own) ? (uint32_t)n_trials : 0u;
+      sh_ring[lane] = (R + lane < own) ? (uint32_t)(R + lane) : 0u;          // the owned replicas beyond the slots wait, in order
+    }
+    if (lane == 0) { sh_ring_ht[0] = 0u; sh_ring_ht[1] = (own > R) ? (uint32_t)(own - R) : 0u; }
   }
 
   // ---- table role
@@ -74,7 +103,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   const bool a_limit = N.lin_actor.limit != 0;
 
   // replica r into a slot: the critic's trace is restored (positions from HBM, weights from the current table)
-  auto slot_load = [&](int r, WideLane &c, WideRep &s) {
+  auto slot_load = [&](int r, WideLane &c, WideRep &s, int left) {
     const ReplicaState &RS = P.states[r];
     const Table tabC = table_of(P, 0, r);
     trace_init(c.tr);
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     s.running = false; s.first = true; s.test = 0;
     s.ending = false;
     s.rows = RS.rows;
-    s.trials_left = (P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget) ? 0 : n_trials;
+    s.trials_left = (P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget) ? 0 : left;
     s.sub_left = 0;
   };
   // ... and back: the critic's trace is persisted (its weights go to the table), the counters and streams to the replica
@@ -195,14 +224,18 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     }
   };
 
+  // ROT: where the last sub-batch's lane state is parked
+  uint4 *gl_ctx = ROT ? (uint4 *)P.park + (size_t)blockIdx.x * (kWideQuads * 64 + 3 * 64 / 4) : nullptr;
+  uint32_t *gl_ins = (uint32_t *)(gl_ctx + kWideQuads * 64);
   for (int b = 0; b < B; ++b)
   {
     const int q = 4 * b + g;
     WideLane c;
     WideRep s;
-    if (wave0 + q < P.n_replicas) slot_load(wave0 + q, c, s);
+    if (q < own) slot_load(wave0 + q, c, s, n_trials);
     else slot_empty(c, s);
-    wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+    if (ROT && b == B - 1) wide_park<true>(c, gl_ctx, gl_ins, lane);
+    else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
@@ -270,7 +303,16 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       RS.lazy_base[1] = RSg.lazy_base[1];
       const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
       WideLane c;
-      wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      // ROT: the loads now, the unpacking after the hashing -- the third sub-batch's come from the L2, not from LDS
+      uint4 raw[kWideQuads];
+      uint32_t rawi[3];
+      if constexpr (ROT)
+      {
+        if (b == B - 1) wide_unpark_load<true>(raw, rawi, gl_ctx, gl_ins, lane);
+        else wide_unpark_load<true>(raw, rawi, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      }
+      else
+        wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
       WideRep s;
       wide_rep_load<R>(s, sh_r64, sh_r32, q);
       if (!__any(live)) continue;                     // (a live slot always has something to do: it retires the moment it has not)
@@ -302,6 +344,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           slotA[0] = tile_slot_obs<T>(N.tile_actor, obs, D, j);
           slotC[0] = tile_slot_obs<T>(N.tile, obs, D, j);
         }
+        if constexpr (ROT) wide_unpark_decode<true>(c, raw, rawi);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (update)
         { // as looked up one pass ago (the actor's: or as written by the last actor update to the same slot); slots shared
@@ -316,6 +359,8 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           else table_issue<1>(tabC, slotC, lkC, brC);
         }
       }
+      else if constexpr (ROT)
+        wide_unpark_decode<true>(c, raw, rawi);
 
       GRLX_AC_STAMP(3)
       // the PREVIOUS step's critic update, in the shadow of the loads just issued
@@ -501,6 +546,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       {
         bool between = at_rest && s.trials_left > 0;
         bool again = false;                                 // another greedy episode of the same test trial follows (test_trials)
+        bool ended_now = false;                             // a trial of this slot's replica has just ended
         if (between && s.ending && s.test && s.sub_left > 0)
         {
           s.sub_left--;
@@ -533,21 +579,61 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           s.trials_left--;
           if (P.steps_budget != 0u && (uint64_t)s.ss >= P.steps_budget) s.trials_left = 0;        // online_learning.cpp:154: `ss < steps_`
           s.ending = false;
+          ended_now = true;
         }
-        if (at_rest && s.trials_left == 0 && !again)
-        { // this replica is done: back to HBM, and the next one from the queue (group-uniform: all 16 lanes are here)
-          slot_store(r, q, c, s);
-          uint32_t nr = 0u;
-          if (j == 0) nr = __hip_atomic_fetch_add(P.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          nr = __shfl(nr, 0, 16);
-          if (j == 0)
+        bool leave = at_rest && s.trials_left == 0 && !again;      // this replica is done
+        if constexpr (ROT)
+        { // ... or has finished a trial and has more to run: to the back of the wave's ring, behind the ones that are waiting
+          const bool rotate = at_rest && ended_now && !again && s.trials_left > 0;
+          if (rotate && j == 0)
           {
-            sh_xwb[q] = rid;
-            sh_est[q] = 0u;
-            sh_rid[q] = (nr < (uint32_t)P.n_replicas) ? nr : kNoReplica;
+            const uint32_t me = rid - (uint32_t)wave0;
+            sh_left[me] = (uint32_t)s.trials_left;
+            sh_ring[atomicAdd(&sh_ring_ht[1], 1u) % (uint32_t)kAcOwnedMax] = me;
           }
-          if (nr < (uint32_t)P.n_replicas) slot_load((int)nr, c, s);
-          else { slot_empty(c, s); now_live = false; }
+          leave = leave || rotate;
+          wave_sync();                                             // every push of this pass before the first pop
+        }
+        if (leave)
+        { // back to HBM, and the next one (group-uniform: all 16 lanes are here)
+          uint32_t nr = (uint32_t)P.n_replicas;                    // (= none)
+          int left = n_trials;
+          if constexpr (ROT)
+          {
+            uint32_t nl = kNoReplica;
+            if (j == 0)
+            {
+              const uint32_t h = atomicAdd(&sh_ring_ht[0], 1u);
+              if (h < sh_ring_ht[1]) nl = sh_ring[h % (uint32_t)kAcOwnedMax];
+              else atomicSub(&sh_ring_ht[0], 1u);
+            }
+            nl = __shfl(nl, 0, 16);
+            if (nl != kNoReplica)
+            {
+              nr = (uint32_t)wave0 + nl;
+              left = (int)sh_left[nl];
+            }
+          }
+          else
+          {
+            if (j == 0) nr = __hip_atomic_fetch_add(P.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nr = __shfl(nr, 0, 16);
+          }
+          if (!(ROT && nr == rid))                                 // (nobody was waiting: the replica goes on in its slot)
+          {
+            slot_store(r, q, c, s);
+            if (j == 0)
+            {
+              sh_xwb[q] = rid;
+              sh_est[q] = 0u;
+              sh_rid[q] = (nr < (uint32_t)P.n_replicas) ? nr : kNoReplica;
+            }
+            // ROT: the replica taken over may have been written back by another slot of this wave a moment ago (or in this very
+            // pass): its state, its trace and the weights the trace flushed must be in memory before they are read
+            if constexpr (ROT) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            if (nr < (uint32_t)P.n_replicas) slot_load((int)nr, c, s, left);
+            else { slot_empty(c, s); now_live = false; }
+          }
           between = now_live && s.trials_left > 0;
         }
         if (between && (s.trials_left > 0 || again))
@@ -586,7 +672,8 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       s.S1 = (uint64_t)__double_as_longlong(ac_noise);
       s.eps_decay = ac_decay;
       wide_rep_store<R>(s, sh_r64, sh_r32, q);
-      wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      if (ROT && b == B - 1) wide_park<true>(c, gl_ctx, gl_ins, lane);
+      else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
       GRLX_AC_STAMP(7)
     }
     wave_sync();

@@ -109,6 +109,48 @@ __device__ __forceinline__ void wide_unpark(WideLane &c, const uint4 *sh_ctx, co
   c.ap_pos = AC ? sh_ins[128 + lane] : kInvalidPos;
 }
 
+// wide_unpark in two halves: the loads, and -- after whatever can be done without the lane state -- the unpacking
+template <bool AC = false>
+__device__ __forceinline__ void wide_unpark_load(uint4 *raw, uint32_t *rawi, const uint4 *ctx, const uint32_t *ins, int lane)
+{
+#pragma unroll
+  for (int k = 0; k < kWideQuads; ++k) raw[k] = ctx[k * 64 + lane];
+  rawi[0] = ins[lane];
+  rawi[1] = AC ? ins[64 + lane] : 0u;
+  rawi[2] = AC ? ins[128 + lane] : kInvalidPos;
+}
+template <bool AC = false>
+__device__ __forceinline__ void wide_unpark_decode(WideLane &c, const uint4 *raw, const uint32_t *rawi)
+{
+  uint4 q = raw[0];
+  c.tr.pos[0] = q.x; c.tr.pos[1] = q.y; c.tr.pos[2] = q.z; c.tr.pos[3] = q.w;
+  q = raw[1];
+  c.tr.pos[4] = q.x; c.tr.pos[5] = q.y; c.tr.pos[6] = q.z; c.tr.pos[7] = q.w;
+  q = raw[2];
+  c.tr.pos[8] = q.x; c.tr.pos[9] = q.y; c.tr.cnt2 = q.z;
+  c.tr.wt = q.w & 0xFFFFu;
+  c.tr.dup = ((q.w >> 16) & 1u) != 0u;
+  c.tr.len = (int)(q.w >> 20);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) unpack2d(raw[3 + k], c.tr.val[2 * k], c.tr.val[2 * k + 1]);
+  q = raw[8];
+  c.tr.total = __longlong_as_double((long long)((uint64_t)q.x | ((uint64_t)q.y << 32)));
+  c.pd_pos = q.z;
+  c.p_pos = q.w;
+  unpack2d(raw[9], c.pd_dW, c.pd_dT);
+  q = raw[10];
+  c.pd_wp = __longlong_as_double((long long)((uint64_t)q.x | ((uint64_t)q.y << 32)));
+  c.pd = (q.z & 1u) != 0u;
+  c.pd_sh = (q.z & 2u) != 0u;
+  c.p_sh = (q.z & 4u) != 0u;
+  c.status = q.w;
+  unpack2d(raw[11], c.wp_seen, c.wap_seen);
+  c.inserted = rawi[0];
+  c.ap_sh = AC && (q.z & 8u) != 0u;
+  c.inserted2 = rawi[1];
+  c.ap_pos = rawi[2];
+}
+
 // per-replica scalars of the table role, parked as a structure of arrays [field][replica in wave]
 enum { WR_G = 0, WR_TL, WR_S1, WR_EPS, WR_TT, WR_SS, WR_TSTEPS, WR_TOTAL, WR_TIME, WR_ACTION, WR_FIELDS64 };
 enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_LEFT, WR_SUB, WR_FIELDS32 };

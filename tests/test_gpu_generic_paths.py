@@ -233,11 +233,12 @@ def test_wide_waves_actor_critic_bit_exact(grlx, over, n, wave_limit):
     critic's trace kept across episodes AND launches (three launches), a ragged batch, every replica checked.
     wave_limit 1 / 2: ONE (two) wave(s) for 29 replicas -- the first 8 (16) start in its slots, the others are taken from the
     device-side queue as slots finish (grlx_rollout_ac_wide.h); 16 replicas on one wave: the queue runs dry with every slot
-    busy.  Who runs a replica must not matter."""
+    busy.  12 slots: the wave OWNS its replicas (29, 15 + 14, 16 of them) and rotates them through its slots trial by trial.
+    Who runs a replica, and when, must not matter."""
     from tests import configs
     trials = 24
     got = {}
-    for rpw in (16, 8, 4):
+    for rpw in (16, 12, 8, 4):
         cfg, spec = configs.cart_pole_ac(grlx, n, **over)
         cfg.replicas_per_wave = rpw
         cfg.wave_limit = wave_limit
@@ -252,7 +253,7 @@ def test_wide_waves_actor_critic_bit_exact(grlx, over, n, wave_limit):
     for k in range(n):
         e = ob.Experiment(spec, seed=201 + k)
         rows, _ = e.run(trials)
-        for rpw in (16, 8, 4):
+        for rpw in (16, 12, 8, 4):
             (t, s, rew), rg, st, w0, w1 = got[rpw][k]
             assert list(s) == [x.steps for x in rows], f"rpw {rpw} replica {k}"
             assert_bit_equal(rew, [x.reward for x in rows], f"rpw {rpw}: returns of replica {k}")
@@ -806,3 +807,45 @@ def test_discrete_actions_on_the_cart_pole(grlx, agent):
             assert_bit_equal(r.weights(k, slots), e.weights(slots), f"rpw {rpw}: weights of replica {k}")
             e.close()
         r.close()
+
+
+def test_twelve_slots_rotate_under_a_steps_budget_and_test_trials(grlx):
+    """The rotating actor-critic kernel (12 slots, grlx_rollout_ac_wide.h) with everything that ends a replica's turn at once: ONE wave
+    owns 17 replicas (5 always waiting), episodes are ragged (end-stop penalty), test trials are two greedy episodes (no hand-over
+    between them), and two successive steps budgets stop the replicas at trials of their own.  Rows, streams, states, step counts
+    and both dense tables' samples against the oracle."""
+    from tests import configs
+    n, budgets = 17, (900, 2100)
+    cfg, spec = configs.cart_pole_ac(grlx, n, replicas_per_wave=12, max_rows=400, test_trials=2, end_stop_penalty=1)
+    cfg.wave_limit = 1
+    spec.test_trials = 2
+    spec.math = ob.MATH_PORTABLE
+    seeds = np.arange(301, 301 + n)
+    r = grlx.Runner(cfg, seeds)
+    assert r.replicas_per_wave() == 12
+    oracles = [ob.Experiment(spec, seed=int(s)) for s in seeds]
+    orows = [[] for _ in seeds]
+    for budget in budgets:
+        r.run_steps(100000, budget)
+        r.sync()
+        for k, e in enumerate(oracles):
+            e.set_steps_budget(budget)
+            orows[k] += e.run(100000)[0]
+    rng = np.random.default_rng(3)
+    slots = rng.integers(0, 8388608, 1200).astype(np.uint32)
+    total_learn, rows_seen = 0, set()
+    for k, e in enumerate(oracles):
+        total_learn += int(e.stats().learn_steps)
+        t, s, rew = r.rows(k)
+        assert list(t) == [x.trial for x in orows[k]] and list(s) == [x.steps for x in orows[k]], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in orows[k]], f"returns of replica {k}")
+        assert_bit_equal(r.row_times(k, 0, len(orows[k])), [x.time for x in orows[k]], f"times of replica {k}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2], f"replica {k}"
+        assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
+        assert_bit_equal(r.weights(k, slots, 0), e.weights(slots, 0), f"critic weights of replica {k}")
+        assert_bit_equal(r.weights(k, slots, 1), e.weights(slots, 1), f"actor weights of replica {k}")
+        rows_seen.add(len(orows[k]))
+        e.close()
+    assert r.step_counts()[0] == total_learn
+    assert len(rows_seen) > 1
+    r.close()

@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
-"""Phases of the wide actor-critic kernel (stamped build: GRLX_EXTRA_FLAGS=-DGRLX_WIDE_STAMPS): ac_wide_phases.py [replicas] [trials]"""
+"""Phases of the wide actor-critic kernel (stamped build: GRLX_EXTRA_FLAGS=-DGRLX_WIDE_STAMPS): ac_wide_phases.py [replicas] [trials] [replicas per wave]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import grl_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+rpw = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 cfg = grl_amd.cart_pole_ac_config(n, max_rows=8 * trials + 8)
+cfg.replicas_per_wave = rpw
 r = grl_amd.Runner(cfg, np.arange(1, n + 1))
 r.run(trials); r.sync()
 r.set_diag(True)
 l0, t0s = r.step_counts()
 t0 = time.perf_counter(); r.run(trials); r.sync(); dt = time.perf_counter() - t0
 l1, t1s = r.step_counts()
-waves = min((n + 7) // 8, 1024)
+waves = min((n + rpw - 1) // rpw, 1024)
 d = r.read_diag().astype(np.float64)[:waves]
 steps = (l1 - l0) + (t1s - t0s)
 passes = d[:, 2].sum()
