@@ -147,7 +147,8 @@ class Runner:
         return a.value, b.value
 
     def replicas_per_wave(self) -> int:
-        """4: one replica per 16 lanes; 8: two sub-batches per wave sharing the environment phase (wide kernels)."""
+        """4: one replica per 16 lanes; 8: two sub-batches per wave sharing the environment phase (wide kernels); 12 / 16: three / four
+        sub-batches (actor-critic only; 12 rotates the wave's own replicas through its slots trial by trial)."""
         return self.lib.grlx_replicas_per_wave(self._ctx)
 
     def row_times(self, replica: int, first: int = 0, count: int = None):
