@@ -384,7 +384,7 @@ __device__ __forceinline__ void rollout_body(const DevParams &P, int n_trials)
               }
             }
           if (!stepped)
-          env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, status, lshare);   // online_learning.cpp:196
+            env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, status, lshare);   // online_learning.cpp:196
           total_reward += reward;                                          // :202
           time += 1;                                                       // tau = 1
         }
@@ -595,7 +595,7 @@ __device__ __forceinline__ void rollout_body(const DevParams &P, int n_trials)
             ++mseq;
             if (j == 0) mail_send(mail, mseq, (unsigned)a_next);
             if (!(P.env_tune & 16u))
-            mpre = mail_prefetch(mbox, mseq - 1, a_next);        // what the next pass starts from: ready unless the server is late
+              mpre = mail_prefetch(mbox, mseq - 1, a_next);        // what the next pass starts from: ready unless the server is late
           }
 
         DIAG_STAMP(4)

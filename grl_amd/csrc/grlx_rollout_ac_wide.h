@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   };
 
   // ROT: where the last sub-batch's lane state is parked
+  static_assert(kAcParkBytes == (kWideQuads * 64 + 3 * 64 / 4) * sizeof(uint4), "grlx_api.cpp sizes DevParams.park with kAcParkBytes per wave");
   uint4 *gl_ctx = ROT ? (uint4 *)P.park + (size_t)blockIdx.x * (kWideQuads * 64 + 3 * 64 / 4) : nullptr;
   uint32_t *gl_ins = (uint32_t *)(gl_ctx + kWideQuads * 64);
   for (int b = 0; b < B; ++b)
