@@ -61,7 +61,7 @@ GRAPHS = {
                                   "rollout_kernel<pendulum, 3 actions, SpecPendulumTc(SARSA), deferred update> with GRLX_ENV_SERVER=0)",
                            text="pendulum swing-up SARSA(lambda) hashed tile coding (cfg/pendulum/sarsa_tc.yaml semantics)"),
     "cart_pole_ac": dict(trials=11, want_kernel=2, pmc_key="cart_pole_ac",
-                         kernel="rollout_ac_wide_kernel<cart_pole, 12 slots per wave rotated over 16 replicas, SpecCartPoleAc, deferred update>",
+                         kernel="rollout_ac_wide_kernel<cart_pole, 16 replicas per wave (four sub-batches, two parked in device memory), SpecCartPoleAc, deferred update>",
                          text="cart-pole swing-up actor-critic, two tile-coded tables (cfg/cart_pole/ac_tc.yaml)"),
     # absorbing environments: episodes of very different lengths, so a launch is bounded by a STEPS budget per replica -- the second bound
     # of the reference's own trial loop (experiment/online_learning:steps, online_learning.cpp:154; grlx_run_steps) -- instead of by a

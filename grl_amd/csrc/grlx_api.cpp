@@ -529,15 +529,19 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
     int dev = 0;
     int simds = 1024;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) simds = 4 * prop.multiProcessorCount;
-    // 8 once the 4-replica waves outnumber the SIMDs.  16 (actor-critic, four sub-batches) is never chosen automatically: the
-    // parked state of four sub-batches is 48 KB of LDS, two waves per CU instead of four -- measured 213 M vs 329 M env-steps/s
-    // at 16384 cart-pole replicas
+    // 8 once the 4-replica waves outnumber the SIMDs.  (Round 2's 16-slot actor-critic kernel parked four sub-batches in 66 KB of LDS,
+    // two waves per CU: 213 M vs 329 M env-steps/s at 16384 cart-pole replicas.  Since round 3 the sub-batches beyond the second park in
+    // device memory)
     if (rpw == 0) rpw = ((N + kReplicasPerWave - 1) / kReplicasPerWave > simds) ? 8 : 4;
-    // actor-critic, more than 8 replicas per SIMD: 12 slots per wave, rotated trial by trial over the wave's own replicas
-    // (grlx_rollout_ac_wide.h; 16384 cart-pole replicas: 373 -> 405 M env-steps/s)
-    if (cfg->replicas_per_wave == 0 && cfg->agent == GRLX_AGENT_AC && rpw == 8 && N > 8 * simds && (N + simds - 1) / simds <= 64 &&
-        cfg->wave_limit == 0)
-      rpw = 12;
+    // actor-critic, more than 8 replicas per SIMD: more slots per wave share one environment phase (grlx_rollout_ac_wide.h; 16384 cart-pole
+    // replicas: 373 M env-steps/s with 8 slots, 405 M with 12, 425 M with 16).  16 slots for 15 or more replicas per SIMD; 12, rotated
+    // trial by trial over the wave's own replicas, for 9 to 14 (13 replicas keep 12 slots busier than 16).
+    if (cfg->replicas_per_wave == 0 && cfg->agent == GRLX_AGENT_AC && rpw == 8 && cfg->wave_limit == 0)
+    {
+      const int per_simd = (N + simds - 1) / simds;
+      if (per_simd >= 15) rpw = 16;
+      else if (per_simd >= 9) rpw = 12;
+    }
     if (!has_wide || P.tap_capacity > 0) rpw = 4;
     P.replicas_per_wave = rpw;
     P.wave_limit = cfg->wave_limit > 0 ? cfg->wave_limit : simds;      // these kernels hold a SIMD's whole register file: one wave per SIMD
@@ -569,9 +573,9 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMemset(ctx->row_time, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->queue, sizeof(uint32_t)));
-  if (cfg->agent == GRLX_AGENT_AC && P.replicas_per_wave == 12)
-  {
-    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * (size_t)P.wave_limit));
+  if (cfg->agent == GRLX_AGENT_AC && P.replicas_per_wave >= 12)
+  { // the sub-batches beyond the second park their lane state here (grlx_rollout_ac_wide.h)
+    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * (size_t)(P.replicas_per_wave / 4 - 2) * (size_t)P.wave_limit));
     P.park = ctx->park;
   }
   CTX_TRY(hipMalloc((void **)&ctx->max_load, sizeof(uint32_t)));

@@ -6,8 +6,8 @@
 // every replica still runs its own trials in order with its own tables and streams: results do not depend on who runs it.
 // B = 3 (12 slots): the environment phase is one instruction stream however many lanes it serves, so a third sub-batch makes a replica-step
 // cheaper (20.8 + 3 x 20.3 k cycles for 12 instead of 20.8 + 2 x 20.3 k for 8).  Two things make it fit and pay:
-//  * the LAST sub-batch's lane state is parked in device memory (P.park: 13 KB per wave, rewritten every pass: it lives in the L2)
-//    instead of LDS: 39 KB instead of 52 KB of LDS, four waves per CU as before.  (Keeping it in registers was tried first: the
+//  * the lane state of the sub-batches beyond the second is parked in device memory (P.park: 13 KB per wave and sub-batch, rewritten
+//    every pass: it lives in the L2) instead of LDS: 39 KB instead of 52 KB (B = 3) / 66 KB (B = 4) of LDS, four waves per CU as before.  (Keeping it in registers was tried first: the
 //    copies in and out of the accumulation registers and 24 more scratch accesses per sub-batch made EVERY sub-batch 15 % slower.)
 //  * ROTATION: a wave owns K = ceil(n / waves) consecutive replicas (K <= kAcOwnedMax) and passes its slots round per TRIAL, not per
 //    launch -- a slot whose replica has finished a trial queues it behind the waiting ones (a ring in LDS) and takes the one that has
@@ -27,8 +27,9 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
 {
   static_assert(B >= 2 && B <= 4, "sub-batches per wave");
   constexpr int R = 4 * B;
-  constexpr bool ROT = B == 3;               // rotation per trial over an owned set of replicas; last sub-batch parked in device memory
-  constexpr int BP = ROT ? B - 1 : B;        // sub-batches parked in LDS
+  constexpr bool ROT = B == 3;               // rotation per trial over an owned set of replicas
+  constexpr bool GLP = B >= 3;               // the sub-batches beyond the second park their lane state in device memory (P.park), not in LDS
+  constexpr int BP = GLP ? 2 : B;            // sub-batches parked in LDS
   const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
   __shared__ double   sh_w[4 * 16 * 4];        // rows: actor(s'), critic(s'), actor(s), critic(s)
@@ -224,10 +225,12 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     }
   };
 
-  // ROT: where the last sub-batch's lane state is parked
-  static_assert(kAcParkBytes == (kWideQuads * 64 + 3 * 64 / 4) * sizeof(uint4), "grlx_api.cpp sizes DevParams.park with kAcParkBytes per wave");
-  uint4 *gl_ctx = ROT ? (uint4 *)P.park + (size_t)blockIdx.x * (kWideQuads * 64 + 3 * 64 / 4) : nullptr;
-  uint32_t *gl_ins = (uint32_t *)(gl_ctx + kWideQuads * 64);
+  // GLP: where the lane state of sub-batch b >= 2 is parked (B - 2 areas per wave)
+  constexpr int kParkQuads = kWideQuads * 64 + 3 * 64 / 4;
+  static_assert(kAcParkBytes == kParkQuads * sizeof(uint4), "grlx_api.cpp sizes DevParams.park with kAcParkBytes per wave and area");
+  uint4 *gl_base = GLP ? (uint4 *)P.park + (size_t)blockIdx.x * (size_t)(kParkQuads * (B - 2)) : nullptr;
+  auto gl_ctx = [&](int b) { return gl_base + (b - 2) * kParkQuads; };
+  auto gl_ins = [&](int b) { return (uint32_t *)(gl_base + (b - 2) * kParkQuads + kWideQuads * 64); };
   for (int b = 0; b < B; ++b)
   {
     const int q = 4 * b + g;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     WideRep s;
     if (q < own) slot_load(wave0 + q, c, s, n_trials);
     else slot_empty(c, s);
-    if (ROT && b == B - 1) wide_park<true>(c, gl_ctx, gl_ins, lane);
+    if (GLP && b >= 2) wide_park<true>(c, gl_ctx(b), gl_ins(b), lane);
     else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
@@ -304,12 +307,12 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       RS.lazy_base[1] = RSg.lazy_base[1];
       const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
       WideLane c;
-      // ROT: the loads now, the unpacking after the hashing -- the third sub-batch's come from the L2, not from LDS
+      // GLP: the loads now, the unpacking after the hashing -- those of the sub-batches beyond the second come from the L2, not from LDS
       uint4 raw[kWideQuads];
       uint32_t rawi[3];
-      if constexpr (ROT)
+      if constexpr (GLP)
       {
-        if (b == B - 1) wide_unpark_load<true>(raw, rawi, gl_ctx, gl_ins, lane);
+        if (b >= 2) wide_unpark_load<true>(raw, rawi, gl_ctx(b), gl_ins(b), lane);
         else wide_unpark_load<true>(raw, rawi, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
       }
       else
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           slotA[0] = tile_slot_obs<T>(N.tile_actor, obs, D, j);
           slotC[0] = tile_slot_obs<T>(N.tile, obs, D, j);
         }
-        if constexpr (ROT) wide_unpark_decode<true>(c, raw, rawi);
+        if constexpr (GLP) wide_unpark_decode<true>(c, raw, rawi);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (update)
         { // as looked up one pass ago (the actor's: or as written by the last actor update to the same slot); slots shared
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           else table_issue<1>(tabC, slotC, lkC, brC);
         }
       }
-      else if constexpr (ROT)
+      else if constexpr (GLP)
         wide_unpark_decode<true>(c, raw, rawi);
 
       GRLX_AC_STAMP(3)
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       s.S1 = (uint64_t)__double_as_longlong(ac_noise);
       s.eps_decay = ac_decay;
       wide_rep_store<R>(s, sh_r64, sh_r32, q);
-      if (ROT && b == B - 1) wide_park<true>(c, gl_ctx, gl_ins, lane);
+      if (GLP && b >= 2) wide_park<true>(c, gl_ctx(b), gl_ins(b), lane);
       else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
       GRLX_AC_STAMP(7)
     }

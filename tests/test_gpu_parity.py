@@ -916,7 +916,8 @@ def _check_sampled_replicas(grlx, r, spec, seeds, sample, trials):
         assert_bit_equal(r.env_state(k), e.state(), f"env state of replica {k}")
 
 
-@pytest.mark.parametrize("name,n,trials", [("pendulum", 4096, 44), ("cart_pole_ac", 16384, 22), ("compass_walker", 8192, 22), ("acrobot", 8192, 33)])
+@pytest.mark.parametrize("name,n,trials", [("pendulum", 4096, 44), ("cart_pole_ac", 16384, 22), ("cart_pole_ac", 13312, 22), ("compass_walker", 8192, 22),
+                                           ("acrobot", 8192, 33)])
 def test_full_size_batches(grlx, name, n, trials):
     """The replica counts BASELINE.json quotes (configs[1..3], per-GPU share of configs[3]): replicas are
     independent, so ANY replica of the big batch must equal the scalar oracle run with its seed
@@ -927,6 +928,8 @@ def test_full_size_batches(grlx, name, n, trials):
     cfg, spec = make(grlx, n)
     seeds = np.arange(1, n + 1)
     r = grlx.Runner(cfg, seeds)
+    if name == "cart_pole_ac":                                 # 16 per SIMD: four sub-batches per wave; 13: twelve slots, rotated (grlx_rollout_ac_wide.h)
+        assert r.replicas_per_wave() == (16 if n == 16384 else 12)
     r.run(trials // 2); r.run(trials - trials // 2)
     r.sync()                                                   # raises if any replica flagged an error
     learn, test = r.step_counts()

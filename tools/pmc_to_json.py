@@ -22,7 +22,7 @@ from bench import csrc_hash  # noqa: E402  (identifies the device code the passe
 WORKLOADS = [("rollout_kernel<0, 3, false, grlx::SpecPendulumTcA<0>", "pendulum_sarsa", 4096, 11, 20),
              ("rollout_served_kernel<3, grlx::SpecPendulumTcA<0>", "pendulum_sarsa", 4096, 11, 20),
              ("env_server_kernel<0, 3, grlx::SpecPendulumTcA<0>", "pendulum_sarsa_env_server", 4096, 11, 20),
-             ("rollout_ac_wide_kernel<1, 3, grlx::SpecCartPoleAc>", "cart_pole_ac", 16384, 11, 5),
+             ("rollout_ac_wide_kernel<1, 4, grlx::SpecCartPoleAc>", "cart_pole_ac", 16384, 11, 5),
              ("rollout_wide_kernel<2, 3, 2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 1100, 5),          # (steps budget per launch)
              ("rollout_wide_kernel<3, 3, 2, grlx::SpecWalkerQ>", "compass_walker_q", 8192, 12200, 5)]
 
