@@ -475,6 +475,10 @@ def main():
         args.workload = args.only
         args.no_secondary = True
     D = Dist(args)
+    if os.environ.get("GRLX_DUMP_MAPS"):
+        # diagnostic: the process's mappings when the interpreter ends (names the libraries behind the PCs of a crash in a C exit handler)
+        import atexit
+        atexit.register(lambda: open(os.environ["GRLX_DUMP_MAPS"], "w").write(open("/proc/self/maps").read()))
 
     import torch
     import torch.distributed as dist

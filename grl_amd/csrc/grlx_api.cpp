@@ -329,6 +329,13 @@ struct grlx_ctx {
   EnvMail      *env_mail = nullptr;
   hipStream_t  srv_stream = nullptr;
   hipEvent_t   srv_go = nullptr, srv_done = nullptr;
+  // per-step entry points (grlx_env_start / _advance, grlx_agent_start / _step / _end): agent state between calls and the staging
+  // buffers of their host arguments, created at the first such call
+  AgentRep     *agent_rep = nullptr;
+  uint32_t     *agent_lane = nullptr;
+  double       *stage_f64 = nullptr;      // [N][GRLX_MAX_DIMS] obs | [N] reward | [N] action
+  int32_t      *stage_i32 = nullptr;      // [N] active | [N] terminal
+  uint64_t     step_calls = 0;            // agent calls since the last look at the tables' load
 };
 
 // small RAII helper for the copy-in / copy-out entry points
@@ -663,6 +670,10 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->queue);
   if (ctx->env_mail) (void)hipFree(ctx->env_mail);
   if (ctx->park) (void)hipFree(ctx->park);
+  if (ctx->agent_rep) (void)hipFree(ctx->agent_rep);
+  if (ctx->agent_lane) (void)hipFree(ctx->agent_lane);
+  if (ctx->stage_f64) (void)hipFree(ctx->stage_f64);
+  if (ctx->stage_i32) (void)hipFree(ctx->stage_i32);
   if (ctx->srv_go) (void)hipEventDestroy(ctx->srv_go);
   if (ctx->srv_done) (void)hipEventDestroy(ctx->srv_done);
   if (ctx->srv_stream) (void)hipStreamDestroy(ctx->srv_stream);
@@ -795,6 +806,8 @@ int grlx_reset_run(grlx_ctx *ctx)
     HIP_TRY(hipMemcpy(ctx->trace_state, init.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   if (ctx->tap_count) HIP_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
+  if (ctx->agent_rep) HIP_TRY(hipMemset(ctx->agent_rep, 0, sizeof(AgentRep) * N));
+  if (ctx->agent_lane) HIP_TRY(hipMemset(ctx->agent_lane, 0, sizeof(uint32_t) * N * 16 * 2));
   ctx->trials_run = 0;
   return GRLX_OK;
 }
@@ -1177,6 +1190,175 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
     }
   }
   return GRLX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The per-step plug-in interfaces on a context's replicas (grlx_step.h).  Host pointers; each call copies its arguments in,
+// launches one kernel over all replicas and copies the results out.
+static int step_buffers(grlx_ctx *ctx)
+{
+  if (ctx->stage_f64) return GRLX_OK;
+  const size_t N = (size_t)ctx->P.n_replicas;
+  if (hipMalloc((void **)&ctx->stage_f64, sizeof(double) * N * (GRLX_MAX_DIMS + 2)) != hipSuccess ||
+      hipMalloc((void **)&ctx->stage_i32, sizeof(int32_t) * N * 2) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    if (ctx->stage_f64) (void)hipFree(ctx->stage_f64);
+    ctx->stage_f64 = nullptr;
+    return fail(GRLX_ERR_OOM, "no device memory for the staging buffers of the per-step entry points");
+  }
+  return GRLX_OK;
+}
+
+static const int32_t *stage_active(grlx_ctx *ctx, const int32_t *active, hipError_t *err)
+{
+  *err = hipSuccess;
+  if (!active) return nullptr;
+  *err = hipMemcpy(ctx->stage_i32, active, sizeof(int32_t) * (size_t)ctx->P.n_replicas, hipMemcpyHostToDevice);
+  return ctx->stage_i32;
+}
+
+int grlx_env_start(grlx_ctx *ctx, int test, const int32_t *active, double *obs)
+{
+  if (!ctx || !obs) return fail(GRLX_ERR_INVALID, "bad argument");
+  DRAIN(ctx);
+  int rc = step_buffers(ctx);
+  if (rc != GRLX_OK) return rc;
+  const size_t N = (size_t)ctx->P.n_replicas, D = (size_t)ctx->D;
+  hipError_t e;
+  const int32_t *act = stage_active(ctx, active, &e);
+  HIP_TRY(e);
+  if (active) HIP_TRY(hipMemcpy(ctx->stage_f64, obs, sizeof(double) * N * D, hipMemcpyHostToDevice));     // inactive rows keep the caller's values
+  HIP_TRY(launch_env_start(ctx->P, test ? 1 : 0, act, ctx->stage_f64, nullptr));
+  HIP_TRY(hipMemcpy(obs, ctx->stage_f64, sizeof(double) * N * D, hipMemcpyDeviceToHost));
+  return GRLX_OK;
+}
+
+int grlx_env_advance(grlx_ctx *ctx, const int32_t *active, const double *action, double *obs, double *reward, int32_t *terminal)
+{
+  if (!ctx || !action || !obs || !reward || !terminal) return fail(GRLX_ERR_INVALID, "bad argument");
+  DRAIN(ctx);
+  int rc = step_buffers(ctx);
+  if (rc != GRLX_OK) return rc;
+  const size_t N = (size_t)ctx->P.n_replicas, D = (size_t)ctx->D;
+  double *d_obs = ctx->stage_f64, *d_reward = d_obs + N * GRLX_MAX_DIMS, *d_action = d_reward + N;
+  int32_t *d_term = ctx->stage_i32 + N;
+  hipError_t e;
+  const int32_t *act = stage_active(ctx, active, &e);
+  HIP_TRY(e);
+  if (active)
+  { // inactive rows keep the caller's values
+    HIP_TRY(hipMemcpy(d_obs, obs, sizeof(double) * N * D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_reward, reward, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_term, terminal, sizeof(int32_t) * N, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemcpy(d_action, action, sizeof(double) * N, hipMemcpyHostToDevice));
+  HIP_TRY(launch_env_advance(ctx->P, act, d_action, d_obs, d_reward, d_term, nullptr));
+  HIP_TRY(hipMemcpy(obs, d_obs, sizeof(double) * N * D, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(reward, d_reward, sizeof(double) * N, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(terminal, d_term, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+  uint64_t h[3];                                        // a state outside the sine's domain is reported at once, as grlx_env_step does
+  HIP_TRY(launch_step_counts(ctx->P, ctx->scratch, nullptr));
+  HIP_TRY(hipMemcpy(h, ctx->scratch, sizeof(h), hipMemcpyDeviceToHost));
+  return status_to_error(h[2] & ST_DOMAIN);
+}
+
+// the agent kinds the per-step kernels are built for, and the state they keep between calls
+static int agent_ready(grlx_ctx *ctx)
+{
+  const grlx_config &c = ctx->cfg;
+  const bool td = c.agent == GRLX_AGENT_SARSA || c.agent == GRLX_AGENT_Q || c.agent == GRLX_AGENT_EXPECTED_SARSA;
+  if (!(td || c.agent == GRLX_AGENT_AC) || c.trace == GRLX_TRACE_ACCUMULATING || c.target_interval > 0 || c.projector.safe != 0 ||
+      (td && c.action_steps != 3 && c.action_steps != 5))
+    return fail(GRLX_ERR_INVALID, "the per-step agent entry points are built for agent/td with predictor/critic/{sarsa, q, expected_sarsa} (3 or 5 actions, "
+                                  "replacing or no trace, no target network, safe = 0) and for the actor-critic agent");
+  if (ctx->P.tap_capacity > 0 || ctx->P.diag_out) return fail(GRLX_ERR_INVALID, "the per-step agent entry points are not available with taps or diagnostics");
+  if (ctx->agent_rep) return GRLX_OK;
+  const size_t N = (size_t)ctx->P.n_replicas;
+  int rc = step_buffers(ctx);
+  if (rc != GRLX_OK) return rc;
+  if (!ctx->trace_state)
+  { // the predictor's trace between calls, in the layout the actor-critic kernels persist theirs in: empty
+    const size_t words = N * 16 * kMaxTrace * 2;
+    if (hipMalloc((void **)&ctx->trace_state, words * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); ctx->trace_state = nullptr; return fail(GRLX_ERR_OOM, "no device memory for the agents' traces"); }
+    std::vector<uint32_t> init(words, 0u);
+    for (size_t i = 0; i < words; i += 2) init[i] = kInvalidPos;
+    HIP_TRY(hipMemcpy(ctx->trace_state, init.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->P.trace_state = ctx->trace_state;
+  }
+  if (hipMalloc((void **)&ctx->agent_lane, sizeof(uint32_t) * N * 16 * 2) != hipSuccess) { (void)hipGetLastError(); ctx->agent_lane = nullptr; return fail(GRLX_ERR_OOM, "no device memory for the agents' state"); }
+  HIP_TRY(hipMemset(ctx->agent_lane, 0, sizeof(uint32_t) * N * 16 * 2));
+  if (hipMalloc((void **)&ctx->agent_rep, sizeof(AgentRep) * N) != hipSuccess) { (void)hipGetLastError(); ctx->agent_rep = nullptr; return fail(GRLX_ERR_OOM, "no device memory for the agents' state"); }
+  HIP_TRY(hipMemset(ctx->agent_rep, 0, sizeof(AgentRep) * N));
+  ctx->P.agent_rep = ctx->agent_rep;
+  ctx->P.agent_lane = ctx->agent_lane;
+  return GRLX_OK;
+}
+
+static int agent_call(grlx_ctx *ctx, int mode, int test, const int32_t *active, double tau, const double *obs, const double *reward,
+                      const int32_t *terminal, double *action)
+{
+  if (!ctx || !obs || (mode != STEP_START && !reward) || (mode != STEP_END && !action)) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (mode != STEP_START && tau != 1.) return fail(GRLX_ERR_INVALID, "Agent::step / end: tau must be 1 (environment/modeled:discrete_time = 1)");
+  DRAIN(ctx);
+  int rc = agent_ready(ctx);
+  if (rc != GRLX_OK) return rc;
+  // the tables these calls fill grow like the fused path's: looked at every 64 calls, between two calls
+  if ((ctx->step_calls++ & 63u) == 63u && ctx->P.logC < ctx->logC_max)
+  {
+    uint32_t used = 0;
+    HIP_TRY(launch_max_load(ctx->P, ctx->n_tables, ctx->max_load, nullptr));
+    HIP_TRY(hipMemcpy(&used, ctx->max_load, sizeof(used), hipMemcpyDeviceToHost));
+    if ((uint64_t)used * 4u > (1ull << ctx->P.logC))
+    {
+      uint32_t want = ctx->P.logC;
+      while ((uint64_t)used * 8u > (1ull << want) && want < ctx->logC_max) ++want;
+      rc = grow_tables(ctx, want);
+      if (rc == GRLX_ERR_OOM) { g_err.clear(); ctx->logC_max = ctx->P.logC; }
+      else if (rc != GRLX_OK) return rc;
+    }
+  }
+  const size_t N = (size_t)ctx->P.n_replicas;
+  const size_t D = (size_t)(ctx->cfg.agent == GRLX_AGENT_AC ? ctx->P.tile.D : ctx->P.tile.D - 1);
+  double *d_obs = ctx->stage_f64, *d_reward = d_obs + N * GRLX_MAX_DIMS, *d_action = d_reward + N;
+  int32_t *d_term = ctx->stage_i32 + N;
+  StepArgs A;
+  A.mode = mode;
+  A.test = test ? 1 : 0;
+  hipError_t e;
+  A.active = stage_active(ctx, active, &e);
+  HIP_TRY(e);
+  HIP_TRY(hipMemcpy(d_obs, obs, sizeof(double) * N * D, hipMemcpyHostToDevice));
+  A.obs = d_obs;
+  A.reward = d_reward;
+  if (mode != STEP_START) HIP_TRY(hipMemcpy(d_reward, reward, sizeof(double) * N, hipMemcpyHostToDevice));
+  A.terminal = nullptr;
+  if (mode == STEP_STEP && terminal)
+  {
+    HIP_TRY(hipMemcpy(d_term, terminal, sizeof(int32_t) * N, hipMemcpyHostToDevice));
+    A.terminal = d_term;
+  }
+  A.action = d_action;
+  if (mode != STEP_END) HIP_TRY(hipMemcpy(d_action, action, sizeof(double) * N, hipMemcpyHostToDevice));    // rows that do not act keep the caller's values
+  HIP_TRY(launch_agent_step(ctx->P, A, nullptr));
+  if (mode != STEP_END) HIP_TRY(hipMemcpy(action, d_action, sizeof(double) * N, hipMemcpyDeviceToHost));
+  else HIP_TRY(hipDeviceSynchronize());
+  return GRLX_OK;
+}
+
+int grlx_agent_start(grlx_ctx *ctx, int test, const int32_t *active, const double *obs, double *action)
+{
+  return agent_call(ctx, STEP_START, test, active, 0., obs, nullptr, nullptr, action);
+}
+
+int grlx_agent_step(grlx_ctx *ctx, int test, const int32_t *active, double tau, const double *obs, const double *reward, const int32_t *terminal, double *action)
+{
+  return agent_call(ctx, STEP_STEP, test, active, tau, obs, reward, terminal, action);
+}
+
+int grlx_agent_end(grlx_ctx *ctx, int test, const int32_t *active, double tau, const double *obs, const double *reward)
+{
+  return agent_call(ctx, STEP_END, test, active, tau, obs, reward, nullptr, nullptr);
 }
 
 int grlx_project(const grlx_tile_spec *spec, const double *in, int n, uint32_t *out)

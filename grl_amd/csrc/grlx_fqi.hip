@@ -602,6 +602,7 @@ struct grlx_fqi_ctx {
   uint64_t *r0 = nullptr;
   int batches_run = 0;
   int replicas_per_launch = 1;       // how many replicas' blocks (16 each) are resident at once
+  bool plain_launch = false;         // diagnostic: GRLX_FQI_NO_COOP=1 launches the epochs kernel without hipLaunchCooperativeKernel
 };
 
 namespace {
@@ -755,6 +756,7 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
     }
     ctx->replicas_per_launch = (cus * per_cu) / kFqiBlocksPerReplica;
   }
+  if (const char *nc = getenv("GRLX_FQI_NO_COOP")) ctx->plain_launch = nc[0] && nc[0] != '0';
   if (const char *st = getenv("GRLX_FQI_STAMPS"))
     if (st[0] && st[0] != '0' && (rc = dev_alloc(ctx, &F.stamps, R * 16 * 4 * 8)) != GRLX_OK)
     {
@@ -801,7 +803,10 @@ int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
       FqiParams Fa = F;
       int r_first = r0, epochs = ctx->cfg.epochs;
       void *args[] = {&Fa, &r_first, &epochs};
-      FQI_TRY(hipLaunchCooperativeKernel((const void *)fqi_epochs_kernel<20>, dim3(nr * kFqiBlocksPerReplica), dim3(256), args, 0, stream));
+      if (ctx->plain_launch)      // diagnostic (GRLX_FQI_NO_COOP=1): the same grid without the runtime's residency check
+        hipLaunchKernelGGL(fqi_epochs_kernel<20>, dim3(nr * kFqiBlocksPerReplica), dim3(256), 0, stream, Fa, r_first, epochs);
+      else
+        FQI_TRY(hipLaunchCooperativeKernel((const void *)fqi_epochs_kernel<20>, dim3(nr * kFqiBlocksPerReplica), dim3(256), args, 0, stream));
     }
   }
   hipLaunchKernelGGL(fqi_test_kernel<20>, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);

@@ -59,6 +59,15 @@ struct __attribute__((aligned(16))) ReplicaState {
   uint32_t pad1;
 };
 
+// Per-replica state of the per-step agent entry points (grlx_step.h) between two calls: TDAgent::time_ (td.h) and the
+// previous action.  The rest of an agent's state is where the fused kernels keep it (ReplicaState, trace_state).
+struct __attribute__((aligned(16))) AgentRep {
+  double  time;
+  double  action;
+  int32_t action_index;
+  int32_t pad;
+};
+
 struct TileParams {
   int32_t  T, D, memory;
   double   scaling[GRLX_MAX_DIMS];
@@ -130,6 +139,9 @@ struct DevParams {
   int32_t  replicas_per_wave;   // 4 (one sub-batch) or 8 (two): chosen at create from the replica count and the SIMD count
   int32_t  wave_limit;          // wide actor-critic kernel: waves launched at most (> 0); further replicas come from `queue`
   uint32_t *queue;              // next unstarted replica (set by the launcher before every launch)
+  // per-step agent entry points (grlx_step.h): created at the first grlx_agent_* call of a context
+  AgentRep *agent_rep;          // [replica]
+  uint32_t *agent_lane;         // [replica][16 lanes][2]: reference slots of project(prev_obs, prev_action) / critic's and actor's project(prev_obs)
 };
 
 // ---------------------------------------------------------------------------
@@ -147,6 +159,23 @@ hipError_t launch_rollout_tgt(const DevParams &P, int n_trials, hipStream_t stre
 // pattern instead of with whatever the previous wave left (GRLX_POISON_REGISTERS)
 hipError_t launch_poison_registers(uint32_t pattern, hipStream_t stream);
 hipError_t launch_get_target_weights(const DevParams &P, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
+// per-step plug-in interfaces (grlx_step.h); the pointers of StepArgs are device pointers
+enum : int { STEP_START = 0, STEP_STEP = 1, STEP_END = 2 };
+
+struct StepArgs {
+  int32_t        mode;        // STEP_*
+  int32_t        test;        // 0: the learning agent (agent/td) / a learning trial's start state; 1: the test agent (agent/fixed) / a test start
+  const int32_t *active;      // [n_replicas] or null: only replicas with a non-zero entry take part in the call
+  const double  *obs;         // [n_replicas][D]   agent calls: the observation handed to the agent
+  const double  *reward;      // [n_replicas]      agent step / end
+  const int32_t *terminal;    // [n_replicas] or null; agent step: a replica whose entry is 2 gets Agent::end instead (td.cpp:76-81)
+  double        *action;      // [n_replicas]      agent start / step: the action taken (untouched for replicas that ended or are inactive)
+};
+
+hipError_t launch_agent_step(const DevParams &P, const StepArgs &A, hipStream_t stream);
+hipError_t launch_env_start(const DevParams &P, int test, const int32_t *active_dev, double *obs_dev, hipStream_t stream);
+hipError_t launch_env_advance(const DevParams &P, const int32_t *active_dev, const double *action_dev, double *obs_dev, double *reward_dev,
+                              int32_t *terminal_dev, hipStream_t stream);
 hipError_t launch_project(const TileParams &tp, const double *in_dev, int n, uint32_t *out_dev, hipStream_t stream);
 hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *action_dev, int n,
                            double *obs_dev, double *reward_dev, int32_t *terminal_dev, uint32_t *err_dev, hipStream_t stream);

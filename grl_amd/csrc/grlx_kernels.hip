@@ -48,6 +48,7 @@ namespace grlx {
 #include "grlx_rollout_qv.h"
 #include "grlx_rollout_acc.h"
 #include "grlx_rollout_tgt.h"
+#include "grlx_step.h"
 
 namespace grlx {
 

@@ -729,6 +729,120 @@ void orc_destroy(orc_exp *e)
   free(e);
 }
 
+/* ------------------------------------------------- per-step interfaces -- */
+/* The experiment's environment and agents behind the reference's own plug-in interfaces, one call per call of
+ * OnlineLearningExperiment::run (online_learning.cpp:172-213): orc_run below is written on top of them, so the golden
+ * files pin these entry points too.  They are what the product's per-step C ABI (grlx_env_start / grlx_env_advance /
+ * grlx_agent_start / _step / _end) is checked against, with one half of the loop on the host and the other on the GPU. */
+void orc_exp_env_start(orc_exp *e, int test, double *obs)
+{ /* Environment::start (environment.h:48) -> ModeledEnvironment::start, modeled.cpp:132-158 */
+  orc_env_start(&e->spec, e, test, e->state);
+  orc_env_observe(&e->spec, e->state, obs);
+}
+
+double orc_exp_env_step(orc_exp *e, double action, double *obs, double *reward, int *terminal)
+{ /* Environment::step (environment.h:49-51) -> ModeledEnvironment::step, modeled.cpp:160-213 */
+  return orc_env_step(&e->spec, e->state, action, obs, reward, terminal);
+}
+
+static void remember_action(orc_exp *e, const act_t *act)
+{
+  e->last_index = act->index;
+  e->last_value = act->value;
+  memcpy(e->last_q, act->q, sizeof(act->q));
+}
+
+double orc_exp_agent_start(orc_exp *e, int test, const double *obs)
+{ /* Agent::start (agent.h:44-47) */
+  const orc_spec *s = &e->spec;
+  const int D = orc_env_obs_dims(s->env);
+  act_t act;
+  memset(&act, 0, sizeof(act));
+  if (test)
+  { /* fixed.cpp:47-51 */
+    e->test_time = 0.;
+    policy_act(e, 1, e->test_time, obs, &act);
+  }
+  else if (s->agent == ORC_AGENT_PID)
+  { /* the learning agent is an agent/fixed too (`test_agent: ../agent`): fixed.cpp:47-51 */
+    e->time = 0;
+    policy_act(e, 0, e->time, obs, &act);
+  }
+  else
+  { /* td.cpp:50-61 */
+    if (s->agent != ORC_AGENT_AC)                            /* predictor_->finalize(), sarsa.cpp:126-132;          */
+      trace_clear(&e->trace);                                /* ActionACPredictor::finalize (ac.cpp:170-173) does   */
+                                                             /* NOT reach the critic: its trace survives episodes   */
+    e->time = 0;
+    policy_act(e, 0, e->time, obs, &act);
+    memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
+    e->prev_action = act.value;
+    e->prev_action_index = act.index;
+  }
+  remember_action(e, &act);
+  return act.value;
+}
+
+static double predictor_update(orc_exp *e, double tau, double reward, const double *obs, int has_action, double action)
+{ /* predictor_->update(Transition(prev_obs, prev_action, tau, reward, obs, action)), td.cpp:70 / :79 */
+  const orc_spec *s = &e->spec;
+  orc_proj *p = &e->last_p, *ap = &e->last_ap;
+  if (s->agent == ORC_AGENT_SARSA)
+    return sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, has_action, action, p);
+  if (s->agent == ORC_AGENT_Q)
+    return q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, has_action, action, p);
+  if (s->agent == ORC_AGENT_EXPECTED_SARSA)
+    return expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, has_action, p);
+  if (s->agent == ORC_AGENT_ADVANTAGE)
+    return advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, has_action, p);
+  if (s->agent == ORC_AGENT_QV)
+    return qv_update(e, e->prev_obs, e->prev_action, tau, reward, obs, has_action, p, ap);
+  return ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, has_action, p, ap);
+}
+
+double orc_exp_agent_step(orc_exp *e, int test, double tau, const double *obs, double reward)
+{ /* Agent::step (agent.h:49-52) */
+  const orc_spec *s = &e->spec;
+  const int D = orc_env_obs_dims(s->env);
+  act_t act;
+  memset(&act, 0, sizeof(act));
+  e->last_delta = 0;
+  e->last_p.n = 0;
+  e->last_ap.n = 0;
+  if (test)
+  { /* fixed.cpp:53-61 */
+    e->test_time += tau;
+    policy_act(e, 1, e->test_time, obs, &act);
+  }
+  else if (s->agent == ORC_AGENT_PID)
+  { /* fixed.cpp:53-61 as the learning agent */
+    e->time += tau;
+    policy_act(e, 0, e->time, obs, &act);
+  }
+  else
+  { /* td.cpp:63-74: act first, then update */
+    e->time += tau;
+    policy_act(e, 0, e->time, obs, &act);
+    e->stats.trace_entries_sum += (uint64_t)e->trace.len;
+    e->last_delta = predictor_update(e, tau, reward, obs, 1, act.value);
+    memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
+    e->prev_action = act.value;
+    e->prev_action_index = act.index;
+  }
+  remember_action(e, &act);
+  return act.value;
+}
+
+void orc_exp_agent_end(orc_exp *e, int test, double tau, const double *obs, double reward)
+{ /* Agent::end (agent.h:54-56): the transition into an absorbing state.  agent/fixed does nothing (fixed.cpp:63-65);
+   * agent/td updates with an empty next action (td.cpp:76-81) */
+  e->last_delta = 0;
+  e->last_p.n = 0;
+  e->last_ap.n = 0;
+  if (test || e->spec.agent == ORC_AGENT_PID) return;
+  e->last_delta = predictor_update(e, tau, reward, obs, 0, 0);
+}
+
 /* ------------------------------------------------------------------ run -- */
 int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             orc_tap *tap, int tap_cap, int *tap_n)
@@ -743,120 +857,42 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
     int test = (ti >= 0 && e->tt % (ti + 1) == ti);           /* :160 */
     double obs[ORC_MAX_DIMS], reward, total_reward = 0, total_time = 0;
     int terminal;
-    act_t act;
     const int subtrials = (test && s->test_trials > 1) ? s->test_trials : 1;     /* :161 */
 
     for (int st = 0; st < subtrials; ++st)
     { /* :170-222: every sub-trial starts the environment and the agent; reward and time keep adding up */
-    /* environment_->start, modeled.cpp:132-158 */
-    orc_env_start(s, e, test, e->state);
-    orc_env_observe(s, e->state, obs);
-
-    /* agent->start */
-    if (test)
-    { /* fixed.cpp:47-51 */
-      e->test_time = 0.;
-      policy_act(e, 1, e->test_time, obs, &act);
-    }
-    else if (s->agent == ORC_AGENT_PID)
-    { /* the learning agent is an agent/fixed too (`test_agent: ../agent`): fixed.cpp:47-51 */
-      e->time = 0;
-      policy_act(e, 0, e->time, obs, &act);
-    }
-    else
-    { /* td.cpp:50-61 */
-      if (s->agent != ORC_AGENT_AC)                            /* predictor_->finalize(), sarsa.cpp:126-132;          */
-        trace_clear(&e->trace);                                /* ActionACPredictor::finalize (ac.cpp:170-173) does   */
-                                                               /* NOT reach the critic: its trace survives episodes   */
-      e->time = 0;
-      policy_act(e, 0, e->time, obs, &act);
-      memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
-      e->prev_action = act.value;
-      e->prev_action_index = act.index;
-    }
+    orc_exp_env_start(e, test, obs);                            /* :172 */
+    double action = orc_exp_agent_start(e, test, obs);          /* :178 */
 
     if (s->tap_starts && tap && ntap < tap_cap)
     { /* the row the transition log gets at the start of a trial (online_learning.cpp:183-184) */
       orc_tap *tp = &tap[ntap++];
       memset(tp, 0, sizeof(*tp));
       tp->test = test;
-      tp->action_index = act.index;
+      tp->action_index = e->last_index;
       memcpy(tp->obs, obs, sizeof(double) * (size_t)D);
-      tp->action = act.value;
+      tp->action = action;
       tp->terminal = -1;
       tp->trace_len = e->trace.len;
       memcpy(tp->state, e->state, sizeof(double) * (size_t)orc_env_state_dims(s->env));
-      for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = act.q[a];
+      for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = e->last_q[a];
     }
 
     do
     {
-      double tau = orc_env_step(s, e->state, act.value, obs, &reward, &terminal);   /* :196 */
+      double tau = orc_exp_env_step(e, action, obs, &reward, &terminal);           /* :196 */
       total_reward += reward;                                                      /* :202 */
       total_time += tau;                                                           /* :203 */
-      double delta = 0;
-      orc_proj p, ap;
-      p.n = 0;
-      ap.n = 0;
 
+      if (terminal == 2)
+        orc_exp_agent_end(e, test, tau, obs, reward);                              /* :210-211 */
+      else
+        action = orc_exp_agent_step(e, test, tau, obs, reward);                    /* :212-213 */
       if (test)
-      { /* fixed.cpp:53-61 */
-        if (terminal != 2)
-        {
-          e->test_time += tau;
-          policy_act(e, 1, e->test_time, obs, &act);
-        }
         e->stats.test_steps++;
-      }
-      else if (s->agent == ORC_AGENT_PID)
-      { /* fixed.cpp:53-61 as the learning agent; learning steps are still counted (online_learning.cpp:219) */
-        if (terminal != 2)
-        {
-          e->time += tau;
-          policy_act(e, 0, e->time, obs, &act);
-        }
-        e->ss++;
-        e->stats.learn_steps++;
-      }
       else
       {
-        if (terminal == 2)
-        { /* td.cpp:76-81: update with an empty next action */
-          if (s->agent == ORC_AGENT_SARSA)
-            delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
-          else if (s->agent == ORC_AGENT_Q)
-            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, 0, &p);
-          else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
-            delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
-          else if (s->agent == ORC_AGENT_ADVANTAGE)
-            delta = advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p);
-          else if (s->agent == ORC_AGENT_QV)
-            delta = qv_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
-          else
-            delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 0, &p, &ap);
-        }
-        else
-        { /* td.cpp:63-74: act first, then update */
-          e->time += tau;
-          policy_act(e, 0, e->time, obs, &act);
-          e->stats.trace_entries_sum += (uint64_t)e->trace.len;
-          if (s->agent == ORC_AGENT_SARSA)
-            delta = sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
-          else if (s->agent == ORC_AGENT_Q)
-            delta = q_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, act.value, &p);
-          else if (s->agent == ORC_AGENT_EXPECTED_SARSA)
-            delta = expected_sarsa_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
-          else if (s->agent == ORC_AGENT_ADVANTAGE)
-            delta = advantage_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p);
-          else if (s->agent == ORC_AGENT_QV)
-            delta = qv_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
-          else
-            delta = ac_update(e, e->prev_obs, e->prev_action, tau, reward, obs, 1, &p, &ap);
-          memcpy(e->prev_obs, obs, sizeof(double) * (size_t)D);
-          e->prev_action = act.value;
-          e->prev_action_index = act.index;
-        }
-        e->ss++;                                                /* :218 */
+        e->ss++;                                                                   /* :218 */
         e->stats.learn_steps++;
       }
 
@@ -865,17 +901,17 @@ int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
         orc_tap *tp = &tap[ntap++];
         memset(tp, 0, sizeof(*tp));
         tp->test = test;
-        tp->action_index = act.index;
+        tp->action_index = e->last_index;
         memcpy(tp->obs, obs, sizeof(double) * (size_t)D);
-        tp->action = act.value;
+        tp->action = e->last_value;
         tp->reward = reward;
         tp->terminal = terminal;
         tp->trace_len = e->trace.len;
         memcpy(tp->state, e->state, sizeof(double) * (size_t)orc_env_state_dims(s->env));
-        for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = act.q[a];
-        tp->delta = delta;
-        for (int j = 0; j < p.n && j < 16; ++j) tp->p_idx[j] = (uint32_t)p.idx[j];
-        for (int j = 0; j < ap.n && j < 16; ++j) tp->p_idx[16 + j] = (uint32_t)ap.idx[j];   /* actor projection (AC) */
+        for (int a = 0; a < (s->agent == ORC_AGENT_AC ? 1 : e->A) && a < 8; ++a) tp->q[a] = e->last_q[a];
+        tp->delta = e->last_delta;
+        for (int j = 0; j < e->last_p.n && j < 16; ++j) tp->p_idx[j] = (uint32_t)e->last_p.idx[j];
+        for (int j = 0; j < e->last_ap.n && j < 16; ++j) tp->p_idx[16 + j] = (uint32_t)e->last_ap.idx[j];   /* actor projection (AC) */
       }
     } while (!terminal);
     } /* sub-trials */
@@ -912,6 +948,7 @@ int orc_set_weights(orc_exp *e, int table, const double *w, size_t n)
   memcpy(e->w[table], w, n * sizeof(double));
   return 0;
 }
+void orc_set_state(orc_exp *e, const double *state) { memcpy(e->state, state, sizeof(double) * (size_t)orc_env_state_dims(e->spec.env)); }
 void orc_get_state(const orc_exp *e, double *state) { memcpy(state, e->state, sizeof(double) * (size_t)orc_env_state_dims(e->spec.env)); }
 void orc_rng_states(const orc_exp *e, uint64_t out[4]) { out[0] = e->G.x; out[1] = e->TL.x; out[2] = e->S1.x; out[3] = e->S2.x; }
 

@@ -210,6 +210,21 @@ void     orc_destroy(orc_exp *e);
 int orc_run(orc_exp *e, int n_trials, orc_row *rows, int max_rows,
             orc_tap *tap, int tap_cap, int *tap_n);
 
+/* The same experiment behind the reference's per-step plug-in interfaces, one call per call of OnlineLearningExperiment::run
+ * (online_learning.cpp:172-213); orc_run is written on top of them, so the golden files pin them.  The caller owns the loop:
+ * trial / step counters, rows and the steps budget are NOT advanced by these calls.
+ *   Environment::start / step (environment.h:48-51 -> ModeledEnvironment, modeled.cpp:132-213) on the experiment's own model state
+ *   and random streams; step returns tau.
+ *   Agent::start / step / end (agent.h:44-56): test = 0 the learning agent (agent/td, td.cpp:50-81), test = 1 the test agent
+ *   (agent/fixed, fixed.cpp:47-65).  start and step return the action taken. */
+void   orc_exp_env_start(orc_exp *e, int test, double *obs);
+double orc_exp_env_step(orc_exp *e, double action, double *obs, double *reward, int *terminal);
+double orc_exp_agent_start(orc_exp *e, int test, const double *obs);
+double orc_exp_agent_step(orc_exp *e, int test, double tau, const double *obs, double reward);
+void   orc_exp_agent_end(orc_exp *e, int test, double tau, const double *obs, double reward);
+/* overwrite the model state (tests that run the environment elsewhere and only want the oracle's final state to compare) */
+void   orc_set_state(orc_exp *e, const double *state);
+
 /* Experiment::reset() between two runs of one process (online_learning.cpp:307-308): parameters re-drawn from the continuing
  * thread-local stream, traces cleared, exploration decay back to 1, the run's counters restart; the streams are NOT reseeded.
  * 0, or -1 for graphs whose reset is not restated (target network, safe >= 1, the PID agent). */

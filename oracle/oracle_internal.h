@@ -47,6 +47,12 @@ struct orc_exp {
   int64_t    tt, ss;                    /* trial counter, learning steps */
   uint64_t   steps_budget;              /* experiment/online_learning:steps (online_learning.cpp:154); 0 = none */
   orc_stats  stats;
+  /* what the last orc_exp_agent_* call did (taps of orc_run; inspection by the per-step tests) */
+  int        last_index;                /* discrete action index chosen (Q agents) */
+  double     last_value;                /* action value returned */
+  double     last_q[ORC_MAX_ACTIONS];   /* Q(s', .) as the policy saw it (actor-critic: the actor's output in [0]) */
+  double     last_delta;                /* TD error of the update */
+  orc_proj   last_p, last_ap;           /* projections written by the update: project(prev_obs, prev_action); actor's (AC) / V's (QV) */
 };
 
 double orc_m_sin(const orc_spec *s, double x);

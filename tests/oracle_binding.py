@@ -110,6 +110,12 @@ def load():
     L.orc_set_weights.argtypes = [C.c_void_p, C.c_int, P(C.c_double), C.c_size_t]; L.orc_set_weights.restype = C.c_int
     L.orc_target_syncs.argtypes = [C.c_void_p]; L.orc_target_syncs.restype = C.c_int64
     L.orc_get_state.argtypes = [C.c_void_p, P(C.c_double)]
+    L.orc_set_state.argtypes = [C.c_void_p, P(C.c_double)]; L.orc_set_state.restype = None
+    L.orc_exp_env_start.argtypes = [C.c_void_p, C.c_int, P(C.c_double)]; L.orc_exp_env_start.restype = None
+    L.orc_exp_env_step.argtypes = [C.c_void_p, C.c_double, P(C.c_double), P(C.c_double), P(C.c_int)]; L.orc_exp_env_step.restype = C.c_double
+    L.orc_exp_agent_start.argtypes = [C.c_void_p, C.c_int, P(C.c_double)]; L.orc_exp_agent_start.restype = C.c_double
+    L.orc_exp_agent_step.argtypes = [C.c_void_p, C.c_int, C.c_double, P(C.c_double), C.c_double]; L.orc_exp_agent_step.restype = C.c_double
+    L.orc_exp_agent_end.argtypes = [C.c_void_p, C.c_int, C.c_double, P(C.c_double), C.c_double]; L.orc_exp_agent_end.restype = None
     L.orc_rng_states.argtypes = [C.c_void_p, P(C.c_uint64)]
     L.orc_format_row.argtypes = [P(Row), C.c_char_p, C.c_size_t]; L.orc_format_row.restype = C.c_int
     L.orc_lazy_weight.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double]
@@ -219,6 +225,43 @@ class Experiment:
         out = (C.c_uint64 * 4)()
         self.L.orc_rng_states(self.h, out)
         return np.array(out[:], dtype=np.uint64)
+
+    # ---- the per-step plug-in interfaces (orc_run is written on top of them) ----
+    def env_start(self, test: int):
+        """Environment::start (environment.h:48): first observation of a trial."""
+        obs = (C.c_double * MAX_DIMS)()
+        self.L.orc_exp_env_start(self.h, int(test), obs)
+        return np.array(obs[: self.L.orc_env_obs_dims(self.spec.env)])
+
+    def env_step(self, action: float):
+        """Environment::step (environment.h:49-51): (tau, obs, reward, terminal)."""
+        obs = (C.c_double * MAX_DIMS)(); rw = C.c_double(); tm = C.c_int()
+        tau = self.L.orc_exp_env_step(self.h, float(action), obs, C.byref(rw), C.byref(tm))
+        return tau, np.array(obs[: self.L.orc_env_obs_dims(self.spec.env)]), rw.value, tm.value
+
+    def _obs(self, obs):
+        buf = (C.c_double * MAX_DIMS)()
+        for i, v in enumerate(obs):
+            buf[i] = float(v)
+        return buf
+
+    def agent_start(self, test: int, obs) -> float:
+        """Agent::start (agent.h:44-47): the first action of a trial."""
+        return self.L.orc_exp_agent_start(self.h, int(test), self._obs(obs))
+
+    def agent_step(self, test: int, tau: float, obs, reward: float) -> float:
+        """Agent::step (agent.h:49-52): act, then learn from the transition."""
+        return self.L.orc_exp_agent_step(self.h, int(test), float(tau), self._obs(obs), float(reward))
+
+    def agent_end(self, test: int, tau: float, obs, reward: float):
+        """Agent::end (agent.h:54-56): the transition into an absorbing state."""
+        self.L.orc_exp_agent_end(self.h, int(test), float(tau), self._obs(obs), float(reward))
+
+    def set_state(self, state):
+        buf = (C.c_double * MAX_STATE)()
+        for i, v in enumerate(state):
+            buf[i] = float(v)
+        self.L.orc_set_state(self.h, buf)
 
 
 SUM_SEQUENTIAL, SUM_TREE = 0, 1
