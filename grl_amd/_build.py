@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgrlx.so")
 SOURCES = ["grlx_kernels.hip", "grlx_fqi.hip", "grlx_api.cpp"]
 HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", "grlx_policy.h", "grlx_update.h",
-           "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h",
+           "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h", "grlx_env_server.h", "grlx_step.h",
            os.path.join("..", "..", "include", "grlx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 TAG_DEFINE = "-DGRLX_BUILD_PIPELINE="
@@ -84,6 +84,8 @@ def _build_hip_object(hipcc, src, tmp, flags, verbose, report):
         raise RuntimeError(f"{src}: hipcc failed only with -print-after=stack-slot-coloring")
     with open(stem + ".mir", errors="replace") as f:
         found, problems = _exec_prologue.find_misplaced(f)
+    if os.environ.get("GRLX_KEEP_MIR"):          # diagnostic: keep the machine code the filter read (hundreds of MB)
+        shutil.copy(stem + ".mir", os.path.join(os.environ["GRLX_KEEP_MIR"], os.path.basename(stem) + ".mir"))
     os.remove(stem + ".mir")
     with open(stem + ".s") as f:
         fixed, n_fixed, p2 = _exec_prologue.apply(f.read().split("\n"), found)
@@ -101,12 +103,33 @@ def _build_hip_object(hipcc, src, tmp, flags, verbose, report):
     return stem + ".host.o"
 
 
+# what each translation unit includes (besides itself): an object whose inputs did not change is taken from the object cache
+# (outside the tree: $GRLX_OBJCACHE or /tmp/grlx_objcache), so that editing grlx_api.cpp does not recompile the kernels
+UNIT_DEPS = {
+    "grlx_kernels.hip": [h for h in HEADERS],
+    "grlx_fqi.hip": ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", os.path.join("..", "..", "include", "grlx.h")],
+    "grlx_api.cpp": ["grlx_internal.h", os.path.join("..", "..", "include", "grlx.h")],
+}
+
+
+def _unit_key(name: str, flags) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    h.update((" ".join(flags) + "|" + PIPELINE + "|" + " ".join(SOURCE_FLAGS.get(name, []))).encode())
+    for f in [name] + UNIT_DEPS[name] + [os.path.abspath(__file__), os.path.join(HERE, "_exec_prologue.py")]:
+        with open(f if os.path.isabs(f) else os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:24]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libgrlx.so if missing or older than its sources; return its path."""
     if not force and not _stale():
         return LIB
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
+    cache = os.environ.get("GRLX_OBJCACHE", "/tmp/grlx_objcache")
+    os.makedirs(cache, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the HIP extension")
@@ -116,11 +139,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with tempfile.TemporaryDirectory(prefix="grlx_build_") as tmp:
         def one(name):
             src = os.path.join(CSRC, name)
+            key = os.path.join(cache, name + "." + _unit_key(name, flags))
+            if not force and os.path.exists(key + ".o") and (not name.endswith(".hip") or os.path.exists(key + ".report")):
+                if name.endswith(".hip"):
+                    with open(key + ".report") as f:
+                        report[name] = tuple(int(x) for x in f.read().split())
+                return key + ".o"
             if name.endswith(".hip"):
-                return _build_hip_object(hipcc, src, tmp, flags, verbose, report)
-            obj = os.path.join(tmp, os.path.splitext(name)[0] + ".o")
-            _run([hipcc] + flags + [TAG_DEFINE + '"' + PIPELINE + '"', "-c", src, "-o", obj], verbose)
-            return obj
+                obj = _build_hip_object(hipcc, src, tmp, flags, verbose, report)
+                with open(key + ".report", "w") as f:
+                    f.write("%d %d" % report[name])
+            else:
+                obj = os.path.join(tmp, os.path.splitext(name)[0] + ".o")
+                _run([hipcc] + flags + [TAG_DEFINE + '"' + PIPELINE + '"', "-c", src, "-o", obj], verbose)
+            shutil.copy(obj, key + ".o")
+            return key + ".o"
         with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
             objs = list(pool.map(one, SOURCES))
         _run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs, verbose)

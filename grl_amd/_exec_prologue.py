@@ -43,6 +43,10 @@ _BB = re.compile(r"^bb\.(\d+)[^:]*:")
 _SLOT = re.compile(r"^\d+B\t")
 _PHYS = re.compile(r"\$(vgpr|agpr|sgpr)(\d+)((?:_(?:vgpr|agpr|sgpr)\d+)*)")
 _WIDEN = re.compile(r"^\$exec = S_OR_B64(_term)? .*\$exec|= S_OR_SAVEEXEC_B64 ")
+# other ways of writing exec whose effect on the mask the text does not tell: a block that begins with one of them behind
+# mask-dependent instructions is refused (fail closed), unless the value is visibly a NARROWED copy of the current mask
+_MAY_WIDEN = re.compile(r"^\$exec = (S_MOV_B64|S_XOR_B64|S_XNOR_B64|S_OR_B64|S_ORN2_B64|S_NOT_B64|S_CSELECT_B64)(_term)? ")
+_MASK_REG = r"\$(sgpr\d+_sgpr\d+|vcc|exec)\b"
 _FIXABLE_RESTORE = re.compile(r"^\$exec = S_OR_B64 (?:killed )?\$exec, (?:killed )?(?:renamable )?\$(sgpr\d+_sgpr\d+|vcc)\b")
 
 
@@ -89,6 +93,31 @@ def _mir_classify(t):
     return "x"
 
 
+def _narrowing_mov(first, head):
+    """`$exec = S_MOV_B64[_term] X` where X was computed in this block as (current mask) AND something: the lowering of an
+    `if`, which can only take lanes away."""
+    m = re.match(r"^\$exec = S_MOV_B64(?:_term)? (?:killed )?(?:renamable )?" + _MASK_REG, first)
+    if not m:
+        return False
+    src = m.group(1)
+    masks = {"exec"}                                    # registers that hold a copy of the current mask
+    for t in head:
+        c = re.match(r"^(?:dead )?(?:renamable )?" + _MASK_REG + r" = COPY (?:killed )?\$exec\b", t)
+        if c:
+            masks.add(c.group(1))
+    for t in reversed(head):
+        d = re.match(r"^(?:dead )?(?:renamable )?" + _MASK_REG + r" = ([A-Z0-9_a-z]+) (.*)$", t)
+        if not d or d.group(1) != src:
+            continue
+        ops = re.findall(_MASK_REG, d.group(3))
+        if d.group(2) == "S_AND_B64":
+            return any(o in masks for o in ops[:2])
+        if d.group(2) == "S_ANDN2_B64":
+            return bool(ops) and ops[0] in masks
+        return False
+    return False
+
+
 def find_misplaced(lines):
     """Parse `-print-after=stack-slot-coloring` output (an iterable of lines).  Returns (found, problems):
     found = [dict(function, bb, restore_mask, vec_dst, head)] for the block heads apply() has to rewrite."""
@@ -127,9 +156,14 @@ def find_misplaced(lines):
                     first = t
                     break
                 head.append(t)
-            if first is None or not _WIDEN.search(first):
-                continue                            # the block narrows the mask first, or never writes it: ordinary code
+            if first is None:
+                continue                            # the block never writes the mask: ordinary code
             kinds = [_mir_classify(t) for t in head]
+            if not _WIDEN.search(first):
+                if _MAY_WIDEN.match(first) and not _narrowing_mov(first, head) and not all(k == "s" for k in kinds):
+                    problems.append(f"{fn} bb.{bb}: mask-dependent instructions in front of `{first.split(',')[0]}`, which may widen the mask "
+                                    "(this filter only knows S_OR_B64 $exec / S_OR_SAVEEXEC_B64 as restores and cannot tell)")
+                continue                            # the block narrows the mask first: ordinary code
             if all(k == "s" for k in kinds):
                 continue
             where = f"{fn} bb.{bb}"
@@ -160,6 +194,9 @@ EXEC_OR = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,\s*(s\[(\d+):(\d+)\]|vcc)\s*$
 VEC = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_mov_b32|v_mov_b64|v_accvgpr_read_b32|v_accvgpr_write_b32|v_accvgpr_mov_b32)\s+(\S+?),\s*(\S+)\s*$")
 LANE = re.compile(r"^\s*(v_readlane_b32|v_writelane_b32)\s+(\S+?),\s*(\S+?),\s*(\S+)\s*$")
 REG = re.compile(r"\b([vsa])\[(\d+):(\d+)\]|\b([vsa])(\d+)\b|\b(vcc_lo|vcc_hi|vcc|exec_lo|exec_hi|exec|m0|scc)\b")
+
+
+HAZARD_NOP = "\ts_nop 4"                    # inserted behind moved copies (rewrite_head)
 
 
 def regs(tok):
@@ -246,7 +283,10 @@ def rewrite_head(block_lines, want_mask=None, want_vec_dst=None, want_vec_src=No
         return None, f"copies write {sorted(vec_dst)}, the machine code says {sorted(want_vec_dst)}"
     if want_vec_src is not None and set(want_vec_src) != vec_src:
         return None, f"copies read {sorted(vec_src)}, the machine code says {sorted(want_vec_src)}"
-    new = [l for l, k, _, _ in head if k != "v"] + [block_lines[j]] + [l for l, k, _, _ in head if k == "v"] + block_lines[j + 1:]
+    # The copies now stand directly in front of the block's next instruction, behind the hazard recogniser's back: the wait states the
+    # restore and the scalar instructions of the head used to provide are gone.  `s_nop 4` (five wait states) covers every distance a
+    # VALU write of a VGPR needs on this family before a lane access / DPP read (1-2) or a matrix-core operand read of that register.
+    new = [l for l, k, _, _ in head if k != "v"] + [block_lines[j]] + [l for l, k, _, _ in head if k == "v"] + [HAZARD_NOP] + block_lines[j + 1:]
     return new, None
 
 

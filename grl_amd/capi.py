@@ -12,7 +12,7 @@ from . import _build
 MAX_DIMS, MAX_STATE, MAX_ACTIONS = 8, 12, 8
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_TABLE_FULL, ERR_DOMAIN, ERR_ROWS_FULL, ERR_OOM = 0, -1, -2, -3, -4, -5, -6, -7
-ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER, ENV_CART_POLE_BALANCING = 0, 1, 2, 3, 4
+ENV_PENDULUM, ENV_CART_POLE, ENV_ACROBOT, ENV_COMPASS_WALKER, ENV_CART_POLE_BALANCING, ENV_EXTERNAL = 0, 1, 2, 3, 4, 5
 AGENT_SARSA, AGENT_Q, AGENT_AC, AGENT_EXPECTED_SARSA, AGENT_ADVANTAGE, AGENT_QV = 0, 1, 2, 3, 4, 5
 TRACE_NONE, TRACE_REPLACING, TRACE_ACCUMULATING = 0, 1, 2
 
@@ -53,7 +53,7 @@ class FqiConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("n_replicas", C.c_int32), ("env", C.c_int32), ("integration_steps", C.c_int32),
                 ("control_step", C.c_double), ("timeout", C.c_double), ("action_min", C.c_double), ("action_max", C.c_double),
                 ("action_steps", C.c_int32), ("batch_size", C.c_int32), ("gamma", C.c_double), ("iterations", C.c_int32),
-                ("epochs", C.c_int32), ("hidden", C.c_int32), ("max_batches", C.c_int32)]
+                ("epochs", C.c_int32), ("hidden", C.c_int32), ("max_batches", C.c_int32), ("eta", C.c_double)]
 
 
 class Tap(C.Structure):
@@ -104,6 +104,11 @@ _SIGS = {
     "grlx_export_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_double)]),
     "grlx_load_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_uint64]),
     "grlx_read_taps": (C.c_int, [C.c_void_p, _P(Tap), C.c_int, _P(C.c_int)]),
+    "grlx_env_start": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), _P(C.c_double)]),
+    "grlx_env_advance": (C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),
+    "grlx_agent_start": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), _P(C.c_double), _P(C.c_double)]),
+    "grlx_agent_step": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), C.c_double, _P(C.c_double), _P(C.c_double), _P(C.c_int32), _P(C.c_double)]),
+    "grlx_agent_end": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int32), C.c_double, _P(C.c_double), _P(C.c_double)]),
     "grlx_project": (C.c_int, [_P(TileSpec), _P(C.c_double), C.c_int, _P(C.c_uint32)]),
     "grlx_env_step": (C.c_int, [_P(Config), _P(C.c_double), _P(C.c_double), C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),
     "grlx_env_dims": (C.c_int, [C.c_int, _P(C.c_int), _P(C.c_int)]),
@@ -122,6 +127,14 @@ _SIGS = {
     "grlx_fqi_get_transitions": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     "grlx_fqi_info": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64), _P(C.c_double), _P(C.c_int32), _P(C.c_double), _P(C.c_uint64)]),
 }
+
+# include/grlx_diag.h: diagnostic exports (tools, tests, bench.py), not part of the boundary
+_DIAG_SIGS = {
+    "grlx_env_server_counts": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
+    "grlx_env_server_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "grlx_fqi_debug_stamps": (C.c_int, [C.c_void_p, _P(C.c_ulonglong), C.c_int]),
+}
+ABI_VERSION = 2         # include/grlx.h: GRLX_ABI_VERSION
 
 
 def lib_path() -> str:
@@ -159,12 +172,12 @@ def load():
                           "grl_amd has no CPU fallback")
     _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
-    for name, (res, args) in _SIGS.items():
+    for name, (res, args) in list(_SIGS.items()) + list(_DIAG_SIGS.items()):
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.grlx_abi_version() != 1:
-        raise ImportError("libgrlx.so ABI version mismatch")
+    if lib.grlx_abi_version() != ABI_VERSION:
+        raise ImportError(f"libgrlx.so ABI version {lib.grlx_abi_version()}, this binding is written for {ABI_VERSION}: rebuild (python -m grl_amd._build)")
     tag = (lib.grlx_build_pipeline() or b"").decode()
     if tag != _build.PIPELINE:
         raise ImportError(f"{path} was not built by grl_amd._build (pipeline tag {tag!r}, expected {_build.PIPELINE!r}): a plain hipcc build skips the "

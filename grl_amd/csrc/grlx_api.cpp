@@ -119,7 +119,16 @@ int make_params(const grlx_config &c, DevParams *P)
   memset(P, 0, sizeof(*P));
   if (c.struct_size != sizeof(grlx_config)) return fail(GRLX_ERR_INVALID, "grlx_config.struct_size %u != %zu (ABI mismatch)", c.struct_size, sizeof(grlx_config));
   int S, D;
-  if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
+  const bool external = c.env == GRLX_ENV_EXTERNAL;        // the environment is the caller's: per-step agent entry points only
+  if (external)
+  {
+    S = 0;
+    D = (c.agent == GRLX_AGENT_AC) ? c.projector.dims : c.projector.dims - 1;
+    if (D < 1 || D >= GRLX_MAX_DIMS) return fail(GRLX_ERR_INVALID, "projector/tile_coding:resolution (an external environment's observation has %d dimensions)", D);
+    if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_EXPECTED_SARSA && c.agent != GRLX_AGENT_AC)
+      return fail(GRLX_ERR_INVALID, "an external environment is served by the per-step agent entry points: SARSA / Q / Expected SARSA or actor-critic");
+  }
+  else if (env_dims(c.env, &S, &D) != GRLX_OK) return fail(GRLX_ERR_INVALID, "environment %d is not supported by the fused path", c.env);
   if (c.agent != GRLX_AGENT_SARSA && c.agent != GRLX_AGENT_Q && c.agent != GRLX_AGENT_AC && c.agent != GRLX_AGENT_EXPECTED_SARSA &&
       c.agent != GRLX_AGENT_ADVANTAGE && c.agent != GRLX_AGENT_QV) return fail(GRLX_ERR_INVALID, "agent %d is not supported by the fused path", c.agent);
   if (c.agent == GRLX_AGENT_ADVANTAGE)
@@ -133,7 +142,9 @@ int make_params(const grlx_config &c, DevParams *P)
   if (qv && ((c.env != GRLX_ENV_PENDULUM && c.env != GRLX_ENV_ACROBOT) || c.action_steps != 3))
     return fail(GRLX_ERR_INVALID, "predictor/critic/qv is built for the pendulum and the acrobot with 3 actions");
   if (qv && !(c.beta > 0)) return fail(GRLX_ERR_INVALID, "predictor/critic/qv:beta");
-  if (ac && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
+  if (ac && !external && c.env != GRLX_ENV_CART_POLE && c.env != GRLX_ENV_PENDULUM) return fail(GRLX_ERR_INVALID, "actor-critic is built for cart-pole and pendulum");
+  if (!external)
+  {
   if (c.discrete_time != 1) return fail(GRLX_ERR_INVALID, "environment/modeled:discrete_time must be 1");
   if (!(c.control_step >= 0.00001)) return fail(GRLX_ERR_INVALID, "model/dynamical:control_step");
   if (c.integration_steps < 1 || c.integration_steps > 1000) return fail(GRLX_ERR_INVALID, "model/dynamical:integration_steps (1..1000 supported)");
@@ -148,10 +159,11 @@ int make_params(const grlx_config &c, DevParams *P)
       return fail(GRLX_ERR_INVALID, "task:timeout / control_step = %.0f steps per episode exceeds GRLX_MAX_EPISODE_STEPS (%d)",
                   std::ceil(horizon / c.control_step), GRLX_MAX_EPISODE_STEPS);
   }
+  }
   if (!ac && (c.action_steps < 1 || c.action_steps > GRLX_MAX_ACTIONS)) return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps (1..%d supported)", GRLX_MAX_ACTIONS);
   if (!ac && !qv && c.agent != GRLX_AGENT_ADVANTAGE && c.trace != GRLX_TRACE_ACCUMULATING && c.env != GRLX_ENV_CART_POLE_BALANCING)
   { // the instantiations of rollout_kernel (launch_rollout): anything else has no kernel to run
-    const bool built = (c.env == GRLX_ENV_PENDULUM && (c.action_steps == 3 || c.action_steps == 5)) ||
+    const bool built = ((c.env == GRLX_ENV_PENDULUM || external) && (c.action_steps == 3 || c.action_steps == 5)) ||
                        ((c.env == GRLX_ENV_ACROBOT || c.env == GRLX_ENV_CART_POLE || c.env == GRLX_ENV_COMPASS_WALKER) && c.action_steps == 3);
     if (!built)
       return fail(GRLX_ERR_INVALID, "discretizer/uniform:steps = %d is not built for this environment (pendulum: 3 or 5 actions; "
@@ -171,7 +183,7 @@ int make_params(const grlx_config &c, DevParams *P)
   P->agent = c.agent;
   P->trace_kind = c.trace;
   P->integration_steps = c.integration_steps;
-  P->h = c.control_step / (double)(size_t)c.integration_steps;      // modeled.cpp:257
+  P->h = external ? 0. : c.control_step / (double)(size_t)c.integration_steps;      // modeled.cpp:257
   P->timeout = c.timeout;
   P->randomization = c.randomization;
 
@@ -180,7 +192,7 @@ int make_params(const grlx_config &c, DevParams *P)
   P->initial_state_variation = c.initial_state_variation;
   P->negative_reward = c.negative_reward;
   // CSWModel::setTiming (SWModel.cpp:126-130): whole microseconds, then the sub-step of singleStep (:151)
-  P->walker_dt = 1.0E-6 * (double)(uint64_t)floor((c.control_step + 0.5E-6) * 1E6) / c.integration_steps;
+  P->walker_dt = external ? 0. : 1.0E-6 * (double)(uint64_t)floor((c.control_step + 0.5E-6) * 1E6) / c.integration_steps;
   P->end_stop_penalty = c.end_stop_penalty;
   P->action_penalty = c.action_penalty;
   P->action_min = c.action_min;
@@ -513,7 +525,8 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
     ctx->poison = pz[0] != 0;
     ctx->poison_pattern = (uint32_t)strtoul(pz, nullptr, 0);
   }
-  env_dims(cfg->env, &ctx->S, &ctx->D);
+  if (cfg->env == GRLX_ENV_EXTERNAL) { ctx->S = 0; ctx->D = (cfg->agent == GRLX_AGENT_AC) ? cfg->projector.dims : cfg->projector.dims - 1; }
+  else env_dims(cfg->env, &ctx->S, &ctx->D);
   const int N = cfg->n_replicas;
   uint32_t logC = cfg->table_log2_capacity ? (uint32_t)cfg->table_log2_capacity : 17u;
   if (logC < 8 || logC > 26) { delete ctx; return fail(GRLX_ERR_INVALID, "table_log2_capacity must be in 8..26"); }
@@ -835,6 +848,7 @@ static bool env_server_ready(grlx_ctx *ctx)
 static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *stream)
 {
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (ctx->cfg.env == GRLX_ENV_EXTERNAL) return fail(GRLX_ERR_INVALID, "this context has no environment (GRLX_ENV_EXTERNAL): drive it through grlx_agent_start / _step / _end");
   if (n_trials == 0) return GRLX_OK;
   if (steps_budget != 0)
   {
@@ -884,6 +898,27 @@ static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *
   for (int done = 0; done < n_trials; done += kTrialsPerLaunch)
   {
     const int n = (n_trials - done < kTrialsPerLaunch) ? n_trials - done : kTrialsPerLaunch;
+    if (done > 0 && ctx->P.logC < ctx->logC_max)
+    { // a run of several launches: the tables may grow BETWEEN its launches too (a launch cannot grow them).  One 4-byte read-back per
+      // further launch, which waits for the launch before it: a call of more than kTrialsPerLaunch trials is no longer fully asynchronous
+      // while the tables may still grow (a deployer runs a whole run as ONE grlx_run; cart-pole actor-critic tables start at 2^16 entries
+      // and 32 trials create about 25 000 slots per table)
+      uint32_t used = 0;
+      HIP_TRY(launch_max_load(ctx->P, ctx->n_tables, ctx->max_load, (hipStream_t)stream));
+      HIP_TRY(hipMemcpyAsync(&used, ctx->max_load, sizeof(used), hipMemcpyDeviceToHost, (hipStream_t)stream));
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      if ((uint64_t)used * 4u > (1ull << ctx->P.logC))
+      {
+        uint32_t want = ctx->P.logC;
+        while ((uint64_t)used * 8u > (1ull << want) && want < ctx->logC_max) ++want;
+        const int rc = grow_tables(ctx, want);
+        if (rc == GRLX_ERR_OOM) { g_err.clear(); ctx->logC_max = ctx->P.logC; }
+        else if (rc != GRLX_OK) return rc;
+        Pb.tables = ctx->P.tables;                 // the launches below work on the new tables
+        Pb.tvals = ctx->P.tvals;
+        Pb.logC = ctx->P.logC;
+      }
+    }
     if (ctx->poison) HIP_TRY(launch_poison_registers(ctx->poison_pattern, (hipStream_t)stream));
     if (ctx->cfg.agent == GRLX_AGENT_AC)
       HIP_TRY(launch_rollout_ac(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
@@ -1221,6 +1256,7 @@ static const int32_t *stage_active(grlx_ctx *ctx, const int32_t *active, hipErro
 int grlx_env_start(grlx_ctx *ctx, int test, const int32_t *active, double *obs)
 {
   if (!ctx || !obs) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (ctx->cfg.env == GRLX_ENV_EXTERNAL) return fail(GRLX_ERR_INVALID, "this context has no environment (GRLX_ENV_EXTERNAL)");
   DRAIN(ctx);
   int rc = step_buffers(ctx);
   if (rc != GRLX_OK) return rc;
@@ -1237,6 +1273,7 @@ int grlx_env_start(grlx_ctx *ctx, int test, const int32_t *active, double *obs)
 int grlx_env_advance(grlx_ctx *ctx, const int32_t *active, const double *action, double *obs, double *reward, int32_t *terminal)
 {
   if (!ctx || !action || !obs || !reward || !terminal) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (ctx->cfg.env == GRLX_ENV_EXTERNAL) return fail(GRLX_ERR_INVALID, "this context has no environment (GRLX_ENV_EXTERNAL)");
   DRAIN(ctx);
   int rc = step_buffers(ctx);
   if (rc != GRLX_OK) return rc;
@@ -1340,6 +1377,7 @@ static int agent_call(grlx_ctx *ctx, int mode, int test, const int32_t *active, 
   }
   A.action = d_action;
   if (mode != STEP_END) HIP_TRY(hipMemcpy(d_action, action, sizeof(double) * N, hipMemcpyHostToDevice));    // rows that do not act keep the caller's values
+  if (ctx->poison) HIP_TRY(launch_poison_registers(ctx->poison_pattern, nullptr));
   HIP_TRY(launch_agent_step(ctx->P, A, nullptr));
   if (mode != STEP_END) HIP_TRY(hipMemcpy(action, d_action, sizeof(double) * N, hipMemcpyDeviceToHost));
   else HIP_TRY(hipDeviceSynchronize());
@@ -1382,6 +1420,7 @@ int grlx_project(const grlx_tile_spec *spec, const double *in, int n, uint32_t *
 int grlx_env_step(const grlx_config *cfg, double *state, const double *action, int n, double *obs, double *reward, int32_t *terminal)
 {
   if (!cfg || !state || !action || !obs || !reward || !terminal || n < 0) return fail(GRLX_ERR_INVALID, "bad argument");
+  if (cfg->env == GRLX_ENV_EXTERNAL) return fail(GRLX_ERR_INVALID, "GRLX_ENV_EXTERNAL is the caller's environment: nothing to step here");
   DevParams P;
   int rc = make_params(*cfg, &P);
   if (rc != GRLX_OK) return rc;

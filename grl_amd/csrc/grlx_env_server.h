@@ -22,7 +22,7 @@
 // The rollout wave never depends on the server: a fetch that does not arrive within kFetchPolls polls is computed locally (it has the state
 // and the action), the replica tells the server to stop and integrates by itself for the rest of the launch.  The server leaves when every
 // replica of its block has sent kExit (or has gone on without it), or after kServerStartPolls polls without a first command /
-// kServerIdlePolls polls without a further one.  Neither side can hang the other.
+// kServerIdlePolls polls (or iterations that consume no command) without a further one.  Neither side can hang the other.
 #pragma once
 
 namespace grlx {
@@ -212,8 +212,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
       if (++idle > (seen ? kServerIdlePolls : kServerStartPolls)) break;
       continue;
     }
-    idle = 0;
     seen = true;
+    // (`idle` is reset only by an iteration that CONSUMED a command: a reset command whose start-state units never arrive -- it cannot
+    //  happen while a reset is always followed by four more commands of the launch, but nothing here relies on that -- keeps `ready`
+    //  true without progress, and still runs into kServerIdlePolls)
+    bool progress = false;
 #ifdef GRLX_ENV_SERVER_STATS
     const unsigned long long t0 = mail_clock();
     if (!__all(ready || done)) ++n_split;
@@ -223,7 +226,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
     {
       unsigned op = (unsigned)(word & 0xFFu);
       if (op == kMailExit)
+      {
         done = true;
+        progress = true;
+      }
       else
       {
         bool have = true;
@@ -269,12 +275,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
           env_step<ENV, false>(N, cx, act, obs, creward, terminal, st);
           cobs0 = obs[0];
           ++expect;
+          progress = true;
 #ifdef GRLX_ENV_SERVER_STATS
           ++n_cmd;
 #endif
         }
       }
     }
+    if (__any(progress)) idle = 0;
+    else if (++idle > kServerIdlePolls) break;
 #ifdef GRLX_ENV_SERVER_STATS
     t_busy += mail_clock() - t0;
 #endif

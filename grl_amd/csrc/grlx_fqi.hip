@@ -665,6 +665,7 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
   *out = nullptr;
   if (cfg->struct_size != sizeof(grlx_fqi_config)) return ffail(GRLX_ERR_INVALID, "grlx_fqi_config.struct_size mismatch");
   if (cfg->env != GRLX_ENV_PENDULUM) return ffail(GRLX_ERR_INVALID, "experiment/batch_learning: the task must support invert(); built for task/pendulum/swingup");
+  if (cfg->eta != 0) return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:eta = %g is not built (instantiated: 0 = RPROP)", cfg->eta);
   if (cfg->hidden != 20) return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:hiddens = [%d] is not built (instantiated: [20])", cfg->hidden);
   if (cfg->n_replicas < 1 || cfg->batch_size < 1 || cfg->max_batches < 1 || cfg->iterations < 1 || cfg->epochs < 0)
     return ffail(GRLX_ERR_INVALID, "n_replicas, batch_size, max_batches, iterations must be >= 1");

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void agent_step_kernel(DevParams P, StepArgs A)
     }
     if (has_next)
     {
-      const double act = pick<double, NA>(P.actions, a_next);    // discretizer_->at(index), uniform.cpp:140-151
+      const double act = P.actions[a_next];                      // discretizer_->at(index), uniform.cpp:140-151
       A.action[r] = act;
       if (!test) { AR.action = act; AR.action_index = a_next; }
     }

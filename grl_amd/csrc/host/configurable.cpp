@@ -301,12 +301,152 @@ static bool looks_like_path(const std::string &v)
 
 static void instantiate_object(Configurator *node, const YamlNode &y);
 
-// value of a parameter node: literal, or the value / object another node holds
+// ---- expressions on parameter values (parser.cpp:49-196): scalars and vectors combined left to right by
+//   +  -  *   element-wise, a scalar broadcast over a vector (vector sizes must match)
+//   ++        concatenation,   --  integer range [a, b),   **  replication
+// anything that is not numeric on both sides is put back together as text (a comma-separated list inside [ ] stays a list).
+static bool expr_numbers(const std::string &s, std::vector<double> &out)
+{
+  out.clear();
+  std::string t = trim(s);
+  if (t.empty()) return false;
+  if (t.front() == '[')
+  {
+    if (t.back() != ']') return false;
+    t = t.substr(1, t.size() - 2);
+    std::replace(t.begin(), t.end(), ',', ' ');
+  }
+  else if (t.find_first_of(", \t") != std::string::npos)
+    return false;                                      // a bare operand is ONE number (vector.h:61-109); "0," is text
+  std::istringstream iss(t);
+  std::string tok;
+  while (iss >> tok)
+  {
+    char *end = nullptr;
+    const double v = std::strtod(tok.c_str(), &end);
+    if (end == tok.c_str() || *end) return false;
+    out.push_back(v);
+  }
+  return !out.empty();
+}
+
+static std::string expr_format(const std::vector<double> &z)
+{
+  std::ostringstream oss;
+  oss << std::setprecision(std::numeric_limits<double>::max_digits10);
+  if (z.size() == 1) { oss << z[0]; return oss.str(); }
+  return format_vector(z);
+}
+
+static std::string expr_apply(const std::string &op, const std::string &left, const std::string &right)
+{ // ASTNode::evaluate (parser.cpp:49-134)
+  std::vector<double> x, y, z;
+  if (!expr_numbers(left, x) || !expr_numbers(right, y)) return left + op + right;
+  auto each = [&](double (*f)(double, double)) -> bool {
+    if (x.size() == 1) { for (double v : y) z.push_back(f(x[0], v)); return true; }
+    if (y.size() == 1) { for (double v : x) z.push_back(f(v, y[0])); return true; }
+    if (x.size() == y.size()) { for (size_t i = 0; i < x.size(); ++i) z.push_back(f(x[i], y[i])); return true; }
+    return false;
+  };
+  bool ok = true;
+  if (op == "+") ok = each([](double a, double b) { return a + b; });
+  else if (op == "-") ok = each([](double a, double b) { return a - b; });
+  else if (op == "*") ok = each([](double a, double b) { return a * b; });
+  else if (op == "++") { z = x; z.insert(z.end(), y.begin(), y.end()); }
+  else if (op == "--")
+  {
+    if (x.size() != 1 || y.size() != 1) throw Exception("Cannot create list from " + left + " to " + right + ": requires scalar operands");
+    for (double v = x[0]; v < y[0]; v += 1) z.push_back(v);
+  }
+  else if (op == "**")
+  {
+    if (y.size() != 1 || !(y[0] > 0)) throw Exception("Cannot replicate " + left + " " + right + " times: vector size mismatch");
+    for (int k = 0; k < (int)y[0]; ++k) z.insert(z.end(), x.begin(), x.end());
+  }
+  else return left + op + right;
+  if (!ok) throw Exception("Cannot combine " + left + " and " + right + " with '" + op + "': vector size mismatch");
+  return expr_format(z);
+}
+
+static std::string evaluate_expression(const std::string &str)
+{ // parseExpression (parser.cpp:136-196): left-associative, sub-expressions in [ ] and ( )
+  static const std::string operators = "+*,-", space = " \t";
+  if (str.empty()) return str;
+  size_t at = 0;
+  std::string op, acc;
+  bool have = false;
+  for (;;)
+  {
+    while (at < str.size() && space.find(str[at]) != std::string::npos) ++at;
+    std::string expr;
+    int paren = 0;
+    for (; at < str.size() && ((operators.find(str[at]) == std::string::npos && space.find(str[at]) == std::string::npos) || paren); ++at)
+    {
+      expr.push_back(str[at]);
+      if (str[at] == '[' || str[at] == '(') paren++;
+      else if ((str[at] == ']' || str[at] == ')') && !--paren) { ++at; break; }
+    }
+    std::string value;
+    if (expr.size() >= 2 && expr.front() == '[' && expr.back() == ']') value = "[ " + evaluate_expression(expr.substr(1, expr.size() - 2)) + " ]";
+    else if (expr.size() >= 2 && expr.front() == '(' && expr.back() == ')') value = evaluate_expression(expr.substr(1, expr.size() - 2));
+    else value = expr;
+    acc = have ? expr_apply(op, acc, value) : value;
+    have = true;
+    while (at < str.size() && space.find(str[at]) != std::string::npos) ++at;
+    if (at < str.size() && operators.find(str[at]) != std::string::npos)
+    {
+      op.clear();
+      for (; at < str.size() && operators.find(str[at]) != std::string::npos; ++at) op.push_back(str[at]);
+    }
+    else if (at < str.size())
+      return expr_apply(" ", acc, evaluate_expression(str.substr(at)));
+    else
+      return acc;
+  }
+}
+
+// an expression over references (ParameterConfigurator::str, configurable.cpp:391-432): every identifier between the separators
+// ' ' \t [ ] + , - * ( ) that names a parameter node is replaced by that node's value, then the text is evaluated
+static bool resolve_expression(Configurator *node, const std::string &raw)
+{
+  static const std::string seps = " \t[]+,-*()";
+  if (raw.find_first_of("+*") == std::string::npos) return false;
+  std::string out, id;
+  bool any = false;
+  auto flush = [&]() {
+    if (id.empty()) return;
+    Configurator *target = nullptr;
+    if (looks_like_path(id) && !std::isdigit((unsigned char)id[0]))
+    {
+      target = node->parent ? node->parent->find(id) : nullptr;
+      if (!target && node->parent) target = node->find(id);
+    }
+    if (target)
+    {
+      if (target->is_object || target->ref) throw Exception(node->path() + ": '" + id + "' names an object inside the expression '" + raw + "'");
+      out += target->value;
+      any = true;
+    }
+    else
+      out += id;
+    id.clear();
+  };
+  for (char ch : raw)
+  {
+    if (seps.find(ch) != std::string::npos) { flush(); out.push_back(ch); }
+    else id.push_back(ch);
+  }
+  flush();
+  if (!any) return false;
+  node->value = evaluate_expression(out);
+  return true;
+}
+
+// value of a parameter node: literal, or the value / object another node holds, or an expression over such values
 static void resolve_parameter(Configurator *node, const std::string &raw)
 {
   node->value = raw;
-  if (raw.find_first_of("+*") != std::string::npos && looks_like_path(raw.substr(0, raw.find_first_of("+* "))))
-    throw Exception(node->path() + ": arithmetic on references ('" + raw + "') is not supported by this loader");
+  if (resolve_expression(node, raw)) return;
   if (!looks_like_path(raw)) return;
   Configurator *target = node->parent ? node->parent->find(raw) : nullptr;     // relative to the owning object first
   if (!target && node->parent) target = node->find(raw);

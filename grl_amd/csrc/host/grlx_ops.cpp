@@ -1,6 +1,7 @@
 // grlx_ops.cpp -- the plug-in interfaces of the host layer, driven from the command line (parity checks, mixed graphs):
 //   grlx_ops project <yaml> <path of a projector/tile_coding> <input file>     Projector::project for every input row
 //   grlx_ops envstep <yaml> <path of an environment/modeled> <input file>      Environment::step for every (state, action) row
+//   grlx_ops stepwise <yaml> <path of an experiment/online_learning> <input>   the experiment's loop on the host over per-step objects
 // Rows are whitespace-separated numbers; results are printed with 17 significant digits (round-trip exact).
 // The objects are instantiated from the reference's yaml exactly as grlxd does; the work happens in the HIP kernels
 // behind grlx_project / grlx_env_step.
@@ -35,7 +36,7 @@ int main(int argc, char **argv)
 {
   if (argc != 5)
   {
-    std::cerr << "usage: " << argv[0] << " project|envstep|represent <yaml> <object path> <input file>" << std::endl;
+    std::cerr << "usage: " << argv[0] << " project|envstep|represent|stepwise <yaml> <object path> <input file>" << std::endl;
     return 1;
   }
   try
@@ -118,6 +119,52 @@ int main(int argc, char **argv)
         else
           throw Exception("unknown representation op");
       }
+    }
+    else if (std::string(argv[1]) == "stepwise")
+    { // grlx_ops stepwise <yaml> <path of an experiment/online_learning> <file: "<seed> <replicas> <trials>">
+      // The loop of OnlineLearningExperiment::run (online_learning.cpp:154-262) written HERE, on the host, over the experiment's
+      // environment and agents as per-step objects (Environment::start / step, Agent::start / step / end): every call serves all
+      // replicas on the GPU.  Prints the rows of replica 0 in the layout of the reference's golden files.
+      StepwiseExperiment *ex = dynamic_cast<StepwiseExperiment *>(node->ptr());
+      if (!ex) throw Exception(std::string(argv[3]) + ": not an experiment/online_learning");
+      if (n != 1 || rows[0].size() != 3) throw Exception("input: one row `<seed> <replicas> <trials>`");
+      RunOptions opt;
+      opt.seed = (int64_t)rows[0][0];
+      opt.replicas = (int)rows[0][1];
+      const int trials = (int)rows[0][2];
+      ex->open(opt);
+      const int N = ex->replicas(), D = ex->obs_dims(), ti = ex->test_interval_of();
+      std::vector<double> obs((size_t)N * D), action(N), reward(N), total(N);
+      std::vector<int32_t> terminal(N), active(N);
+      std::vector<long long> ss(N, 0);
+      StepwiseEnvironment *env = ex->stepwise_environment();
+      for (int tt = 0; tt < trials; ++tt)
+      {
+        const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;                         // online_learning.cpp:160
+        StepwiseAgent *agent = test ? ex->stepwise_test_agent() : ex->stepwise_agent();     // :167-168
+        std::fill(active.begin(), active.end(), 1);
+        std::fill(total.begin(), total.end(), 0.);
+        env->start(test, active.data(), obs.data());                                        // :172
+        agent->start(active.data(), obs.data(), action.data());                             // :178
+        bool any = true;
+        while (any)
+        {
+          env->step(active.data(), action.data(), obs.data(), reward.data(), terminal.data());     // :196
+          agent->step(active.data(), 1., obs.data(), reward.data(), terminal.data(), action.data());   // :210-213 (terminal == 2: Agent::end)
+          any = false;
+          for (int k = 0; k < N; ++k)
+            if (active[k])
+            {
+              total[k] += reward[k];                                                        // :202
+              if (!test) ss[k]++;                                                           // :218
+              if (terminal[k]) active[k] = 0;
+              else any = true;
+            }
+        }
+        if (ti >= 0 ? test : 1)
+          printf("%15lld%15lld%15g\n", (long long)(ti >= 0 ? tt + 1 - (tt + 1) / (ti + 1) : tt), ss[0], total[0]);
+      }
+      ex->close();
     }
     else
       throw Exception(std::string("unknown operator '") + argv[1] + "'");

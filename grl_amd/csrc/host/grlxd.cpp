@@ -68,7 +68,7 @@ int main(int argc, char **argv)
     std::unique_ptr<Configurator> tree = instantiate(root);
     Configurator *expconf = tree->child("experiment");
     if (!expconf || !expconf->is_object) { log(0, "YAML configuration does not specify an experiment"); return 1; }
-    OnlineLearningExperiment *experiment = dynamic_cast<OnlineLearningExperiment *>(expconf->object.get());
+    Experiment *experiment = dynamic_cast<Experiment *>(expconf->object.get());
     if (!experiment) { log(0, "Specified experiment has wrong type"); return 1; }
     log(2, "Starting experiment");
     experiment->run(opt);

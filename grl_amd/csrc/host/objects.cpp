@@ -515,6 +515,7 @@ struct QPolicy : Policy {
   GRLX_TYPEINFO("mapping/policy/discrete/value/q")
   UniformDiscretizer *discretizer = nullptr; TileCodingProjector *projector = nullptr;
   LinearRepresentation *representation = nullptr; GreedySampler *sampler = nullptr;
+  Configurable *any_projector = nullptr, *any_representation = nullptr;     // whatever the yaml gave (the batch path: normalizing projector, iterative ANN)
   void request(const std::string &, ConfigurationRequest *config) override
   {
     config->push_back(CRP("discretizer", "discretizer.action", "Action discretizer", (Configurable *)nullptr));
@@ -528,8 +529,12 @@ struct QPolicy : Policy {
     projector = dynamic_cast<TileCodingProjector *>(config["projector"].ptr());
     representation = dynamic_cast<LinearRepresentation *>(config["representation"].ptr());
     sampler = dynamic_cast<GreedySampler *>(config["sampler"].ptr());
-    if (!discretizer || !projector || !representation || !sampler)
-      throw Exception(path() + ": the accelerated path needs discretizer/uniform, projector/tile_coding, representation/parameterized/linear and a greedy sampler");
+    any_projector = config["projector"].ptr();
+    any_representation = config["representation"].ptr();
+    // (projector / representation kinds are checked where the graph is lowered: tile coding + linear for experiment/online_learning,
+    //  projector/pre/normalizing + representation/iterative over an ANN for experiment/batch_learning)
+    if (!discretizer || !any_projector || !any_representation || !sampler)
+      throw Exception(path() + ": the accelerated path needs discretizer/uniform, a projector, a representation and a greedy sampler");
   }
 };
 GRLX_REGISTER(QPolicy)
@@ -833,9 +838,333 @@ struct CSVExporter : Configurable {
 };
 GRLX_REGISTER(CSVExporter)
 
+// ------------------------------------------------------------- batch path ---
+// The classes of the reference's tests/pendulum-fqi-ann.yaml (BASELINE configs[4]): descriptors, lowered to a grlx_fqi_config.
+// projector/identity (projector.h:79-101): no parameters
+struct IdentityProjector : Configurable { GRLX_TYPEINFO("projector/identity") };
+GRLX_REGISTER(IdentityProjector)
+
+// projector/pre/normalizing (normalizing.cpp:34-75)
+struct NormalizingProjector : Configurable {
+  GRLX_TYPEINFO("projector/pre/normalizing")
+  VecD input_min, input_max;
+  int signed_ = 0;
+  Configurable *projector = nullptr;
+  void request(const std::string &role, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("signed", "If true, project onto [-1, 1] instead of [0, 1]", 0));
+    config->push_back(CRP("input_min", "Lower input dimension limit (for scaling)", VecD{}, CRP::System));
+    config->push_back(CRP("input_max", "Upper input dimension limit (for scaling)", VecD{}, CRP::System));
+    config->push_back(CRP("projector", "projector." + role, "Downstream projector", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    projector = config["projector"].ptr();
+    input_min = config["input_min"].v(); input_max = config["input_max"].v();
+    signed_ = config["signed"];
+    if (signed_ != 0 && signed_ != 1) throw bad_param("projector/pre/normalizing:signed");
+    if (input_min.size() != input_max.size()) throw bad_param("projector/normalizing:{input_min,input_max}");
+    if (!dynamic_cast<IdentityProjector *>(projector)) throw Exception(path() + ": the accelerated path runs projector/pre/normalizing over projector/identity");
+  }
+};
+GRLX_REGISTER(NormalizingProjector)
+
+// representation/parameterized/ann (ann.cpp:36-96)
+struct ANNRepresentation : Configurable {
+  GRLX_TYPEINFO("representation/parameterized/ann")
+  int inputs = 1, outputs = 1, interval = 0;
+  VecD hiddens;
+  double eta = 0.7, tau = 1;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("interval", "Target network update interval", 0.));          // ParameterizedRepresentation (representation.h:173-184)
+    config->push_back(CRP("tau", "Target network update rate", 1.));
+    config->push_back(CRP("inputs", "Number of input dimensions", 1, CRP::System));
+    config->push_back(CRP("outputs", "Number of output dimensions", 1, CRP::System));
+    config->push_back(CRP("hiddens", "Number of hidden nodes per layer", VecD{5}));
+    config->push_back(CRP("eta", "Learning rate (0=RPROP, <0=RMSPROP)", 0.7));
+  }
+  void configure(Configuration &config) override
+  {
+    inputs = config["inputs"]; outputs = config["outputs"]; hiddens = config["hiddens"].v(); eta = config["eta"];
+    interval = (int)(double)config["interval"]; tau = config["tau"];
+    if (inputs < 1) throw bad_param("representation/parameterized/ann:inputs");
+    if (outputs < 1) throw bad_param("representation/parameterized/ann:outputs");
+    for (double h : hiddens) if (std::round(h) <= 0) throw bad_param("representation/parameterized/ann:hiddens");     // ann.cpp:74-75
+    if (eta < -2 || eta > 2) throw bad_param("representation/parameterized/ann:eta");
+  }
+};
+GRLX_REGISTER(ANNRepresentation)
+
+// representation/iterative (iterative.cpp:34-53)
+struct IterativeRepresentation : Configurable {
+  GRLX_TYPEINFO("representation/iterative")
+  int epochs = 5000, cumulative = 1, batch_size = 0;
+  Configurable *representation = nullptr;
+  void request(const std::string &role, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("epochs", "Learning epochs", 5000));
+    config->push_back(CRP("cumulative", "Add to training set instead of replacing it", 1));
+    config->push_back(CRP("batch_size", "Batch size for gradient estimation (0=entire dataset)", 0));
+    config->push_back(CRP("representation", "representation." + role, "Downstream representation", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    epochs = config["epochs"]; cumulative = config["cumulative"]; batch_size = config["batch_size"];
+    representation = config["representation"].ptr();
+    if (cumulative != 0 && cumulative != 1) throw bad_param("representation/iterative:cumulative");
+    if (batch_size < 0) throw bad_param("representation/iterative:batch_size");
+  }
+};
+GRLX_REGISTER(IterativeRepresentation)
+
+// predictor/fqi (fqi.cpp:34-77)
+struct FQIPredictor : Predictor {
+  GRLX_TYPEINFO("predictor/fqi")
+  double gamma = 0.97;
+  int transitions = 100000, iterations = 10, macro_batch_size = 1;
+  std::string reset_strategy = "iteration";
+  UniformDiscretizer *discretizer = nullptr;
+  NormalizingProjector *projector = nullptr;
+  IterativeRepresentation *representation = nullptr;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("importer", "importer", "Optional importer", (Configurable *)nullptr, true));     // Predictor::request
+    config->push_back(CRP("exporter", "exporter", "Optional exporter", (Configurable *)nullptr, true));
+    config->push_back(CRP("gamma", "Discount rate", 0.97));
+    config->push_back(CRP("transitions", "Maximum number of transitions to store", 100000));
+    config->push_back(CRP("iterations", "Number of policy improvement rounds per episode", 10));
+    config->push_back(CRP("reset_strategy", "At which point to reset the representation", std::string("iteration")));
+    config->push_back(CRP("macro_batch_size", "Number of episodes/batches after which prediction is rebuilt. Use 0 for no rebuilds.", 1));
+    config->push_back(CRP("discretizer", "discretizer.action", "Action discretizer", (Configurable *)nullptr));
+    config->push_back(CRP("projector", "projector.pair", "Projects observations onto critic representation space", (Configurable *)nullptr));
+    config->push_back(CRP("representation", "representation.value/action", "Value function representation", (Configurable *)nullptr));
+  }
+  void configure(Configuration &config) override
+  {
+    gamma = config["gamma"]; transitions = config["transitions"]; iterations = config["iterations"];
+    macro_batch_size = config["macro_batch_size"]; reset_strategy = config["reset_strategy"].str();
+    discretizer = dynamic_cast<UniformDiscretizer *>(config["discretizer"].ptr());
+    projector = dynamic_cast<NormalizingProjector *>(config["projector"].ptr());
+    representation = dynamic_cast<IterativeRepresentation *>(config["representation"].ptr());
+    if (transitions < 1) throw bad_param("predictor/fqi:transitions");
+    if (iterations < 1) throw bad_param("predictor/fqi:iterations");
+    if (reset_strategy != "never" && reset_strategy != "batch" && reset_strategy != "iteration") throw bad_param("predictor/fqi:reset_strategy");
+    if (config["importer"].ptr() || config["exporter"].ptr()) throw Exception(path() + ": importer/exporter are outside the accelerated path");
+    if (!discretizer || !projector || !representation)
+      throw Exception(path() + ": the accelerated path needs discretizer/uniform, projector/pre/normalizing and representation/iterative");
+  }
+};
+GRLX_REGISTER(FQIPredictor)
+
+// experiment/batch_learning (batch_learning.cpp:36-205): batches of uniformly drawn transitions, FQIPredictor::rebuild after each, one greedy
+// test trial per batch.  Lowered to a grlx_fqi_config and run by the kernels of grlx_fqi.hip (grlx_fqi_*): PARITY UNPINNED, oracle/fqi.c D1-D4.
+struct BatchLearningExperimentImpl : Experiment {
+  GRLX_TYPEINFO("experiment/batch_learning")
+  int runs = 1, batches = 0, batch_size = 100;
+  std::string output;
+  Model *model = nullptr; Task *task = nullptr; FQIPredictor *predictor = nullptr; FixedAgent *test_agent = nullptr;
+  VecD observation_min, observation_max, action_min, action_max;
+  void request(const std::string &, ConfigurationRequest *config) override
+  {
+    config->push_back(CRP("runs", "Number of separate learning runs to perform", 1));
+    config->push_back(CRP("batches", "Number of batches per learning run", 0));
+    config->push_back(CRP("batch_size", "Number of transitions per batch", 100));
+    config->push_back(CRP("rate", "Test trial control step frequency in Hz", 0, CRP::Online));
+    config->push_back(CRP("output", "Output base filename", std::string()));
+    config->push_back(CRP("model", "model", "Model in which the task is set", (Configurable *)nullptr));
+    config->push_back(CRP("task", "task", "Task to be solved", (Configurable *)nullptr));
+    config->push_back(CRP("predictor", "predictor", "Learner", (Configurable *)nullptr));
+    config->push_back(CRP("test_agent", "agent", "Agent to use in test trials after each batch", (Configurable *)nullptr));
+    config->push_back(CRP("observation_min", "Lower limit for observations", VecD{}, CRP::System));
+    config->push_back(CRP("observation_max", "Upper limit for observations", VecD{}, CRP::System));
+    config->push_back(CRP("action_min", "Lower limit for actions", VecD{}, CRP::System));
+    config->push_back(CRP("action_max", "Upper limit for actions", VecD{}, CRP::System));
+  }
+  void configure(Configuration &config) override
+  {
+    runs = config["runs"]; batches = config["batches"]; batch_size = config["batch_size"]; output = config["output"].str();
+    model = dynamic_cast<Model *>(config["model"].ptr());
+    task = dynamic_cast<Task *>(config["task"].ptr());
+    predictor = dynamic_cast<FQIPredictor *>(config["predictor"].ptr());
+    test_agent = dynamic_cast<FixedAgent *>(config["test_agent"].ptr());
+    observation_min = config["observation_min"].v(); observation_max = config["observation_max"].v();
+    action_min = config["action_min"].v(); action_max = config["action_max"].v();
+    if (runs < 1) throw bad_param("experiment/batch_learning:runs");
+    if (batch_size < 1) throw bad_param("experiment/batch_learning:batch_size");
+    if ((int)config["rate"] != 0) throw Exception(path() + ": rate (wall-clock pacing) is outside the accelerated path");
+    if (!model || !task || !predictor || !test_agent)
+      throw Exception(path() + ": the accelerated path needs model/dynamical, a task, predictor/fqi and agent/fixed");
+  }
+
+  // every assumption the batch kernels make is checked here; what they do not implement is refused, never emulated
+  void lower(grlx_fqi_config *c) const
+  {
+    grlx_fqi_config_pendulum(c);
+    const DynamicalModel *dm = dynamic_cast<const DynamicalModel *>(model);
+    if (!dm || dm->env_id() != GRLX_ENV_PENDULUM || task->env_id() != GRLX_ENV_PENDULUM)
+      throw Exception(path() + ": the batch path is built for model/dynamical with dynamics/pendulum and task/pendulum/swingup (the task must support invert(), pendulum.cpp:147-155)");
+    if (task->randomization != 0) throw Exception(task->path() + ": randomization must be 0 on the batch path");
+    c->control_step = dm->control_step; c->integration_steps = dm->integration_steps; c->timeout = task->timeout;
+    // the experiment's sampling box must be the task's (the kernels draw observations and actions over the task's limits)
+    const Configurator *t = task->configurator;
+    auto task_vec = [&](const char *n) { return parse_vector(t->child(n)->value, n); };
+    if (observation_min != task_vec("observation_min") || observation_max != task_vec("observation_max") ||
+        action_min != task_vec("action_min") || action_max != task_vec("action_max"))
+      throw Exception(path() + ": observation_min/max and action_min/max must be the task's limits on the accelerated path");
+    const UniformDiscretizer *d = predictor->discretizer;
+    if (d->min.size() != 1 || d->min != action_min || d->max != action_max) throw Exception(d->path() + ": one action dimension over the task's action range");
+    c->action_min = d->min[0]; c->action_max = d->max[0]; c->action_steps = (int)d->steps[0];
+    // projector/pre/normalizing over (observation ++ action).  The reference's yaml writes `observation_min+action_min`, which its
+    // own parser adds element-wise with the scalar broadcast (parser.cpp:76-83) -- two entries for a three-dimensional input, which
+    // NormalizingProjector::project then refuses (normalizing.cpp:78-83).  Deviation D4 (oracle/fqi.c): a limit
+    // vector that does not have observation + action entries is replaced by the role's default, observation_min ++ action_min
+    // (normalizing.cpp:50-51); one that has them must BE that concatenation.
+    const NormalizingProjector *np = predictor->projector;
+    VecD want_min = observation_min, want_max = observation_max;
+    want_min.insert(want_min.end(), action_min.begin(), action_min.end());
+    want_max.insert(want_max.end(), action_max.begin(), action_max.end());
+    if (np->input_min.size() != want_min.size())
+      log(1, np->path() + ": input_min / input_max have " + std::to_string(np->input_min.size()) + " entries for a " + std::to_string(want_min.size()) +
+                 "-dimensional (observation, action) input; using observation_min++action_min, observation_max++action_max (deviation D4)");
+    else if (np->input_min != want_min || np->input_max != want_max)
+      throw Exception(np->path() + ": input_min / input_max must be the task's observation and action limits on the accelerated path");
+    if (np->signed_ != 0) throw Exception(np->path() + ": signed = 1 is outside the accelerated path");
+    // representation/iterative over representation/parameterized/ann
+    const IterativeRepresentation *it = predictor->representation;
+    const ANNRepresentation *ann = dynamic_cast<const ANNRepresentation *>(it->representation);
+    if (!ann) throw Exception(it->path() + ": the accelerated path runs representation/iterative over representation/parameterized/ann");
+    if (it->cumulative != 0 || it->batch_size != 0) throw Exception(it->path() + ": cumulative = 0 and batch_size = 0 (the whole data set per epoch) on the accelerated path");
+    if (ann->inputs != (int)want_min.size() || ann->outputs != 1) throw Exception(ann->path() + ": inputs must be observation_dims+action_dims and outputs 1");
+    if (ann->hiddens.size() != 1) throw Exception(ann->path() + ": one hidden layer on the accelerated path");
+    if (ann->interval != 0) throw Exception(ann->path() + ": a target network (interval) is outside the accelerated path");
+    c->hidden = (int)std::round(ann->hiddens[0]);
+    c->eta = ann->eta;
+    c->epochs = it->epochs;
+    c->gamma = predictor->gamma; c->iterations = predictor->iterations;
+    if (predictor->reset_strategy != "never") throw Exception(predictor->path() + ": reset_strategy must be never on the accelerated path");
+    if (predictor->macro_batch_size != 1) throw Exception(predictor->path() + ": macro_batch_size must be 1 on the accelerated path");
+    // the test agent: agent/fixed with the greedy Q policy over the predictor's own discretizer, projector and representation
+    const QPolicy *tp = dynamic_cast<const QPolicy *>(test_agent->policy);
+    if (!tp || tp->discretizer != d || tp->any_projector != np || tp->any_representation != it || tp->sampler->explores())
+      throw Exception(test_agent->path() + ": the test agent must be agent/fixed with policy/discrete/q over the predictor's discretizer, projector and representation and sampler/greedy");
+    c->batch_size = batch_size;
+    if (batches < 1) throw Exception(path() + ": batches must be > 0 (the reference's batches: 0 runs forever)");
+    c->max_batches = batches;
+    if ((long long)batches * batch_size > (long long)predictor->transitions)
+      throw Exception(predictor->path() + ": transitions (the store's size) is smaller than batches x batch_size; the accelerated path keeps every transition");
+  }
+
+  std::vector<double> run(const RunOptions &opt) override
+  {
+    if (runs != 1) throw Exception(path() + ": runs > 1 (Experiment::reset between runs) is not built for the batch path");
+    grlx_fqi_config c;
+    lower(&c);
+    c.n_replicas = opt.replicas;
+    if (!output.empty())
+    {
+      std::ofstream ofs(output + ".yaml");
+      ofs << configurator->root()->yaml();
+    }
+    std::vector<int64_t> seeds((size_t)opt.replicas);
+    for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i;
+    grlx_fqi_ctx *ctx = nullptr;
+    if (grlx_fqi_create(&c, seeds.data(), &ctx) != GRLX_OK) throw Exception(grlx_last_error());
+    std::vector<std::ofstream> files((size_t)opt.replicas);
+    if (!output.empty())
+      for (int i = 0; i < opt.replicas; ++i)
+      { // <output>-<run>.txt (batch_learning.cpp:96-101); clones carry the identity "@i" (multi.cpp:52-56)
+        std::ostringstream name;
+        name << output << "-" << 0;
+        if (opt.replicas > 1) name << "@" << i;
+        name << ".txt";
+        files[(size_t)i].open(name.str());
+      }
+    std::vector<double> curve;
+    for (int bb = 0; bb < batches; ++bb)
+    { // the rows are written batch by batch, as the reference does (a run can be watched)
+      auto start = std::chrono::steady_clock::now();
+      int rc = grlx_fqi_run_batch(ctx, nullptr);
+      if (rc == GRLX_OK) rc = grlx_fqi_sync(ctx, nullptr);
+      if (rc != GRLX_OK) { std::string e = grlx_last_error(); grlx_fqi_destroy(ctx); throw Exception(e); }
+      const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+      for (int i = 0; i < opt.replicas; ++i)
+      {
+        int64_t batch = 0, transitions = 0;
+        double reward = 0;
+        if (grlx_fqi_read_rows(ctx, i, bb, 1, &batch, &transitions, &reward) != GRLX_OK) { std::string e = grlx_last_error(); grlx_fqi_destroy(ctx); throw Exception(e); }
+        std::ostringstream oss;                          // batch_learning.cpp:179
+        oss << std::setw(15) << batch << std::setw(15) << transitions << std::setw(15) << reward;
+        if (files[(size_t)i].is_open()) files[(size_t)i] << oss.str() << std::endl;
+        if (i == 0 && opt.print_rows) std::cout << oss.str() << std::endl;
+        if (i == 0) curve.push_back(reward);
+      }
+      int32_t its = 0;
+      grlx_fqi_info(ctx, 0, nullptr, nullptr, &its, nullptr, nullptr);
+      std::ostringstream msg;
+      msg << "batch " << bb << ": " << opt.replicas << " replicas, " << (bb + 1) * batch_size << " stored transitions, " << its << " iterations x " << c.epochs
+          << " epochs (replica 0) in " << wall << " s";
+      log(2, msg.str());
+    }
+    grlx_fqi_destroy(ctx);
+    return curve;
+  }
+};
+GRLX_REGISTER(BatchLearningExperimentImpl)
+
 // ------------------------------------------------------------- experiment ---
-struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
+// The experiment's objects stepped by the caller: thin forwards to the per-step entry points of the C ABI on the experiment's context
+struct ContextEnvironment : StepwiseEnvironment {
+  grlx_ctx *ctx = nullptr;
+  void start(int test, const int32_t *active, double *obs) override
+  { if (grlx_env_start(ctx, test, active, obs) != GRLX_OK) throw Exception(std::string("environment/modeled: ") + grlx_last_error()); }
+  void step(const int32_t *active, const double *action, double *obs, double *reward, int32_t *terminal) override
+  { if (grlx_env_advance(ctx, active, action, obs, reward, terminal) != GRLX_OK) throw Exception(std::string("environment/modeled: ") + grlx_last_error()); }
+};
+struct ContextAgent : StepwiseAgent {
+  grlx_ctx *ctx = nullptr;
+  int test = 0;                                     // 0: agent/td, 1: agent/fixed (the test agent)
+  void start(const int32_t *active, const double *obs, double *action) override
+  { if (grlx_agent_start(ctx, test, active, obs, action) != GRLX_OK) throw Exception(std::string("agent: ") + grlx_last_error()); }
+  void step(const int32_t *active, double tau, const double *obs, const double *reward, const int32_t *terminal, double *action) override
+  { if (grlx_agent_step(ctx, test, active, tau, obs, reward, terminal, action) != GRLX_OK) throw Exception(std::string("agent: ") + grlx_last_error()); }
+  void end(const int32_t *active, double tau, const double *obs, const double *reward) override
+  { if (grlx_agent_end(ctx, test, active, tau, obs, reward) != GRLX_OK) throw Exception(std::string("agent: ") + grlx_last_error()); }
+};
+
+struct OnlineLearningExperimentImpl : OnlineLearningExperiment, StepwiseExperiment {
   GRLX_TYPEINFO("experiment/online_learning")
+  // ---- StepwiseExperiment: the graph instantiated on the GPU, its environment and agents stepped by the caller
+  grlx_ctx *step_ctx = nullptr;
+  grlx_config step_cfg;
+  ContextEnvironment step_env;
+  ContextAgent step_agent, step_test_agent;
+  ~OnlineLearningExperimentImpl() override { close(); }
+  void open(const RunOptions &opt) override
+  {
+    close();
+    lower(&step_cfg);
+    step_cfg.n_replicas = opt.replicas;
+    if (opt.table_log2_capacity) step_cfg.table_log2_capacity = opt.table_log2_capacity;
+    std::vector<int64_t> seeds((size_t)opt.replicas);
+    for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i;
+    if (grlx_create(&step_cfg, seeds.data(), &step_ctx) != GRLX_OK) { step_ctx = nullptr; throw Exception(grlx_last_error()); }
+    step_env.ctx = step_agent.ctx = step_test_agent.ctx = step_ctx;
+    step_agent.test = 0;
+    step_test_agent.test = 1;
+  }
+  void close() override
+  {
+    if (step_ctx) grlx_destroy(step_ctx);
+    step_ctx = nullptr;
+  }
+  int replicas() const override { return step_cfg.n_replicas; }
+  int obs_dims() const override { int s = 0, d = 0; grlx_env_dims(step_cfg.env, &s, &d); return d; }
+  int test_interval_of() const override { return test_interval; }
+  StepwiseEnvironment *stepwise_environment() override { return &step_env; }
+  StepwiseAgent *stepwise_agent() override { return &step_agent; }
+  StepwiseAgent *stepwise_test_agent() override { return &step_test_agent; }
+
   int runs = 1, run_offset = 0, trials = 0, steps = 0, test_interval = -1, test_trials = 1;
   std::string output, load_file, save_every;
   ModeledEnvironment *environment = nullptr; TDAgent *agent = nullptr; FixedAgent *test_agent = nullptr;
@@ -956,6 +1285,8 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment {
     const QPolicy *tpol = test_agent ? dynamic_cast<const QPolicy *>(test_agent->policy) : nullptr;
     if (!pol || !pred || (test_agent && !tpol))
       throw Exception(path() + ": the accelerated path needs mapping/policy/discrete/value/q with predictor/critic/sarsa|q, or policy/action with predictor/ac/action");
+    if (!pol->projector || !pol->representation || (tpol && (!tpol->projector || !tpol->representation)))
+      throw Exception(path() + ": experiment/online_learning runs projector/tile_coding with representation/parameterized/linear on the accelerated path");
     if (pred->projector != pol->projector || pred->representation != pol->representation)
       throw Exception(pred->path() + ": predictor and policy must share projector and representation on the accelerated path");
     if (const ExpectedSARSAPredictor *es = dynamic_cast<const ExpectedSARSAPredictor *>(pred))

@@ -42,8 +42,38 @@ struct Representation : Configurable {
 };
 
 // Experiment::run (experiment.h:44) -> learning curve of replica 0
-struct OnlineLearningExperiment : Configurable {
+struct Experiment : Configurable {
   virtual std::vector<double> run(const RunOptions &opt) = 0;
+};
+struct OnlineLearningExperiment : Experiment {};
+
+// The per-step side of the plug-in API: the experiment's environment and agents as objects a caller steps itself -- the loop of
+// OnlineLearningExperiment::run (online_learning.cpp:172-213) stays with the caller, one side (or both) runs on the GPU, every call
+// serves all replicas of the experiment's device context (rows of [replicas]; `active`: NULL or a mask of the replicas taking part).
+//   Environment::start / step  (environment.h:48-51)  -> grlx_env_start / grlx_env_advance
+//   Agent::start / step / end  (agent.h:44-56)        -> grlx_agent_start / _step / _end; agent/td is the learning agent, agent/fixed the test agent
+struct StepwiseEnvironment {
+  virtual ~StepwiseEnvironment() {}
+  virtual void start(int test, const int32_t *active, double *obs) = 0;
+  virtual void step(const int32_t *active, const double *action, double *obs, double *reward, int32_t *terminal) = 0;
+};
+struct StepwiseAgent {
+  virtual ~StepwiseAgent() {}
+  virtual void start(const int32_t *active, const double *obs, double *action) = 0;
+  virtual void step(const int32_t *active, double tau, const double *obs, const double *reward, const int32_t *terminal, double *action) = 0;
+  virtual void end(const int32_t *active, double tau, const double *obs, const double *reward) = 0;
+};
+// experiment/online_learning as the owner of the device context its objects step on
+struct StepwiseExperiment {
+  virtual ~StepwiseExperiment() {}
+  virtual void open(const RunOptions &opt) = 0;                 // instantiate on the GPU (grlx_create of the lowered graph)
+  virtual void close() = 0;
+  virtual int replicas() const = 0;
+  virtual int obs_dims() const = 0;
+  virtual int test_interval_of() const = 0;
+  virtual StepwiseEnvironment *stepwise_environment() = 0;
+  virtual StepwiseAgent *stepwise_agent() = 0;
+  virtual StepwiseAgent *stepwise_test_agent() = 0;
 };
 
 } // namespace grlx_host

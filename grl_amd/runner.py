@@ -79,9 +79,12 @@ class Runner:
         self.seeds = seeds
         self._ctx = C.c_void_p()
         capi.check(self.lib.grlx_create(C.byref(cfg), _ptr(seeds, C.c_int64), C.byref(self._ctx)))
-        sd, od = C.c_int(), C.c_int()
-        capi.check(self.lib.grlx_env_dims(cfg.env, C.byref(sd), C.byref(od)))
-        self.state_dims, self.obs_dims = sd.value, od.value
+        if cfg.env == capi.ENV_EXTERNAL:        # the caller's environment: the agent's observation = the projector's input (minus the action)
+            self.state_dims, self.obs_dims = 0, cfg.projector.dims - (0 if cfg.agent == capi.AGENT_AC else 1)
+        else:
+            sd, od = C.c_int(), C.c_int()
+            capi.check(self.lib.grlx_env_dims(cfg.env, C.byref(sd), C.byref(od)))
+            self.state_dims, self.obs_dims = sd.value, od.value
 
     def close(self):
         if self._ctx:
@@ -139,11 +142,8 @@ class Runner:
     def env_server_counts(self):
         """(replicas served by the environment server to the end of the last launch that had it, replicas that fell back to integrating
         themselves); (0, 0) when no launch of this context had it -- diagnostic export, not part of include/grlx.h"""
-        fn = self.lib.grlx_env_server_counts
-        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        fn.restype = C.c_int
         a, b = C.c_int(0), C.c_int(0)
-        capi.check(fn(self._ctx, C.byref(a), C.byref(b)))
+        capi.check(self.lib.grlx_env_server_counts(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def replicas_per_wave(self) -> int:
@@ -230,6 +230,68 @@ class Runner:
         n = C.c_int()
         capi.check(self.lib.grlx_read_taps(self._ctx, buf, cap, C.byref(n)))
         return [buf[i] for i in range(n.value)]
+
+    # ---- the per-step plug-in interfaces: one call of the reference's interface for every replica (include/grlx.h) ----
+    def _active(self, active):
+        if active is None:
+            return None, None
+        a = np.ascontiguousarray(active, dtype=np.int32)
+        if a.shape != (self.cfg.n_replicas,):
+            raise ValueError("active: one entry per replica")
+        return a, _ptr(a, C.c_int32)
+
+    def _rows(self, x, cols=None):
+        shape = (self.cfg.n_replicas,) if cols is None else (self.cfg.n_replicas, cols)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != shape:
+            raise ValueError(f"expected an array of shape {shape}, got {x.shape}")
+        return x
+
+    def env_start(self, test: int, active=None, obs=None):
+        """Environment::start (environment.h:48) for the replicas: first observations [n_replicas][obs_dims]."""
+        obs = np.zeros((self.cfg.n_replicas, self.obs_dims), np.float64) if obs is None else self._rows(obs, self.obs_dims)
+        keep, ap = self._active(active)
+        capi.check(self.lib.grlx_env_start(self._ctx, int(test), ap, _ptr(obs, C.c_double)))
+        return obs
+
+    def env_advance(self, action, active=None, obs=None, reward=None, terminal=None):
+        """Environment::step (environment.h:49-51) on the replicas' model states: (obs, reward, terminal); tau = 1."""
+        n = self.cfg.n_replicas
+        action = self._rows(action)
+        obs = np.zeros((n, self.obs_dims), np.float64) if obs is None else self._rows(obs, self.obs_dims)
+        reward = np.zeros(n, np.float64) if reward is None else self._rows(reward)
+        terminal = np.zeros(n, np.int32) if terminal is None else np.ascontiguousarray(terminal, dtype=np.int32)
+        keep, ap = self._active(active)
+        capi.check(self.lib.grlx_env_advance(self._ctx, ap, _ptr(action, C.c_double), _ptr(obs, C.c_double), _ptr(reward, C.c_double), _ptr(terminal, C.c_int32)))
+        return obs, reward, terminal
+
+    def agent_start(self, test: int, obs, active=None, action=None):
+        """Agent::start (agent.h:44-47): test = 0 the learning agent, 1 the test agent; returns the actions [n_replicas]."""
+        obs = self._rows(obs, np.asarray(obs).shape[-1])
+        action = np.zeros(self.cfg.n_replicas, np.float64) if action is None else self._rows(action)
+        keep, ap = self._active(active)
+        capi.check(self.lib.grlx_agent_start(self._ctx, int(test), ap, _ptr(obs, C.c_double), _ptr(action, C.c_double)))
+        return action
+
+    def agent_step(self, test: int, obs, reward, terminal=None, active=None, action=None, tau: float = 1.0):
+        """Agent::step (agent.h:49-52); replicas whose `terminal` entry is 2 get Agent::end instead and keep their `action` row."""
+        obs = self._rows(obs, np.asarray(obs).shape[-1])
+        reward = self._rows(reward)
+        action = np.zeros(self.cfg.n_replicas, np.float64) if action is None else self._rows(action)
+        tp = None
+        if terminal is not None:
+            terminal = np.ascontiguousarray(terminal, dtype=np.int32)
+            tp = _ptr(terminal, C.c_int32)
+        keep, ap = self._active(active)
+        capi.check(self.lib.grlx_agent_step(self._ctx, int(test), ap, float(tau), _ptr(obs, C.c_double), _ptr(reward, C.c_double), tp, _ptr(action, C.c_double)))
+        return action
+
+    def agent_end(self, test: int, obs, reward, active=None, tau: float = 1.0):
+        """Agent::end (agent.h:54-56): the transition into an absorbing state."""
+        obs = self._rows(obs, np.asarray(obs).shape[-1])
+        reward = self._rows(reward)
+        keep, ap = self._active(active)
+        capi.check(self.lib.grlx_agent_end(self._ctx, int(test), ap, float(tau), _ptr(obs, C.c_double), _ptr(reward, C.c_double)))
 
     # Representation::read / write / update (batched rows, applied in order)
     def read(self, replica, idx, table: int = 0):

@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define GRLX_ABI_VERSION 1
+/* 2 (round 4): grlx_config grew test_trials / reserved0 in round 3 and the per-step entry points were added; a binding compiled against
+ * version 1's header must not drive this library (grlx_create would read past the end of its struct). */
+#define GRLX_ABI_VERSION 2
 
 enum {
   GRLX_OK = 0,
@@ -38,8 +40,13 @@ enum { GRLX_ENV_PENDULUM = 0,        /* dynamics/pendulum + task/pendulum/swingu
        GRLX_ENV_CART_POLE = 1,       /* dynamics/cart_pole + task/cart_pole/swingup (cart_pole.cpp)      */
        GRLX_ENV_ACROBOT = 2,         /* dynamics/acrobot + task/acrobot/balancing   (acrobot.cpp)        */
        GRLX_ENV_COMPASS_WALKER = 3,  /* sandbox/compass_walker (walk task)          (compass_walker.cpp) */
-       GRLX_ENV_CART_POLE_BALANCING = 4 /* dynamics/cart_pole + task/cart_pole/balancing (cart_pole.cpp:239-320): the task of the
-                                        reference's tests/cart_pole_balancing-pid.yaml; grlx_env_step only (grlx_create refuses it) */ };
+       GRLX_ENV_CART_POLE_BALANCING = 4,/* dynamics/cart_pole + task/cart_pole/balancing (cart_pole.cpp:239-320): the task of the
+                                        reference's tests/cart_pole_balancing-pid.yaml; grlx_env_step only (grlx_create refuses it) */
+       GRLX_ENV_EXTERNAL = 5         /* no environment in the context: it is the caller's (any grl Environment: gym, a robot, a CPU
+                                        simulator).  Observation dimensions = the projector's input dimensions (minus the action's for
+                                        the Q agents).  Only the per-step agent entry points (grlx_agent_start / _step / _end) and the
+                                        table operators serve such a context; grlx_run, grlx_env_start and grlx_env_advance refuse it.
+                                        The environment fields of grlx_config (control_step, timeout, ...) are not read. */ };
 enum { GRLX_AGENT_SARSA = 0,         /* agent/td + policy/discrete/q + predictor/critic/sarsa (sarsa.cpp)     */
        GRLX_AGENT_Q = 1,             /* ... + predictor/critic/q (advantage.cpp:71-110)                       */
        GRLX_AGENT_AC = 2,            /* policy/action + predictor/ac/action + predictor/critic/td (ac.cpp)    */
@@ -314,6 +321,38 @@ int  grlx_write(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t
 int  grlx_update(grlx_ctx *ctx, int table, const int32_t *replica, const uint32_t *idx, int n,
                  const double *delta);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The per-step plug-in interfaces on the replicas of a context: one call of the reference's interface for EVERY replica per
+ * call, for graphs in which only one side of the loop of OnlineLearningExperiment::run (online_learning.cpp:172-213) lives on the
+ * GPU -- the agent beside an environment of the caller's, or the environment beside an agent of the caller's -- from the first
+ * step of a trial on.  (grlx_run stays the fast path: it fuses both sides.)  Host pointers, [n_replicas] rows each.
+ *   active   NULL = every replica takes part; else only those with a non-zero entry (episodes of different replicas end at
+ *            different steps); the output rows of the others are left as the caller passed them.
+ * The loop is the caller's: trial / step counters, rows and the steps budget are not advanced by these calls.  State between
+ * calls lives where the fused kernels keep it between launches (streams, decay, the predictor's trace), so grlx_run and these
+ * calls can be mixed on one context at trial boundaries. */
+
+/* Environment::start (environment.h:48 -> ModeledEnvironment::start, modeled.cpp:132-158): test = 0 a learning trial's start state,
+ * 1 a test trial's; the start state is drawn from the replica's own random streams; obs[n_replicas][obs_dims]. */
+int  grlx_env_start(grlx_ctx *ctx, int test, const int32_t *active, double *obs);
+/* Environment::step (environment.h:49-51 -> ModeledEnvironment::step, modeled.cpp:160-213) on the replicas' model states:
+ * action[n_replicas] -> obs[n_replicas][obs_dims], reward[n_replicas], terminal[n_replicas] (0, 1 = timed out, 2 = absorbing); tau = 1
+ * (discrete_time).  (grlx_env_step above is the stateless form: explicit states, no context.) */
+int  grlx_env_advance(grlx_ctx *ctx, const int32_t *active, const double *action, double *obs, double *reward, int32_t *terminal);
+/* Agent::start (agent.h:44-47): test = 0 the learning agent (agent/td, td.cpp:50-61: the predictor's trace is cleared -- not the
+ * actor-critic's critic, ac.cpp:170-173 --, time_ = 0, the policy acts), test = 1 the test agent (agent/fixed, fixed.cpp:47-51: the
+ * greedy / noise-free policy over the same tables).  obs[n_replicas][obs_dims] -> action[n_replicas]. */
+int  grlx_agent_start(grlx_ctx *ctx, int test, const int32_t *active, const double *obs, double *action);
+/* Agent::step (agent.h:49-52; td.cpp:63-74: act at obs, then predictor->update(prev_obs, prev_action, tau, reward, obs, action);
+ * fixed.cpp:53-61: act).  tau must be 1.  terminal: NULL, or [n_replicas]: a replica whose entry is 2 gets Agent::end instead
+ * (online_learning.cpp:210-213) and no action. */
+int  grlx_agent_step(grlx_ctx *ctx, int test, const int32_t *active, double tau, const double *obs, const double *reward,
+                     const int32_t *terminal, double *action);
+/* Agent::end (agent.h:54-56; td.cpp:76-81: the update with an empty next action, target = reward; agent/fixed: nothing). */
+int  grlx_agent_end(grlx_ctx *ctx, int test, const int32_t *active, double tau, const double *obs, const double *reward);
+/* Built for agent/td with predictor/critic/{sarsa, q, expected_sarsa} (3 or 5 actions, replacing or no trace, no target network,
+ * safe = 0) and for the actor-critic agent; GRLX_ERR_INVALID otherwise. */
+
 /* device math used by the environments (bit-identical to the documented
  * portable specification): op 0 sin, 1 cos, 2 log, 3 fmod(x, y[i]), 4 sqrt, 5 x/6 (the 3-operation exact form used by RK4),
  * 6 / 7 / 8 the small-angle-aware sin, cos and sin+cos the compass walker uses (bitwise equal to 0 / 1 / their sum) */
@@ -343,8 +382,9 @@ typedef struct {
   double   gamma;                     /* predictor/fqi                                                            */
   int32_t  iterations;
   int32_t  epochs;                    /* representation/iterative:epochs                                          */
-  int32_t  hidden;                    /* representation/parameterized/ann:hiddens = [hidden]; eta = 0 (RPROP)     */
+  int32_t  hidden;                    /* representation/parameterized/ann:hiddens = [hidden]                      */
   int32_t  max_batches;               /* batches reserved (transition store and rows): experiment:batches         */
+  double   eta;                       /* representation/parameterized/ann:eta (ann.cpp:198-221): 0 = RPROP        */
 } grlx_fqi_config;
 typedef struct grlx_fqi_ctx grlx_fqi_ctx;
 /* Fill *cfg with the values of the reference's tests/pendulum-fqi-ann.yaml. */

@@ -16,6 +16,10 @@
 using namespace grl;
 
 REGISTER_CONFIGURABLE(GrlxOnlineLearningExperiment)
+REGISTER_CONFIGURABLE(GrlxBatchLearningExperiment)
+REGISTER_CONFIGURABLE(GrlxTDAgent)
+REGISTER_CONFIGURABLE(GrlxFixedAgent)
+REGISTER_CONFIGURABLE(GrlxModeledEnvironment)
 REGISTER_CONFIGURABLE(GrlxTileCodingProjector)
 
 namespace {
@@ -69,6 +73,9 @@ void GrlxOnlineLearningExperiment::request(ConfigurationRequest *config)
 // register-allocation bug of ROCm 7.2's compiler.  A plain `hipcc -shared` build carries no tag.
 static void requireFilteredBuild()
 {
+  // the structs of include/grlx.h are passed by address: a library of another ABI version would read them with another layout
+  if (grlx_abi_version() != GRLX_ABI_VERSION)
+    throw Exception("libgrlx.so has another ABI version than the grlx.h this addon was compiled against: rebuild the addon");
   const char *tag = grlx_build_pipeline();
   if (!tag || strncmp(tag, "device-asm+mir-exec-prologue-fix/", 33))
     throw Exception(std::string("libgrlx.so was not built by `python -m grl_amd._build` (pipeline tag '") + (tag ? tag : "") +
@@ -153,9 +160,15 @@ void GrlxOnlineLearningExperiment::lower(grlx_config *c) const
     c->max_rows = test_interval_ >= 0 ? trial_cap / (test_interval_ + 1) + 1 : trial_cap + 1;
   }
 
+  lowerEnvironment((*environment_)["model"].ptr(), (*environment_)["task"].ptr(), environment_, c);
+  lowerAgent((*agent_)["policy"].ptr(), (*agent_)["predictor"].ptr(), test_agent_ ? (*test_agent_)["policy"].ptr() : NULL, c);
+  if (c->agent == GRLX_AGENT_AC && !table_log2_capacity_) c->table_log2_capacity = 18;
+}
+
+void GrlxOnlineLearningExperiment::lowerEnvironment(const Configurable *model, const Configurable *task, const Configurable *environment, grlx_config *c)
+{
   // ---- environment/modeled { model, task }
-  const Configurable *model = (*environment_)["model"].ptr(), *task = (*environment_)["task"].ptr();
-  c->discrete_time = (*environment_)["discrete_time"];
+  c->discrete_time = environment ? (*environment)["discrete_time"].i() : 1;
   c->control_step = (*model)["control_step"];
   c->integration_steps = (*model)["integration_steps"];
   if (typeIs(model, "model/dynamical"))
@@ -185,10 +198,11 @@ void GrlxOnlineLearningExperiment::lower(grlx_config *c) const
     throw bad_param(model->path() + ": model not implemented by the fused kernels");
   if (c->env != GRLX_ENV_ACROBOT) c->timeout = (*task)["timeout"];
   if (c->env == GRLX_ENV_PENDULUM || c->env == GRLX_ENV_CART_POLE) c->randomization = (*task)["randomization"];
+}
 
+void GrlxOnlineLearningExperiment::lowerAgent(const Configurable *policy, const Configurable *predictor, const Configurable *test_policy, grlx_config *c)
+{
   // ---- agent/td { policy, predictor }
-  const Configurable *policy = (*agent_)["policy"].ptr(), *predictor = (*agent_)["predictor"].ptr();
-  const Configurable *test_policy = test_agent_ ? (*test_agent_)["policy"].ptr() : NULL;
 
   if (typeIs(predictor, "predictor/ac/action"))
   { // actor-critic (cfg/cart_pole/ac_tc.yaml): mapping/policy/action + predictor/ac/action { critic: predictor/critic/td }
@@ -219,7 +233,6 @@ void GrlxOnlineLearningExperiment::lower(grlx_config *c) const
     c->ac_decay_min = (*policy)["decay_min"];
     c->ac_update_method = (*predictor)["update_method"].str() == "proportional" ? 0 : 1;
     c->ac_step_limit = first((*predictor)["step_limit"].v(), -1.);
-    if (!c->table_log2_capacity) c->table_log2_capacity = 18;
     return;
   }
 
@@ -353,6 +366,243 @@ LargeVector GrlxOnlineLearningExperiment::run()
   LargeVector result;
   toVector(curve, result);
   return result;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// experiment/batch_learning/grlx: the reference's BatchLearningExperiment (batch_learning.cpp:36-205) with predictor/fqi over
+// representation/iterative + representation/parameterized/ann and projector/pre/normalizing, lowered to a grlx_fqi_config.
+
+void GrlxBatchLearningExperiment::request(ConfigurationRequest *config)
+{ // mirrors BatchLearningExperiment::request (batch_learning.cpp:38-58); the sampling box is the task's (observation / action limits)
+  config->push_back(CRP("runs", "Number of separate learning runs to perform", runs_, CRP::Configuration, 1, 1));
+  config->push_back(CRP("batches", "Number of batches per learning run", batches_, CRP::Configuration, 1));
+  config->push_back(CRP("batch_size", "Number of transitions per batch", batch_size_, CRP::Configuration, 1));
+  config->push_back(CRP("output", "Output base filename", output_));
+  config->push_back(CRP("replicas", "Independent-seed replicas run side by side on the GPU", replicas_, CRP::Configuration, 1));
+  config->push_back(CRP("seed", "Seed of replica 0 (replica i uses seed+i)", seed_));
+  config->push_back(CRP("model", "model", "Model in which the task is set (model/dynamical over dynamics/pendulum)", model_));
+  config->push_back(CRP("task", "task", "Task to be solved (task/pendulum/swingup: it must support invert())", task_));
+  config->push_back(CRP("predictor", "predictor", "Learner (predictor/fqi)", predictor_));
+  config->push_back(CRP("test_agent", "agent", "Agent to use in test trials after each batch (agent/fixed over the predictor's objects)", test_agent_));
+}
+
+void GrlxBatchLearningExperiment::configure(Configuration &config)
+{
+  requireFilteredBuild();
+  model_ = config["model"].ptr();
+  task_ = config["task"].ptr();
+  predictor_ = config["predictor"].ptr();
+  test_agent_ = config["test_agent"].ptr();
+  runs_ = config["runs"];
+  batches_ = config["batches"];
+  batch_size_ = config["batch_size"];
+  output_ = config["output"].str();
+  replicas_ = config["replicas"];
+  seed_ = config["seed"];
+  if (!typeIs(predictor_, "predictor/fqi")) throw bad_param("experiment/batch_learning/grlx:predictor (must be predictor/fqi)");
+  if (!typeIs(test_agent_, "agent/fixed")) throw bad_param("experiment/batch_learning/grlx:test_agent (must be agent/fixed)");
+}
+
+void GrlxBatchLearningExperiment::lower(grlx_fqi_config *c) const
+{
+  grlx_fqi_config_pendulum(c);
+  c->n_replicas = replicas_;
+  if (!typeIs(model_, "model/dynamical") || !typeIs((*model_)["dynamics"].ptr(), "dynamics/pendulum") || !typeIs(task_, "task/pendulum/swingup"))
+    throw bad_param(model_->path() + ": the batch path is built for model/dynamical with dynamics/pendulum and task/pendulum/swingup");
+  if ((*task_)["randomization"].d() != 0) throw bad_param(task_->path() + ":randomization (must be 0)");
+  c->control_step = (*model_)["control_step"];
+  c->integration_steps = (*model_)["integration_steps"];
+  c->timeout = (*task_)["timeout"];
+  const Configurable *discretizer = (*predictor_)["discretizer"].ptr(), *projector = (*predictor_)["projector"].ptr(),
+                     *representation = (*predictor_)["representation"].ptr();
+  if (!typeIs(discretizer, "discretizer/uniform")) throw bad_param(discretizer->path() + ": discretizer/uniform expected");
+  const LargeVector dmin = (*discretizer)["min"].v(), dmax = (*discretizer)["max"].v(), dsteps = (*discretizer)["steps"].v();
+  if (dmin.size() != 1 || dmax.size() != 1 || dsteps.size() != 1) throw bad_param(discretizer->path() + ": one action dimension supported");
+  c->action_min = dmin[0];
+  c->action_max = dmax[0];
+  c->action_steps = (int)dsteps[0];
+  if (!typeIs(projector, "projector/pre/normalizing") || !typeIs((*projector)["projector"].ptr(), "projector/identity") || (*projector)["signed"].i() != 0)
+    throw bad_param(projector->path() + ": projector/pre/normalizing (signed = 0) over projector/identity expected");
+  // (the limits are the task's observation ++ action limits: a yaml that adds them element-wise, as tests/pendulum-fqi-ann.yaml does under
+  //  today's parser, would be refused by NormalizingProjector::project at the first sample anyway; the kernels scale by the task's limits)
+  if (!typeIs(representation, "representation/iterative")) throw bad_param(representation->path() + ": representation/iterative expected");
+  const Configurable *ann = (*representation)["representation"].ptr();
+  if (!typeIs(ann, "representation/parameterized/ann")) throw bad_param(ann->path() + ": representation/parameterized/ann expected");
+  if ((*representation)["cumulative"].i() != 0 || (*representation)["batch_size"].i() != 0)
+    throw bad_param(representation->path() + ": cumulative = 0 and batch_size = 0 (the whole data set per epoch)");
+  const LargeVector hiddens = (*ann)["hiddens"].v();
+  if (hiddens.size() != 1 || (*ann)["outputs"].i() != 1 || (*ann)["inputs"].i() != 3) throw bad_param(ann->path() + ": a 3-H-1 network (one hidden layer)");
+  c->hidden = (int)round(hiddens[0]);
+  c->eta = (*ann)["eta"];
+  c->epochs = (*representation)["epochs"];
+  c->gamma = (*predictor_)["gamma"];
+  c->iterations = (*predictor_)["iterations"];
+  if ((*predictor_)["reset_strategy"].str() != "never" || (*predictor_)["macro_batch_size"].i() != 1)
+    throw bad_param(predictor_->path() + ": reset_strategy never and macro_batch_size 1");
+  c->batch_size = batch_size_;
+  c->max_batches = batches_;
+  if ((long long)batches_ * batch_size_ > (long long)(*predictor_)["transitions"].i())
+    throw bad_param(predictor_->path() + ":transitions (smaller than batches x batch_size)");
+  const Configurable *tp = (*test_agent_)["policy"].ptr();
+  if ((*tp)["discretizer"].ptr() != discretizer || (*tp)["projector"].ptr() != projector || (*tp)["representation"].ptr() != representation ||
+      !typeIs((*tp)["sampler"].ptr(), "sampler/greedy"))
+    throw bad_param(test_agent_->path() + ": the test policy must be the greedy Q policy over the predictor's discretizer, projector and representation");
+}
+
+LargeVector GrlxBatchLearningExperiment::run()
+{
+  grlx_fqi_config c;
+  lower(&c);
+  std::vector<int64_t> seeds(replicas_);
+  for (int i = 0; i < replicas_; ++i) seeds[i] = (int64_t)seed_ + i;
+  grlx_fqi_ctx *ctx = NULL;
+  check(grlx_fqi_create(&c, &seeds[0], &ctx));
+  std::vector<double> curve;
+  try
+  {
+    std::vector<std::ofstream> files(replicas_);
+    if (!output_.empty())
+      for (int i = 0; i < replicas_; ++i)
+      {
+        std::ostringstream name;
+        name << output_ << "-0";
+        if (replicas_ > 1) name << "@" << i;
+        name << ".txt";
+        files[i].open(name.str().c_str());
+      }
+    for (int bb = 0; bb < batches_; ++bb)
+    { // batch_learning.cpp:105-188: one batch of samples, FQIPredictor::rebuild, one greedy test trial -> one row
+      check(grlx_fqi_run_batch(ctx, NULL));
+      check(grlx_fqi_sync(ctx, NULL));
+      for (int i = 0; i < replicas_; ++i)
+      {
+        int64_t batch = 0, transitions = 0;
+        double reward = 0;
+        check(grlx_fqi_read_rows(ctx, i, bb, 1, &batch, &transitions, &reward));
+        std::ostringstream oss;
+        oss << std::setw(15) << batch << std::setw(15) << transitions << std::setw(15) << reward;        // :179
+        if (files[i].is_open()) files[i] << oss.str() << std::endl;
+        if (i == 0) { INFO(oss.str()); curve.push_back(reward); }
+      }
+    }
+  }
+  catch (...)
+  {
+    grlx_fqi_destroy(ctx);
+    throw;
+  }
+  grlx_fqi_destroy(ctx);
+  LargeVector result;
+  toVector(curve, result);
+  return result;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The per-step side: a grl graph keeps its own loop (experiment/online_learning, or anything that drives Agent / Environment) and puts
+// ONE of the two objects on the GPU.  One replica per object; every call is one kernel launch plus the copies of its arguments.
+
+void GrlxTDAgent::request(ConfigurationRequest *config)
+{ // agent/td (td.cpp:36-41) + what the device context needs
+  config->push_back(CRP("policy", "mapping/policy", "Control policy (mapping/policy/discrete/value/q or mapping/policy/action over tile coding)", policy_));
+  config->push_back(CRP("predictor", "predictor", "Value function predictor (predictor/critic/{sarsa,q,expected_sarsa} or predictor/ac/action)", predictor_));
+  config->push_back(CRP("seed", "Seed of the agent's random streams (what `grld -s` seeds)", seed_));
+  config->push_back(CRP("table_log2_capacity", "Sparse weight table slots = 2^this (0 = default)", table_log2_capacity_, CRP::Configuration, 0, 26));
+}
+
+void GrlxTDAgent::configure(Configuration &config)
+{
+  requireFilteredBuild();
+  policy_ = config["policy"].ptr();
+  predictor_ = config["predictor"].ptr();
+  seed_ = config["seed"];
+  table_log2_capacity_ = config["table_log2_capacity"];
+  grlx_config c;
+  grlx_config_pendulum_sarsa(&c);
+  c.env = GRLX_ENV_EXTERNAL;                         // the environment is another object of the graph
+  c.n_replicas = 1;
+  c.table_log2_capacity = table_log2_capacity_;
+  GrlxOnlineLearningExperiment::lowerAgent(policy_, predictor_, NULL, &c);
+  const int64_t seed = seed_;
+  check(grlx_create(&c, &seed, &ctx_));
+}
+
+static void agentCall(grlx_ctx *ctx, int mode, int test, double tau, const Observation &obs, double reward, Action *action)
+{
+  std::vector<double> o(obs.v.size());
+  for (size_t i = 0; i < (size_t)obs.v.size(); ++i) o[i] = obs.v[i];
+  double a = (action && action->v.size()) ? action->v[0] : 0.;
+  if (mode == 0) check(grlx_agent_start(ctx, test, NULL, &o[0], &a));
+  else if (mode == 1) check(grlx_agent_step(ctx, test, NULL, tau, &o[0], &reward, NULL, &a));
+  else check(grlx_agent_end(ctx, test, NULL, tau, &o[0], &reward));
+  if (action)
+  {
+    action->v = VectorConstructor(a);
+    action->type = atUndefined;                      // (exploration is decided on the device; the type flag is informational)
+  }
+}
+
+void GrlxTDAgent::start(const Observation &obs, Action *action) { agentCall(ctx_, 0, 0, 0., obs, 0., action); }
+void GrlxTDAgent::step(double tau, const Observation &obs, double reward, Action *action) { agentCall(ctx_, 1, 0, tau, obs, reward, action); }
+void GrlxTDAgent::end(double tau, const Observation &obs, double reward) { agentCall(ctx_, 2, 0, tau, obs, reward, NULL); }
+
+void GrlxFixedAgent::request(ConfigurationRequest *config)
+{
+  config->push_back(CRP("agent", "agent/td/grlx", "The learning agent whose tables the test policy reads", agent_));
+}
+
+void GrlxFixedAgent::configure(Configuration &config)
+{
+  agent_ = dynamic_cast<GrlxTDAgent *>((Configurable *)config["agent"].ptr());
+  if (!agent_) throw bad_param("agent/fixed/grlx:agent (must be an agent/td/grlx)");
+}
+
+void GrlxFixedAgent::start(const Observation &obs, Action *action) { agentCall(agent_->context(), 0, 1, 0., obs, 0., action); }
+void GrlxFixedAgent::step(double tau, const Observation &obs, double reward, Action *action) { agentCall(agent_->context(), 1, 1, tau, obs, reward, action); }
+void GrlxFixedAgent::end(double tau, const Observation &obs, double reward) { agentCall(agent_->context(), 2, 1, tau, obs, reward, NULL); }
+
+void GrlxModeledEnvironment::request(ConfigurationRequest *config)
+{ // environment/modeled (modeled.cpp:37-65) without window / delta / exporter
+  config->push_back(CRP("model", "model", "Environment model", model_));
+  config->push_back(CRP("task", "task", "Task to perform in the environment (should match model)", task_));
+  config->push_back(CRP("seed", "Seed of the environment's random streams", seed_));
+}
+
+void GrlxModeledEnvironment::configure(Configuration &config)
+{
+  requireFilteredBuild();
+  model_ = config["model"].ptr();
+  task_ = config["task"].ptr();
+  seed_ = config["seed"];
+  grlx_config c;
+  grlx_config_pendulum_sarsa(&c);                    // a context needs an agent block: the default one, never stepped here
+  GrlxOnlineLearningExperiment::lowerEnvironment(model_, task_, NULL, &c);
+  int sd = 0;
+  check(grlx_env_dims(c.env, &sd, &obs_dims_));
+  c.projector.dims = obs_dims_ + 1;
+  for (int i = 0; i < GRLX_MAX_DIMS; ++i) { c.projector.resolution[i] = 1.; c.projector.wrapping[i] = 0.; }
+  c.n_replicas = 1;
+  const int64_t seed = seed_;
+  check(grlx_create(&c, &seed, &ctx_));
+}
+
+void GrlxModeledEnvironment::start(int test, Observation *obs)
+{
+  std::vector<double> o(obs_dims_);
+  check(grlx_env_start(ctx_, test, NULL, &o[0]));
+  toVector(o, obs->v);
+  obs->absorbing = false;
+}
+
+double GrlxModeledEnvironment::step(const Action &action, Observation *obs, double *reward, int *terminal)
+{
+  std::vector<double> o(obs_dims_);
+  const double a = action.v[0];
+  int32_t term = 0;
+  check(grlx_env_advance(ctx_, NULL, &a, &o[0], reward, &term));
+  toVector(o, obs->v);
+  obs->absorbing = term == 2;
+  *terminal = term;
+  return 1.;                                         // discrete_time (modeled.cpp:209-212)
 }
 
 // ---------------------------------------------------------------------------------------------------------------

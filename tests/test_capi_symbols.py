@@ -9,10 +9,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "grlx.h")).read()
+def declared_functions(header="grlx.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(grlx_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_functions(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("grlx_")})
 
 
 def test_exports_every_declared_symbol(grlx):
@@ -23,6 +29,14 @@ def test_exports_every_declared_symbol(grlx):
         assert hasattr(lib, n), f"{n} declared in include/grlx.h but not exported"
     # and the Python binding covers them all
     assert set(names) == set(grlx.capi._SIGS.keys())
+
+
+def test_every_exported_symbol_is_declared(grlx):
+    """exported == declared: the boundary in include/grlx.h, the diagnostics in include/grlx_diag.h, nothing else."""
+    diag = declared_functions("grlx_diag.h")
+    assert diag and not set(diag) & set(declared_functions())
+    assert exported_functions(grlx.capi.lib_path()) == sorted(set(declared_functions()) | set(diag))
+    assert set(diag) == set(grlx.capi._DIAG_SIGS.keys())
 
 
 def test_struct_layout_matches_header(grlx):

@@ -74,8 +74,9 @@ def test_copies_in_front_of_the_restore_move_behind_it():
     lines = [l.strip() for l in out.split("\n")]
     i = lines.index("s_or_b64 exec, exec, s[26:27]")
     assert lines[i - 1] == "s_mov_b64 s[76:77], s[60:61]"
-    assert lines[i + 1:i + 3] == ["v_mov_b32_e32 v198, v239", "v_accvgpr_write_b32 a21, v135"]
-    assert sorted(lines) == sorted(l.strip() for l in ASM.strip("\n").split("\n"))        # nothing added or lost
+    assert lines[i + 1:i + 4] == ["v_mov_b32_e32 v198, v239", "v_accvgpr_write_b32 a21, v135", "s_nop 4"]
+    # nothing lost, and nothing added but the wait states behind the moved copies (the hazard recogniser ran before this filter)
+    assert sorted(lines) == sorted([l.strip() for l in ASM.strip("\n").split("\n")] + ["s_nop 4"])
 
 
 def test_the_copy_of_a_then_block_is_left_alone_even_when_the_assembly_merged_it_with_the_join():
@@ -200,7 +201,49 @@ def test_dependencies_a_moved_copy_would_cross_stop_the_build():
     assert new is None and "exec or vcc" in why
     # the same instructions in an order the move does not disturb are fine (the scalar comes FIRST and stays first)
     new, why = _asm_only("\ts_mov_b32 s4, s9\n\tv_mov_b32_e32 v3, s4\n\ts_waitcnt lgkmcnt(0)\n\ts_or_b64 exec, exec, s[8:9]\n\tv_add_u32_e32 v1, v3, v3")
-    assert why is None and [l.strip() for l in new] == ["s_mov_b32 s4, s9", "s_waitcnt lgkmcnt(0)", "s_or_b64 exec, exec, s[8:9]", "v_mov_b32_e32 v3, s4", "v_add_u32_e32 v1, v3, v3"]
+    assert why is None and [l.strip() for l in new] == ["s_mov_b32 s4, s9", "s_waitcnt lgkmcnt(0)", "s_or_b64 exec, exec, s[8:9]", "v_mov_b32_e32 v3, s4", "s_nop 4", "v_add_u32_e32 v1, v3, v3"]
+
+
+def test_wait_states_follow_the_moved_copies():
+    """The copies end up directly in front of the block's next instruction, after the compiler's hazard recogniser has run: a
+    v_readlane / DPP / matrix-core read of a moved destination would be closer to its write than the hardware allows."""
+    new, why = _asm_only("\tv_mov_b32_e32 v3, v9\n\ts_or_b64 exec, exec, s[8:9]\n\tv_readlane_b32 s4, v3, 2")
+    assert why is None and [l.strip() for l in new] == ["s_or_b64 exec, exec, s[8:9]", "v_mov_b32_e32 v3, v9", "s_nop 4", "v_readlane_b32 s4, v3, 2"]
+
+
+def test_other_exec_writes_behind_mask_dependent_code_fail_closed():
+    """`$exec = S_MOV_B64 ..` / `S_XOR_B64 ..` at the head of a block may restore lanes as well as take them away: with
+    mask-dependent instructions in front the build stops -- unless the value is visibly the current mask AND something."""
+    for restore in ("$exec = S_MOV_B64 killed renamable $sgpr26_sgpr27", "$exec = S_XOR_B64 $exec, killed renamable $sgpr26_sgpr27, implicit-def $scc",
+                    "$exec = S_MOV_B64_term killed renamable $sgpr26_sgpr27", "$exec = S_OR_B64 killed renamable $sgpr2_sgpr3, killed renamable $sgpr26_sgpr27, implicit-def $scc"):
+        m = "\nbb.3:\n  renamable $vgpr198 = COPY renamable $vgpr239\n  " + restore + "\n"
+        found, problems = ep.find_misplaced(mir(m))
+        assert found == [] and len(problems) == 1 and "may widen" in problems[0] and "bb.3" in problems[0], (restore, problems)
+        # only scalar code in front: nothing to complain about
+        m = "\nbb.3:\n  renamable $sgpr76 = S_MOV_B32 -32\n  " + restore + "\n"
+        assert ep.find_misplaced(mir(m)) == ([], [])
+    # the lowering of an `if`: the new mask is (a copy of) the current one AND a condition
+    m = """
+bb.3:
+  renamable $sgpr2_sgpr3 = COPY $exec
+  renamable $vcc = V_CMP_LT_U32_e64 $vgpr22, $vgpr8, implicit $exec
+  renamable $sgpr0_sgpr1 = S_AND_B64 renamable $sgpr2_sgpr3, killed renamable $vcc, implicit-def dead $scc
+  $exec = S_MOV_B64_term killed renamable $sgpr0_sgpr1
+bb.4:
+  renamable $vcc = V_CMP_LT_U32_e64 $vgpr22, $vgpr8, implicit $exec
+  renamable $sgpr0_sgpr1 = S_ANDN2_B64 $exec, killed renamable $vcc, implicit-def dead $scc
+  $exec = S_MOV_B64_term killed renamable $sgpr0_sgpr1
+"""
+    assert ep.find_misplaced(mir(m)) == ([], [])
+    # ... but not a value that merely passed through an AND with something that is not the mask
+    m = """
+bb.3:
+  renamable $vcc = V_CMP_LT_U32_e64 $vgpr22, $vgpr8, implicit $exec
+  renamable $sgpr0_sgpr1 = S_AND_B64 renamable $sgpr8_sgpr9, killed renamable $vcc, implicit-def dead $scc
+  $exec = S_MOV_B64_term killed renamable $sgpr0_sgpr1
+"""
+    found, problems = ep.find_misplaced(mir(m))
+    assert found == [] and len(problems) == 1
 
 
 def test_the_assembly_must_hold_what_the_machine_code_named():

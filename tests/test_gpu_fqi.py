@@ -121,3 +121,30 @@ def test_fqi_validation(grlx):
         r.run_batch()
     assert ei.value.code == capi.ERR_ROWS_FULL
     r.close()
+
+
+def test_fqi_reference_yaml_through_the_deployer(grlx, tmp_path):
+    """`grlxd -s 1 tests/pendulum-fqi-ann.yaml` (the reference's own file, unmodified): experiment/batch_learning in the C++ host layer
+    lowers the graph to a grlx_fqi_config and writes `<output>-0.txt` -- the two rows test_fqi_reference_yaml_first_row checks: the first
+    is the template's first row byte for byte, both equal the oracle's."""
+    import os
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    yaml = os.path.join(os.path.dirname(__file__), "golden", "pendulum-fqi-ann.yaml")
+    res = subprocess.run([grlxd, "-s", "1", yaml], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    e = ob.FqiExperiment(ob.pendulum_fqi_spec(), seed=1)
+    want = "".join(e.format_row(e.run_batch()) for _ in range(2))
+    e.close()
+    got = (tmp_path / "pendulum-fqi-ann-0.txt").read_text()
+    assert got == want and res.stdout == want
+    template = open(os.path.join(os.path.dirname(__file__), "golden", "pendulum-fqi-ann-0.txt")).read().splitlines()
+    assert got.splitlines()[0] == template[0]
+    # clones: `-r 3` runs seeds 1, 2, 3 and writes <output>-0@i.txt (multi.cpp:52-56); clone 0 is the run above
+    res = subprocess.run([grlxd, "-s", "1", "-r", "3", "-q", yaml], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert (tmp_path / "pendulum-fqi-ann-0@0.txt").read_text() == want
+    e = ob.FqiExperiment(ob.pendulum_fqi_spec(), seed=3)
+    assert (tmp_path / "pendulum-fqi-ann-0@2.txt").read_text() == "".join(e.format_row(e.run_batch()) for _ in range(2))
+    e.close()

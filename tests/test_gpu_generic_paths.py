@@ -438,6 +438,30 @@ def test_results_do_not_depend_on_stale_register_content(grlx, monkeypatch, patt
 
 
 # ------------------------------------------------ sparse tables that grow between launches ---
+def test_tables_grow_between_the_launches_of_one_call(grlx):
+    """A deployer runs a whole run as ONE grlx_run, which the library chunks into launches of 32 trials: the tables must grow BETWEEN those
+    launches too (a launch cannot grow them).  The cart-pole actor-critic's tables start at 2^16 entries per replica (grlx_config_cart_pole_ac)
+    and 32 trials create about 25 000 slots per table: 230 trials in one call ended with GRLX_ERR_TABLE_FULL before round 4."""
+    from tests import configs
+    n, trials = 5, 230
+    cfg, spec = configs.cart_pole_ac(grlx, n)
+    assert cfg.table_log2_capacity == 16
+    cfg.max_rows = trials // 11 + 1
+    seeds = np.arange(41, 41 + n)
+    r = grlx.Runner(cfg, seeds)
+    r.run(trials); r.sync()                                         # ONE call, no sync in between
+    assert r.table_capacity() >= 18, r.table_capacity()
+    for k in (0, 4):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows, _ = e.run(trials)
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        assert list(r.rng(k))[:2] == list(e.rng())[:2]
+        e.close()
+    r.close()
+
+
 @pytest.mark.parametrize("kind", ["pendulum_sarsa", "pendulum_wide", "cart_pole_ac", "cart_pole_ac_wide", "target_network", "accumulating"])
 def test_tables_grow_between_launches(grlx, kind):
     """grlx_config.table_log2_capacity is the INITIAL size: started at 2^13 entries per replica, with a grlx_sync between

@@ -607,6 +607,21 @@ def test_deployer_reproduces_golden_file(grlx, tmp_path):
     assert (tmp_path / "pendulum-sarsa-tc-0@2.txt").read_text() != first
 
 
+def test_host_layer_steps_the_experiments_objects(grlx, tmp_path):
+    """The host layer's per-step objects (grl_amd/csrc/host/objects.h: StepwiseEnvironment / StepwiseAgent of an experiment/online_learning):
+    `grlx_ops stepwise` runs the loop of OnlineLearningExperiment::run on the HOST over them -- Environment::start / step and
+    Agent::start / step / end forwarded to grlx_env_start / _advance and grlx_agent_start / _step / _end, all replicas per call -- on the
+    reference's own yaml: the rows of replica 0 are the golden file's."""
+    import subprocess
+    from grl_amd import _build
+    _build.build_host()
+    yaml = os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml")
+    (tmp_path / "in.txt").write_text("1 3 33\n")
+    res = subprocess.run([_build.GRLX_OPS, "stepwise", yaml, "experiment", str(tmp_path / "in.txt")], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout == "".join(open(GOLDEN).readlines()[:3])
+
+
 def test_deployer_experiment_multi(grlx, tmp_path):
     """experiment/multi (multi.cpp:36-75): `instances` clones side by side, outputs named <output>-<run>@<i>.txt.
     Here the clones are replicas of one device context, instance i seeded seed + i."""

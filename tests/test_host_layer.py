@@ -179,3 +179,63 @@ experiment:
         assert res.returncode == 1 and "no HIP device" in res.stderr, res.stderr
     else:
         assert res.returncode == 0, res.stderr
+
+
+FQI_YAML = os.path.join(ROOT, "tests", "golden", "pendulum-fqi-ann.yaml")
+
+
+def test_instantiates_reference_fqi_yaml(grlxd, tmp_path):
+    """tests/pendulum-fqi-ann.yaml of the reference, unmodified: experiment/batch_learning + predictor/fqi + representation/iterative +
+    representation/parameterized/ann over projector/pre/normalizing.  Its `a+b` expressions over references are evaluated as the
+    reference's parser evaluates them (parser.cpp:49-134: element-wise with the scalar broadcast -- two entries for input_min, the yaml's
+    own defect, deviation D4), integers add, and without a GPU the deployer stops at the device, never at the configuration."""
+    from grl_amd import capi
+    res = run(grlxd, ["-s", "1", "-q", FQI_YAML], tmp_path)
+    dumped = (tmp_path / "pendulum-fqi-ann.yaml").read_text()
+    assert "type: experiment/batch_learning" in dumped and "type: predictor/fqi" in dumped and "type: representation/parameterized/ann" in dumped
+    assert "input_min: [ -3, -40.699111843077517 ]" in dumped and "input_max: [ 9.2831853071795862, 40.699111843077517 ]" in dumped
+    assert "inputs: 3" in dumped and "hiddens: [ 20 ]" in dumped
+    assert "projector: experiment/predictor/projector" in dumped                      # the test policy refers to the predictor's objects
+    assert "deviation D4" in res.stderr and "outside the accelerated path" not in res.stderr
+    if capi.load().grlx_device_count() == 0:
+        assert res.returncode == 1 and "no HIP device" in res.stderr
+
+
+@pytest.mark.parametrize("old,new,needle", [
+    ("hiddens: [ 20 ]", "hiddens: [ 20, 20 ]", "one hidden layer"),
+    ("hiddens: [ 20 ]", "hiddens: [ 0 ]", "representation/parameterized/ann:hiddens"),                 # ann.cpp:74-75
+    ("cumulative: 0", "cumulative: 1", "cumulative = 0"),
+    ("reset_strategy: never", "reset_strategy: sometimes", "predictor/fqi:reset_strategy"),             # fqi.cpp:66-69
+    ("reset_strategy: never", "reset_strategy: batch", "reset_strategy must be never"),
+    ("transitions: 100000", "transitions: 1500", "transitions (the store's size)"),
+    ("batches: 2", "batches: 0", "batches must be > 0"),
+    ("type: dynamics/pendulum", "type: dynamics/cart_pole", "built for model/dynamical with dynamics/pendulum"),
+    ("steps: [3]", "steps: [3, 3]", "discretizer/uniform:{min,max,steps}"),
+    ("inputs: experiment/task/observation_dims+experiment/task/action_dims", "inputs: 2", "inputs must be observation_dims+action_dims"),
+])
+def test_bad_batch_configurations_are_refused(grlxd, tmp_path, old, new, needle):
+    text = open(FQI_YAML).read()
+    assert old in text
+    p = tmp_path / "variant.yaml"
+    p.write_text(text.replace(old, new))
+    res = run(grlxd, ["-s", "1", "-q", str(p)], tmp_path)
+    assert res.returncode == 1
+    assert needle in res.stderr, res.stderr
+
+
+def test_expressions_over_references(grlxd, tmp_path):
+    """parser.cpp:49-134 on the values of referenced parameters: + - * element-wise with a scalar broadcast, ++ concatenation; a vector
+    size mismatch is an error, as in the reference."""
+    text = open(FQI_YAML).read()
+    ok = text.replace("input_min: experiment/task/observation_min+experiment/task/action_min", "input_min: experiment/task/observation_min++experiment/task/action_min") \
+             .replace("input_max: experiment/task/observation_max+experiment/task/action_max", "input_max: experiment/task/observation_max++experiment/task/action_max")
+    p = tmp_path / "concat.yaml"
+    p.write_text(ok)
+    res = run(grlxd, ["-s", "1", "-q", str(p)], tmp_path)
+    dumped = (tmp_path / "pendulum-fqi-ann.yaml").read_text()
+    assert "input_min: [ 0, -37.699111843077517, -3 ]" in dumped and "deviation D4" not in res.stderr
+    bad = text.replace("input_min: experiment/task/observation_min+experiment/task/action_min", "input_min: experiment/task/observation_min*[1, 2, 3]")
+    p = tmp_path / "mismatch.yaml"
+    p.write_text(bad)
+    res = run(grlxd, ["-s", "1", "-q", str(p)], tmp_path)
+    assert res.returncode == 1 and "vector size mismatch" in res.stderr
