@@ -52,6 +52,7 @@ struct FqiParams {
   double   in_min[kFqiNIn], in_scale[kFqiNIn], obs_min[kFqiD], obs_range[kFqiD];
   double   action_min, action_range;
   double   gamma_tau;
+  double   eta;                                     // representation/parameterized/ann:eta (0: RPROP, > 0: gradient descent, < 0: RMSprop)
   FqiRep  *rep;
   double  *in, *next_obs, *reward, *targets;        // [R][cap][...]
   int32_t *absorbing;
@@ -65,32 +66,40 @@ struct FqiParams {
 };
 
 // ANNRepresentation::read (ann.cpp:133-160): net input ((w0 a0 + w1 a1) + w2 a2) + bias, logistic hidden layer, linear output.
-// Written stage by stage over the H hidden units (per unit the operations and their order are those of the scalar text:
-// oracle/fqi.c ann_forward): H independent chains for the wave to overlap -- a branchy exp per unit serialises them.
+// Written stage by stage over the hidden units (per unit the operations and their order are those of the scalar text:
+// oracle/fqi.c ann_forward): independent chains for the wave to overlap -- a branchy exp per unit serialises them.  Up to 20
+// units are one batch; wider layers go 16 at a time (two batches of stage values would not fit the registers), the output sum
+// still adds the units in their order.  a_out: registers (H <= 20) or the lane's row of the factor tile in LDS.
 template <int H>
 __device__ __forceinline__ double ann_forward(const double *w, const double (&in)[kFqiNIn], double *a_out)
 {
+  constexpr int CH = (H <= 20) ? H : 16;
+  static_assert(H % CH == 0, "hidden units per batch");
   const double *W2 = w + (kFqiNIn + 1) * H;
-  double net[H], e[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h)
-  {
-    double v = 0;
-#pragma unroll
-    for (int i = 0; i < kFqiNIn; ++i) v += w[h * (kFqiNIn + 1) + i] * in[i];
-    v += w[h * (kFqiNIn + 1) + kFqiNIn];
-    net[h] = -v;
-  }
-  pexp_batch<H>(net, e);
   double out = 0;
 #pragma unroll
-  for (int h = 0; h < H; ++h) net[h] = 1. + e[h];
-  pdiv_batch<H>(1., net, e);                                    // a = 1 / (1 + exp(-net)), ann.h:108-111
-#pragma unroll
-  for (int h = 0; h < H; ++h)
+  for (int h0 = 0; h0 < H; h0 += CH)
   {
-    if (a_out) a_out[h] = e[h];
-    out += W2[h] * e[h];
+    double net[CH], e[CH];
+#pragma unroll
+    for (int h = 0; h < CH; ++h)
+    {
+      double v = 0;
+#pragma unroll
+      for (int i = 0; i < kFqiNIn; ++i) v += w[(h0 + h) * (kFqiNIn + 1) + i] * in[i];
+      v += w[(h0 + h) * (kFqiNIn + 1) + kFqiNIn];
+      net[h] = -v;
+    }
+    pexp_batch<CH>(net, e);
+#pragma unroll
+    for (int h = 0; h < CH; ++h) net[h] = 1. + e[h];
+    pdiv_batch<CH>(1., net, e);                                   // a = 1 / (1 + exp(-net)), ann.h:108-111
+#pragma unroll
+    for (int h = 0; h < CH; ++h)
+    {
+      if (a_out) a_out[h0 + h] = e[h];
+      out += W2[h0 + h] * e[h];
+    }
   }
   out += W2[H];
   return out;
@@ -103,7 +112,7 @@ __device__ __forceinline__ void fqi_normalise(const FqiParams &F, const double *
   in[kFqiD] = (action - F.in_min[kFqiD]) * F.in_scale[kFqiD] - 0;
 }
 
-// weights: w[i] = 0.01 * (2 u_i - 1) from the initialisation stream (fqi.c D1); eta = 0.1 (RPROP, ann.cpp:108-109)
+// weights: w[i] = 0.01 * (2 u_i - 1) from the initialisation stream (fqi.c D1); eta = Ones, x 0.1 for RPROP (ann.cpp:106-109)
 __global__ void fqi_init_kernel(FqiParams F, const uint64_t *r0)
 {
   const int r = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,7 +120,7 @@ __global__ void fqi_init_kernel(FqiParams F, const uint64_t *r0)
   double *net = F.net + (size_t)r * 4 * F.P;
   const uint64_t x = lcg_next(lcg_jump(r0[r], (uint64_t)k));
   net[k] = (2 * lcg_double(x) - 1) * 0.01;
-  net[F.P + k] = 1. * 0.1;
+  net[F.P + k] = (F.eta == 0) ? 1. * 0.1 : 1.;
   net[2 * F.P + k] = 0;
   net[3 * F.P + k] = 0;
 }
@@ -235,7 +244,8 @@ __global__ __launch_bounds__(256) void fqi_targets_kernel(FqiParams F, int first
 // Level 2 is the mapping: wave (replica r, L) walks ITS chunks in order and keeps its partial sums in registers -- no
 // per-chunk sums ever reach memory (round 2 wrote and re-read 41 MB of them per epoch at 16 x 200 000 transitions, in two
 // launches per epoch whose dispatch gaps were a quarter of the time).  A block = 4 waves = 4 consecutive L of one replica;
-// 16 blocks per replica; 16 replicas fill the 256 CUs with one block each (93 KB of LDS per block: four factor tiles).
+// 16 blocks per replica; 16 replicas fill the 256 CUs with one block each (93 KB of LDS per block: four factor tiles) -- for the
+// 20 hidden units of the reference's file; FqiShape<H> gives the numbers of the other instantiated widths (8, 16, 32, 64).
 // One wave per SIMD means nothing but the wave's own instruction-level parallelism hides latency: the forward pass is
 // written stage by stage over the 20 hidden units (pexp_batch, pdiv_batch: grlx_math.h), the next chunk's inputs are
 // loaded while the current one is computed.
@@ -292,41 +302,66 @@ __device__ __forceinline__ double fqi_row_shl(double v)
   return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
 }
 
-constexpr int kFqiCols = 2 * 20 + kFqiNIn + 2;       // in[3], d1[H], a[H], d2, 1.0  (H = 20)
-constexpr int kFqiBlocksPerReplica = 16;             // x 4 waves = the 64 partial sums of level 2
-template <int H>
-__global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_first, int epochs)
+// The shape of the epochs kernel for H hidden units.  A lane sums KP parameters (lane, lane + 64, ...: P + 1 <= 64 KP, the extra one
+// is the squared error); a wave's factor tile is 64 samples x COLS doubles (COLS odd: a column read by 64 lanes hits 64 banks); as many
+// waves per block as their tiles fit the CU's 160 KB of LDS (4 up to 32 hidden units, 2 for 64), 64 waves = the 64 partial sums of
+// level 2 per replica.  LDS reads of level 1 go SPB samples (2 KP SPB <= 12 reads) at a time.
+template <int H> struct FqiShape {
+  static constexpr int P = (kFqiNIn + 1) * H + H + 1;
+  static constexpr int KP = (P + 1 + 63) / 64;
+  static constexpr int COLS = 2 * H + kFqiNIn + 2;        // in[3], d1[H], a[H], d2, 1.0
+  static constexpr int WAVES = ((size_t)4 * 64 * COLS * 8 + 3 * P * 8 + 64 <= 160 * 1024) ? 4 : 2;
+  static constexpr int BLOCKS = 64 / WAVES;               // per replica
+  static constexpr int SPB = (KP == 1) ? 4 : (KP == 2) ? 3 : (KP == 3) ? 2 : 1;
+  static constexpr int QSPLIT = (63 * COLS * 8 <= 65535) ? 64 : 32;      // ds_read offsets are 16 bits: a second base address beyond
+  static_assert(KP <= 6 && 2 * KP * SPB <= 12, "reads per batch");
+  static_assert((size_t)WAVES * 64 * COLS * 8 + 3 * P * 8 + 64 <= 160 * 1024, "factor tiles exceed the LDS");
+};
+constexpr int kFqiStampBlocks = 16;
+
+// s_waitcnt lgkmcnt(N) that the compiler may not move the uses of x[] across
+template <int N>
+__device__ __forceinline__ void fqi_lds_wait(double (&x)[12])
 {
-  static_assert(H == 20, "column layout of the factor tile");
-  constexpr int P = (kFqiNIn + 1) * H + H + 1;
-  constexpr int C_IN = 0, C_D1 = kFqiNIn, C_A = kFqiNIn + H, C_D2 = kFqiNIn + 2 * H, C_ONE = C_D2 + 1, COLS = C_ONE + 1;
-  constexpr int TREES = (P + 1 + 3) / 4;                 // level-3 trees per wave: parameters w, w + 4, ... (and the squared error)
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11])
+               : "n"(N));
+}
+
+template <int H>
+__global__ __launch_bounds__(FqiShape<H>::WAVES * 64) void fqi_epochs_kernel(FqiParams F, int r_first, int epochs)
+{
+  typedef FqiShape<H> Sh;
+  constexpr int P = Sh::P, KP = Sh::KP, COLS = Sh::COLS, WAVES = Sh::WAVES, BLOCKS = Sh::BLOCKS, SPB = Sh::SPB, QSPLIT = Sh::QSPLIT, NT = WAVES * 64;
+  constexpr int C_IN = 0, C_D1 = kFqiNIn, C_A = kFqiNIn + H, C_D2 = kFqiNIn + 2 * H, C_ONE = C_D2 + 1;
+  constexpr int TREES = (P + 1 + WAVES - 1) / WAVES;     // level-3 trees per wave: parameters w, w + WAVES, ... (and the squared error)
   constexpr int GROUPS = (TREES + 3) / 4;                // ... taken four at a time, one per row of 16 lanes
-  static_assert(COLS == kFqiCols, "factor tile width");
+  constexpr int GB = 8;                                  // ... and at most 8 groups of leaves in registers together
+  static_assert(COLS == C_ONE + 1, "factor tile width");
   __shared__ double sh_net[P], sh_eta[P], sh_prev[P];
-  __shared__ double sh_tile[4][64 * COLS];
+  __shared__ double sh_tile[WAVES][64 * COLS];
   __shared__ int sh_ok;
-  const int r = r_first + (int)blockIdx.x / kFqiBlocksPerReplica, bl = (int)blockIdx.x % kFqiBlocksPerReplica;
+  const int r = r_first + (int)blockIdx.x / BLOCKS, bl = (int)blockIdx.x % BLOCKS;
   if (r >= F.R || epochs <= 0) return;
   FqiRep &rep = F.rep[r];
-  if (rep.done) return;                                  // uniform over the replica's 16 blocks
+  if (rep.done) return;                                  // uniform over the replica's blocks
   const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  const int L = bl * 4 + w;
+  const int L = bl * WAVES + w;
   const int64_t n = rep.n, chunks = (n + 63) / 64;
   double *net = F.net + (size_t)r * 4 * F.P;
   unsigned int *counter = F.sync + (size_t)r * 4;        // one 16-byte slot per replica
   double *tile = sh_tile[w];
   double *row = tile + lane * COLS;
-  for (int k = (int)threadIdx.x; k < P; k += 256)
+  for (int k = (int)threadIdx.x; k < P; k += NT)
   {
     sh_net[k] = net[k];
     sh_eta[k] = net[F.P + k];
     sh_prev[k] = net[3 * F.P + k];
   }
-  // the two factors of the per-sample gradient terms this lane sums (parameters lane and lane + 64; x * 1.0 is exact)
-  int cx[2], cy[2];
+  // the two factors of the per-sample gradient terms this lane sums (parameters lane, lane + 64, ...; x * 1.0 is exact)
+  int cx[KP], cy[KP];
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < KP; ++k)
   {
     const int p = lane + 64 * k;
     if (p < (kFqiNIn + 1) * H)
@@ -342,12 +377,15 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
   row[C_ONE] = 1.;                                        // the constant factor of the bias terms: written once
   const size_t base = (size_t)r * (size_t)F.cap;
   double last_error = 0.;
+  bool has_error = false;                                 // this lane ran the tree of the squared error
   __syncthreads();
-#define FQI_STAMP(k) do { if (F.stamps && e < 4 && threadIdx.x == 0) F.stamps[(((size_t)r * 16 + bl) * 4 + e) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FQI_STAMP(k) do { if (F.stamps && e < 4 && bl < kFqiStampBlocks && threadIdx.x == 0) F.stamps[(((size_t)r * kFqiStampBlocks + bl) * 4 + e) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   for (int e = 0; e < epochs; ++e)
   {
     FQI_STAMP(0);
-    double acc[2] = {0., 0.};
+    double acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.;
     // inputs of the wave's first chunk; inside the loop the next chunk's are requested before the current one is worked on
     double nin[kFqiNIn] = {0., 0., 0.}, ntarget = 0.;
     if (L < chunks && (int64_t)L * 64 + lane < n)
@@ -374,20 +412,39 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
       if (c == L) FQI_STAMP(5);
       if (s < n)
       {
-        double a[H];
-        const double out = ann_forward<H>(sh_net, in, a);
-        if (c == L) FQI_STAMP(6);
-        const double d2 = out - target;
         const double *W2 = sh_net + (kFqiNIn + 1) * H;
+        if constexpr (H <= 20)
+        { // the activations stay in registers between the two passes
+          double a[H];
+          const double out = ann_forward<H>(sh_net, in, a);
+          if (c == L) FQI_STAMP(6);
+          const double d2 = out - target;
 #pragma unroll
-        for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
+          for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
 #pragma unroll
-        for (int h = 0; h < H; ++h)
-        {
-          row[C_D1 + h] = (W2[h] * d2) * (a[h] * (1. - a[h]));       // ann.cpp:249 with deviation D2
-          row[C_A + h] = a[h];
+          for (int h = 0; h < H; ++h)
+          {
+            row[C_D1 + h] = (W2[h] * d2) * (a[h] * (1. - a[h]));       // ann.cpp:249 with deviation D2
+            row[C_A + h] = a[h];
+          }
+          row[C_D2] = d2;
         }
-        row[C_D2] = d2;
+        else
+        { // the activations go to the lane's row as they are produced and are read back for the hidden deltas
+          const double out = ann_forward<H>(sh_net, in, row + C_A);
+          asm volatile("" ::: "memory");                               // (read back from the row: do not keep H activations live in registers)
+          if (c == L) FQI_STAMP(6);
+          const double d2 = out - target;
+#pragma unroll
+          for (int i = 0; i < kFqiNIn; ++i) row[C_IN + i] = in[i];
+#pragma unroll
+          for (int h = 0; h < H; ++h)
+          {
+            const double ah = row[C_A + h];
+            row[C_D1 + h] = (W2[h] * d2) * (ah * (1. - ah));           // ann.cpp:249 with deviation D2
+          }
+          row[C_D2] = d2;
+        }
       }
       // the tile belongs to this wave alone: its LDS writes are complete before its LDS reads issue (in-order LDS, one wave)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -395,65 +452,68 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int n_here = (int)((n - c * 64 < 64) ? n - c * 64 : 64);
       if (c == L) FQI_STAMP(7);
-      { // the lane turns into one lane per PARAMETER (two of them): per-sample products added in sample order (level 1), then level 2
-        double v0 = 0., v1 = 0.;
+      { // the lane turns into one lane per PARAMETER (KP of them): per-sample products added in sample order (level 1), then level 2
+        double v[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) v[k] = 0.;
         if (n_here == 64)
-        { // 256 LDS reads per wave and chunk: issued as plain ds_read_b64 (2 LDS cycles each; the compiler pairs neighbouring rows
-          // into ds_read2_b64, 8 cycles per pair: MI355X_MICROARCH.md, LDS table), three samples (12 reads) per batch, the next
+        { // 128 KP LDS reads per wave and chunk: issued as plain ds_read_b64 (2 LDS cycles each; the compiler pairs neighbouring rows
+          // into ds_read2_b64, 8 cycles per pair: MI355X_MICROARCH.md, LDS table), SPB samples (<= 12 reads) per batch, the next
           // batch in flight while the current one is multiplied and added (lgkmcnt counts at most 15 operations)
+          constexpr int RPB = 2 * KP * SPB, NB = 64 / SPB, REM = 64 % SPB;
           double x[2][12];
+          const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) double *)tile;
+          unsigned a_cx[64 / QSPLIT][KP], a_cy[64 / QSPLIT][KP];
+#pragma unroll
+          for (int hf = 0; hf < 64 / QSPLIT; ++hf)
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+            {
+              a_cx[hf][k] = lds0 + (unsigned)(hf * QSPLIT * COLS + cx[k]) * 8u;
+              a_cy[hf][k] = lds0 + (unsigned)(hf * QSPLIT * COLS + cy[k]) * 8u;
+            }
 #define FQI_RD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define FQI_ISSUE(buf, q0)                                                                                                \
-          _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                                    \
-          {                                                                                                               \
-            FQI_RD(x[buf][4 * t + 0], a_cx0, ((q0) + t) * COLS * 8); FQI_RD(x[buf][4 * t + 1], a_cy0, ((q0) + t) * COLS * 8); \
-            FQI_RD(x[buf][4 * t + 2], a_cx1, ((q0) + t) * COLS * 8); FQI_RD(x[buf][4 * t + 3], a_cy1, ((q0) + t) * COLS * 8); \
-          }
+#define FQI_ISSUE(buf, q0, cnt)                                                                                           \
+          _Pragma("unroll") for (int t = 0; t < (cnt); ++t)                                                                \
+            _Pragma("unroll") for (int k = 0; k < KP; ++k)                                                                 \
+            {                                                                                                             \
+              FQI_RD(x[buf][2 * (t * KP + k) + 0], a_cx[((q0) + t) / QSPLIT][k], (((q0) + t) % QSPLIT) * COLS * 8);          \
+              FQI_RD(x[buf][2 * (t * KP + k) + 1], a_cy[((q0) + t) / QSPLIT][k], (((q0) + t) % QSPLIT) * COLS * 8);          \
+            }
 #define FQI_USE(buf, cnt)                                                                                                 \
           _Pragma("unroll") for (int t = 0; t < (cnt); ++t)                                                                \
+            _Pragma("unroll") for (int k = 0; k < KP; ++k) v[k] += x[buf][2 * (t * KP + k) + 0] * x[buf][2 * (t * KP + k) + 1];
+#define FQI_BATCH(cur, nxt)                                                                                               \
           {                                                                                                               \
-            v0 += x[buf][4 * t + 0] * x[buf][4 * t + 1];                                                                  \
-            v1 += x[buf][4 * t + 2] * x[buf][4 * t + 3];                                                                  \
+            if (b + 1 < NB) { FQI_ISSUE(nxt, SPB * (b + 1), SPB); fqi_lds_wait<RPB>(x[cur]); }                             \
+            else if (REM) { FQI_ISSUE(nxt, SPB * NB, REM); fqi_lds_wait<2 * KP * REM>(x[cur]); }                           \
+            else fqi_lds_wait<0>(x[cur]);                                                                                 \
+            FQI_USE(cur, SPB);                                                                                            \
           }
-#define FQI_WAIT(buf, n_out)                                                                                              \
-          asm volatile("s_waitcnt lgkmcnt(" #n_out ")"                                                                    \
-                       : "+v"(x[buf][0]), "+v"(x[buf][1]), "+v"(x[buf][2]), "+v"(x[buf][3]), "+v"(x[buf][4]), "+v"(x[buf][5]),   \
-                         "+v"(x[buf][6]), "+v"(x[buf][7]), "+v"(x[buf][8]), "+v"(x[buf][9]), "+v"(x[buf][10]), "+v"(x[buf][11]))
-          const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) double *)tile;
-          const unsigned a_cx0 = lds0 + cx[0] * 8, a_cy0 = lds0 + cy[0] * 8, a_cx1 = lds0 + cx[1] * 8, a_cy1 = lds0 + cy[1] * 8;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the tile writes of this wave have left for the LDS
-          FQI_ISSUE(0, 0);
+          FQI_ISSUE(0, 0, SPB);
 #pragma unroll
-          for (int b = 0; b < 21; ++b)
-          { // batch b = samples 3b .. 3b+2 (the 22nd batch is the single sample 63)
-            if (b & 1)
-            {
-              if (b < 20) { FQI_ISSUE(0, 3 * (b + 1)); FQI_WAIT(1, 12); }
-              else { FQI_RD(x[0][0], a_cx0, 63 * COLS * 8); FQI_RD(x[0][1], a_cy0, 63 * COLS * 8); FQI_RD(x[0][2], a_cx1, 63 * COLS * 8); FQI_RD(x[0][3], a_cy1, 63 * COLS * 8); FQI_WAIT(1, 4); }
-              FQI_USE(1, 3);
-            }
-            else
-            {
-              if (b < 20) { FQI_ISSUE(1, 3 * (b + 1)); FQI_WAIT(0, 12); }
-              else { FQI_RD(x[1][0], a_cx0, 63 * COLS * 8); FQI_RD(x[1][1], a_cy0, 63 * COLS * 8); FQI_RD(x[1][2], a_cx1, 63 * COLS * 8); FQI_RD(x[1][3], a_cy1, 63 * COLS * 8); FQI_WAIT(0, 4); }
-              FQI_USE(0, 3);
-            }
+          for (int b = 0; b < NB; ++b)
+          { // batch b = samples SPB b .. SPB b + SPB - 1 (and one last batch of the REM samples that remain)
+            if (b & 1) FQI_BATCH(1, 0)
+            else FQI_BATCH(0, 1)
           }
-          FQI_WAIT(1, 0);                                          // b = 20 is even: the last sample went into buffer 1
-          FQI_USE(1, 1);
+          if (REM)
+          {
+            fqi_lds_wait<0>(x[NB & 1]);
+            FQI_USE(NB & 1, REM);
+          }
 #undef FQI_RD
 #undef FQI_ISSUE
 #undef FQI_USE
-#undef FQI_WAIT
+#undef FQI_BATCH
         }
         else
           for (int q = 0; q < n_here; ++q)
-          {
-            v0 += tile[q * COLS + cx[0]] * tile[q * COLS + cy[0]];
-            v1 += tile[q * COLS + cx[1]] * tile[q * COLS + cy[1]];
-          }
-        acc[0] += v0;
-        acc[1] += v1;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) v[k] += tile[q * COLS + cx[k]] * tile[q * COLS + cy[k]];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[k] += v[k];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -462,56 +522,77 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
     FQI_STAMP(1);
     // the hand-off: the 64 partial sums of every parameter (buffer e mod 2: a block that is one epoch ahead writes the other one)
     double *vL = F.vL + ((size_t)(e & 1) * (size_t)F.R + (size_t)r) * 64 * (size_t)(P + 1);
-    fqi_publish(vL + (size_t)lane * 64 + L, acc[0]);                 // [parameter][L]: the 64 leaves of a tree are 512 contiguous bytes
-    if (lane + 64 <= P) fqi_publish(vL + (size_t)(lane + 64) * 64 + L, acc[1]);
-    if (!fqi_meet(counter, (unsigned)(e + 1) * kFqiBlocksPerReplica, &sh_ok))
+#pragma unroll
+    for (int k = 0; k < KP; ++k)                                     // [parameter][L]: the 64 leaves of a tree are 512 contiguous bytes
+      if (lane + 64 * k <= P) fqi_publish(vL + (size_t)(lane + 64 * k) * 64 + L, acc[k]);
+    if (!fqi_meet(counter, (unsigned)(e + 1) * BLOCKS, &sh_ok))
     {
       if (threadIdx.x == 0) atomicOr(&rep.status, ST_SYNC_TIMEOUT);
       return;
     }
     FQI_STAMP(2);
-    // level 3 and the RPROP step of ANNRepresentation::finalize (ann.cpp:186-192, 199), in every block for all parameters
+    // level 3 and the step of ANNRepresentation::finalize (ann.cpp:198-221), in every block for all parameters
     // Four trees at a time, one per row of 16 lanes: lane j of row t loads leaves j, j+32, j+16, j+48 of its tree and adds them as
     // levels 32 and 16 do -- (v[j] + v[j+32]) + (v[j+16] + v[j+48]) --, levels 8..1 are row shifts (DPP); lane 0 of the row holds the
     // sum and steps the parameter, whose eta / previous gradient live in LDS beside the network.
     const int rowi = lane >> 4, j16 = lane & 15;
-    double leaf[GROUPS][4];
 #pragma unroll
-    for (int g = 0; g < GROUPS; ++g)
+    for (int g0 = 0; g0 < GROUPS; g0 += GB)
     {
-      const int p = w + 4 * (4 * g + rowi);
-      const double *t = vL + (size_t)(p <= P ? p : P) * 64 + j16;
+      constexpr int GBmax = GB;
+      double leaf[GBmax][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) leaf[g][k] = t[16 * k];
-    }
-    double st_eta[GROUPS], st_prev[GROUPS], st_net[GROUPS];
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g)
-    {
-      const int p = w + 4 * (4 * g + rowi), pc = p < P ? p : 0;
-      st_eta[g] = sh_eta[pc]; st_prev[g] = sh_prev[pc]; st_net[g] = sh_net[pc];
-    }
-#pragma unroll
-    for (int g = 0; g < GROUPS; ++g)
-    {
-      double v = (leaf[g][0] + leaf[g][2]) + (leaf[g][1] + leaf[g][3]);
-      v += fqi_row_shl<8>(v);
-      v += fqi_row_shl<4>(v);
-      v += fqi_row_shl<2>(v);
-      v += fqi_row_shl<1>(v);
-      const int p = w + 4 * (4 * g + rowi);
-      if (j16 == 0)
-      {
-        if (p == P) last_error = v / (double)n;
-        else if (p < P)
+      for (int gg = 0; gg < GBmax; ++gg)
+        if (g0 + gg < GROUPS)
         {
-          const double Delta = 0. + v;                               // Delta was zero before this epoch (ann.cpp:199)
-          const double eta = (Delta * st_prev[g] > 0) ? st_eta[g] * 1.2 : st_eta[g] * 0.5;
-          sh_net[p] = st_net[g] - ((Delta > 0) ? eta : -eta);
-          sh_eta[p] = eta;
-          sh_prev[p] = Delta;
+          const int p = w + WAVES * (4 * (g0 + gg) + rowi);
+          const double *t = vL + (size_t)(p <= P ? p : P) * 64 + j16;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) leaf[gg][k] = t[16 * k];
         }
-      }
+      double st_eta[GBmax], st_prev[GBmax], st_net[GBmax];
+#pragma unroll
+      for (int gg = 0; gg < GBmax; ++gg)
+        if (g0 + gg < GROUPS)
+        {
+          const int p = w + WAVES * (4 * (g0 + gg) + rowi), pc = p < P ? p : 0;
+          st_eta[gg] = sh_eta[pc]; st_prev[gg] = sh_prev[pc]; st_net[gg] = sh_net[pc];
+        }
+#pragma unroll
+      for (int gg = 0; gg < GBmax; ++gg)
+        if (g0 + gg < GROUPS)
+        {
+          double v = (leaf[gg][0] + leaf[gg][2]) + (leaf[gg][1] + leaf[gg][3]);
+          v += fqi_row_shl<8>(v);
+          v += fqi_row_shl<4>(v);
+          v += fqi_row_shl<2>(v);
+          v += fqi_row_shl<1>(v);
+          const int p = w + WAVES * (4 * (g0 + gg) + rowi);
+          if (j16 == 0)
+          {
+            if (p == P) { last_error = v / (double)n; has_error = true; }
+            else if (p < P)
+            {
+              const double Delta = 0. + v;                             // Delta was zero before this epoch (ann.cpp:221)
+              if (F.eta == 0)
+              { // RPROP (ann.cpp:207-213)
+                const double eta = (Delta * st_prev[gg] > 0) ? st_eta[gg] * 1.2 : st_eta[gg] * 0.5;
+                sh_net[p] = st_net[gg] - ((Delta > 0) ? eta : -eta);
+                sh_eta[p] = eta;
+                sh_prev[p] = Delta;
+              }
+              else if (F.eta > 0)
+                sh_net[p] = st_net[gg] - (F.eta * Delta) / (double)n;   // gradient descent (:202-206), samples_ = n
+              else
+              { // RMSprop (:214-219); sqrt and the divisions are the correctly rounded IEEE operations
+                const double gm = Delta / (double)n;
+                const double eta = 0.9 * st_eta[gg] + 0.1 * (gm * gm);
+                sh_eta[p] = eta;
+                sh_net[p] = st_net[gg] + F.eta * (Delta / __builtin_sqrt(eta));
+              }
+            }
+          }
+        }
     }
     FQI_STAMP(3);
     __syncthreads();
@@ -519,14 +600,14 @@ __global__ __launch_bounds__(256) void fqi_epochs_kernel(FqiParams F, int r_firs
   }
 #undef FQI_STAMP
   if (bl == 0)
-  { // the 16 blocks hold the same bits: one of them writes the state back for the kernels and launches that follow
-    for (int k = (int)threadIdx.x; k < P; k += 256)
+  { // the blocks hold the same bits: one of them writes the state back for the kernels and launches that follow
+    for (int k = (int)threadIdx.x; k < P; k += NT)
     {
       net[k] = sh_net[k];
       net[F.P + k] = sh_eta[k];
       net[3 * F.P + k] = sh_prev[k];
     }
-    if ((lane & 15) == 0 && w + 4 * (4 * ((P - w) / 16) + (lane >> 4)) == P) rep.last_error = last_error;   // the row that ran the tree of p == P
+    if (has_error) rep.last_error = last_error;
   }
 }
 
@@ -601,11 +682,25 @@ struct grlx_fqi_ctx {
   std::vector<void *> bufs;
   uint64_t *r0 = nullptr;
   int batches_run = 0;
-  int replicas_per_launch = 1;       // how many replicas' blocks (16 each) are resident at once
+  int replicas_per_launch = 1;       // how many replicas' blocks are resident at once
+  int blocks_per_replica = 16, block_threads = 256;      // FqiShape<hidden>
   bool plain_launch = false;         // diagnostic: GRLX_FQI_NO_COOP=1 launches the epochs kernel without hipLaunchCooperativeKernel
 };
 
 namespace {
+// the instantiated widths of the hidden layer (representation/parameterized/ann:hiddens = [H])
+#define FQI_FOR_H(H_, ...)                                           \
+  switch (H_)                                                        \
+  {                                                                  \
+    case 8:  { constexpr int HH = 8;  __VA_ARGS__; } break;          \
+    case 16: { constexpr int HH = 16; __VA_ARGS__; } break;          \
+    case 20: { constexpr int HH = 20; __VA_ARGS__; } break;          \
+    case 32: { constexpr int HH = 32; __VA_ARGS__; } break;          \
+    case 64: { constexpr int HH = 64; __VA_ARGS__; } break;          \
+    default: break;                                                  \
+  }
+inline bool fqi_width_built(int H) { return H == 8 || H == 16 || H == 20 || H == 32 || H == 64; }
+
 int ffail(int code, const char *fmt, ...)
 {
   char buf[512];
@@ -665,8 +760,9 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
   *out = nullptr;
   if (cfg->struct_size != sizeof(grlx_fqi_config)) return ffail(GRLX_ERR_INVALID, "grlx_fqi_config.struct_size mismatch");
   if (cfg->env != GRLX_ENV_PENDULUM) return ffail(GRLX_ERR_INVALID, "experiment/batch_learning: the task must support invert(); built for task/pendulum/swingup");
-  if (cfg->eta != 0) return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:eta = %g is not built (instantiated: 0 = RPROP)", cfg->eta);
-  if (cfg->hidden != 20) return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:hiddens = [%d] is not built (instantiated: [20])", cfg->hidden);
+  if (!(cfg->eta >= -2. && cfg->eta <= 2.)) return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:eta = %g outside [-2, 2] (ann.cpp:61)", cfg->eta);
+  if (!fqi_width_built(cfg->hidden))
+    return ffail(GRLX_ERR_INVALID, "representation/parameterized/ann:hiddens = [%d] is not built (instantiated: [8], [16], [20], [32], [64])", cfg->hidden);
   if (cfg->n_replicas < 1 || cfg->batch_size < 1 || cfg->max_batches < 1 || cfg->iterations < 1 || cfg->epochs < 0)
     return ffail(GRLX_ERR_INVALID, "n_replicas, batch_size, max_batches, iterations must be >= 1");
   if (cfg->action_steps < 1 || cfg->action_steps > GRLX_MAX_ACTIONS) return ffail(GRLX_ERR_INVALID, "discretizer/uniform:steps");
@@ -713,6 +809,7 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
   F.in_min[kFqiD] = cfg->action_min;
   F.in_scale[kFqiD] = 1. / (cfg->action_max - cfg->action_min) * (1 + 0);
   F.gamma_tau = pow(cfg->gamma, cfg->control_step);                               // pow(gamma_, tau), tau = control_step
+  F.eta = cfg->eta;
 
   const size_t R = (size_t)F.R, cap = (size_t)F.cap;
   int rc = GRLX_OK;
@@ -749,17 +846,21 @@ int grlx_fqi_create(const grlx_fqi_config *cfg, const int64_t *seeds, grlx_fqi_c
   }
   {
     int dev = 0, cus = 0, per_cu = 0;
+    hipError_t occ = hipErrorInvalidValue;
+    FQI_FOR_H(F.H, ctx->blocks_per_replica = FqiShape<HH>::BLOCKS; ctx->block_threads = FqiShape<HH>::WAVES * 64;
+              occ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fqi_epochs_kernel<HH>, FqiShape<HH>::WAVES * 64, 0));
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fqi_epochs_kernel<20>, 256, 0) != hipSuccess || cus * per_cu < kFqiBlocksPerReplica)
+        occ != hipSuccess || cus * per_cu < ctx->blocks_per_replica)
     {
+      const int need = ctx->blocks_per_replica;
       grlx_fqi_destroy(ctx);
-      return ffail(GRLX_ERR_HIP, "fqi_epochs_kernel: the device cannot hold the %d resident blocks of one replica", kFqiBlocksPerReplica);
+      return ffail(GRLX_ERR_HIP, "fqi_epochs_kernel: the device cannot hold the %d resident blocks of one replica", need);
     }
-    ctx->replicas_per_launch = (cus * per_cu) / kFqiBlocksPerReplica;
+    ctx->replicas_per_launch = (cus * per_cu) / ctx->blocks_per_replica;
   }
   if (const char *nc = getenv("GRLX_FQI_NO_COOP")) ctx->plain_launch = nc[0] && nc[0] != '0';
   if (const char *st = getenv("GRLX_FQI_STAMPS"))
-    if (st[0] && st[0] != '0' && (rc = dev_alloc(ctx, &F.stamps, R * 16 * 4 * 8)) != GRLX_OK)
+    if (st[0] && st[0] != '0' && (rc = dev_alloc(ctx, &F.stamps, R * kFqiStampBlocks * 4 * 8)) != GRLX_OK)
     {
       grlx_fqi_destroy(ctx);
       return rc;
@@ -795,8 +896,8 @@ int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
   for (int ii = 0; ii < ctx->cfg.iterations; ++ii)
   {
     hipLaunchKernelGGL(fqi_iter_begin_kernel, dim3((F.R + 63) / 64), dim3(64), 0, stream, F, ii);
-    hipLaunchKernelGGL(fqi_targets_kernel<20>, dim3(chunks, F.R), dim3(256), 0, stream, F, ii == 0 ? 1 : 0);
-    // the epochs of the iteration: one cooperative launch per group of replicas that fills the chip (16 blocks per replica)
+    FQI_FOR_H(F.H, hipLaunchKernelGGL(fqi_targets_kernel<HH>, dim3(chunks, F.R), dim3(256), 0, stream, F, ii == 0 ? 1 : 0));
+    // the epochs of the iteration: one cooperative launch per group of replicas that fills the chip (16 blocks per replica for [20])
     for (int r0 = 0; r0 < F.R; r0 += ctx->replicas_per_launch)
     {
       const int nr = (F.R - r0 < ctx->replicas_per_launch) ? F.R - r0 : ctx->replicas_per_launch;
@@ -804,13 +905,16 @@ int grlx_fqi_run_batch(grlx_fqi_ctx *ctx, void *stream_)
       FqiParams Fa = F;
       int r_first = r0, epochs = ctx->cfg.epochs;
       void *args[] = {&Fa, &r_first, &epochs};
+      const dim3 grid(nr * ctx->blocks_per_replica), block(ctx->block_threads);
+      hipError_t le = hipSuccess;
       if (ctx->plain_launch)      // diagnostic (GRLX_FQI_NO_COOP=1): the same grid without the runtime's residency check
-        hipLaunchKernelGGL(fqi_epochs_kernel<20>, dim3(nr * kFqiBlocksPerReplica), dim3(256), 0, stream, Fa, r_first, epochs);
+      { FQI_FOR_H(F.H, hipLaunchKernelGGL(fqi_epochs_kernel<HH>, grid, block, 0, stream, Fa, r_first, epochs)); }
       else
-        FQI_TRY(hipLaunchCooperativeKernel((const void *)fqi_epochs_kernel<20>, dim3(nr * kFqiBlocksPerReplica), dim3(256), args, 0, stream));
+      { FQI_FOR_H(F.H, le = hipLaunchCooperativeKernel((const void *)fqi_epochs_kernel<HH>, grid, block, args, 0, stream)); }
+      FQI_TRY(le);
     }
   }
-  hipLaunchKernelGGL(fqi_test_kernel<20>, dim3((F.R + 63) / 64), dim3(64), 0, stream, F);
+  FQI_FOR_H(F.H, hipLaunchKernelGGL(fqi_test_kernel<HH>, dim3((F.R + 63) / 64), dim3(64), 0, stream, F));
   FQI_TRY(hipGetLastError());
   ctx->batches_run++;
   return GRLX_OK;
@@ -866,7 +970,7 @@ int grlx_fqi_get_transitions(grlx_fqi_ctx *ctx, int replica, int first, int coun
 // diagnostic, not part of include/grlx.h: the stamps of the LAST fqi_epochs_kernel launch (GRLX_FQI_STAMPS=1 at create)
 int grlx_fqi_debug_stamps(grlx_fqi_ctx *ctx, unsigned long long *out, int count)
 {
-  if (!ctx || !out || !ctx->F.stamps || count != ctx->F.R * 16 * 4 * 8) return ffail(GRLX_ERR_INVALID, "no stamps (GRLX_FQI_STAMPS=1 at create; count = R * 512)");
+  if (!ctx || !out || !ctx->F.stamps || count != ctx->F.R * kFqiStampBlocks * 4 * 8) return ffail(GRLX_ERR_INVALID, "no stamps (GRLX_FQI_STAMPS=1 at create; count = R * 512)");
   FQI_TRY(hipDeviceSynchronize());
   FQI_TRY(hipMemcpy(out, ctx->F.stamps, sizeof(unsigned long long) * (size_t)count, hipMemcpyDeviceToHost));
   return GRLX_OK;

@@ -24,9 +24,10 @@
  *      ((w_0 a_0 + w_1 a_1) + ...) + bias; the gradient of an epoch is summed over samples either in sample order
  *      (sum_order 0: what ann.cpp:252-253 does) or by the fixed two-level tree the GPU uses (sum_order 1: chunks of
  *      64 samples in sample order, chunk sums strided over 64 lanes and reduced by a wavefront shuffle; see
- *      ann_epoch).  RPROP
- *      (ann.cpp:186-192) looks at SIGNS only, so the two orders give the same weights unless a component of the
- *      summed gradient is within rounding of zero.
+ *      ann_epoch).  RPROP (eta = 0, ann.cpp:207-213) looks at SIGNS only, so the two orders give the same weights
+ *      unless a component of the summed gradient is within rounding of zero; gradient descent (eta > 0, :202-206) and
+ *      RMSprop (eta < 0, :214-219) use the sum's value, so there the orders differ by rounding and tests compare the GPU
+ *      with sum_order 1 only.
  *  D4  tests/pendulum-fqi-ann.yaml gives input_min as "observation_min+action_min": with the current parser `+`
  *      is an element-wise sum (parser.cpp:49-134), which would make the projector reject its 3-dimensional input
  *      (normalizing.cpp:80-84).  HERE: the role default of normalizing.cpp:50-51, the concatenation (`++`).
@@ -140,12 +141,12 @@ orc_fqi *orc_fqi_create(const orc_fqi_spec *spec, long seed)
   orc_srand48(&f->core->G, seed);
   orc_srand48(&f->core->S2, (long)orc_lrand48(&f->core->G));
   orc_srand48(&f->core->TL, (long)orc_lrand48(&f->core->G));
-  /* ANNRepresentation reset (ann.cpp:92-120) with D1's stream; eta = 0.1 for RPROP (ann.cpp:108-109) */
+  /* ANNRepresentation reset (ann.cpp:92-120) with D1's stream; eta = Ones, x 0.1 for RPROP (ann.cpp:106-109) */
   orc_srand48(&f->R, seed);
   for (int i = 0; i < f->n_params; ++i)
   {
     f->params[i] = (2 * orc_drand48(&f->R) - 1) * 0.01;
-    f->eta[i] = 1. * 0.1;
+    f->eta[i] = (spec->eta == 0) ? 1. * 0.1 : 1.;
     f->Delta[i] = 0;
     f->prev_Delta[i] = 0;
   }
@@ -222,12 +223,26 @@ static void ann_epoch(orc_fqi *f)
     err += lanes[0][P];
   }
   f->last_error = err / (double)f->n;
-  /* ANNRepresentation::finalize, eta_ == 0: RPROP (ann.cpp:186-192), element-wise; then Delta = 0 (ann.cpp:199) */
+  /* ANNRepresentation::finalize (ann.cpp:198-221), element-wise; samples_ = the backprop calls of the epoch = n; then Delta = 0 */
+  const double eta_ = f->spec.eta, samples = (double)f->n;
   for (int k = 0; k < P; ++k)
   {
-    f->eta[k] = (f->Delta[k] * f->prev_Delta[k] > 0) ? f->eta[k] * 1.2 : f->eta[k] * 0.5;
-    f->params[k] -= (f->Delta[k] > 0) ? f->eta[k] : -f->eta[k];
-    f->prev_Delta[k] = f->Delta[k];
+    if (eta_ > 0)
+    { /* stochastic gradient descent (:202-206): W -= eta_*Delta/samples_, evaluated left to right */
+      f->params[k] -= (eta_ * f->Delta[k]) / samples;
+    }
+    else if (eta_ == 0)
+    { /* RPROP (:207-213) */
+      f->eta[k] = (f->Delta[k] * f->prev_Delta[k] > 0) ? f->eta[k] * 1.2 : f->eta[k] * 0.5;
+      f->params[k] -= (f->Delta[k] > 0) ? f->eta[k] : -f->eta[k];
+      f->prev_Delta[k] = f->Delta[k];
+    }
+    else
+    { /* RMSprop (:214-219): eta = 0.9 eta + 0.1 (Delta/samples_)^2;  W += eta_ * Delta / sqrt(eta)  (IEEE sqrt and division) */
+      const double g = f->Delta[k] / samples;
+      f->eta[k] = 0.9 * f->eta[k] + 0.1 * (g * g);
+      f->params[k] += eta_ * (f->Delta[k] / sqrt(f->eta[k]));
+    }
     f->Delta[k] = 0;
   }
 }

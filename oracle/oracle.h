@@ -257,9 +257,10 @@ typedef struct {
   int      batch_size;    /* experiment/batch_learning:batch_size: transitions drawn per batch                          */
   int      iterations;    /* predictor/fqi:iterations                                                                   */
   int      epochs;        /* representation/iterative:epochs                                                            */
-  int      hidden;        /* representation/parameterized/ann:hiddens = [hidden]; eta = 0 (RPROP)                       */
+  int      hidden;        /* representation/parameterized/ann:hiddens = [hidden]                                        */
   int      sum_order;     /* 0: gradient summed in sample order (the reference); 1: the GPU's fixed tree (fqi.c D3)     */
   double   gamma_tau;     /* pow(gamma, control_step), evaluated once by the caller with libm                           */
+  double   eta;           /* representation/parameterized/ann:eta: 0 = RPROP, > 0 = gradient descent, < 0 = RMSprop     */
 } orc_fqi_spec;
 typedef struct orc_fqi orc_fqi;
 void     orc_fqi_spec_pendulum(orc_fqi_spec *s);                 /* the reference's tests/pendulum-fqi-ann.yaml */

@@ -49,7 +49,7 @@ class Spec(C.Structure):
 
 class FqiSpec(C.Structure):
     _fields_ = [("base", Spec), ("batch_size", C.c_int), ("iterations", C.c_int), ("epochs", C.c_int), ("hidden", C.c_int),
-                ("sum_order", C.c_int), ("gamma_tau", C.c_double)]
+                ("sum_order", C.c_int), ("gamma_tau", C.c_double), ("eta", C.c_double)]
 
 
 class Row(C.Structure):

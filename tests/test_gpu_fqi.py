@@ -85,6 +85,22 @@ def test_fqi_more_replicas_than_one_launch_holds(grlx):
     r.close()
 
 
+@pytest.mark.parametrize("hidden", [8, 16, 32, 64])
+def test_fqi_other_hidden_layer_widths_bit_exact(grlx, hidden):
+    """representation/parameterized/ann:hiddens = [8], [16], [32], [64] (41 .. 321 parameters: one to six per lane of the summing
+    wave; 64 units run two waves per block, 32 blocks per replica): two batches of 4500 transitions (the second rebuild: 141 chunks,
+    two or three per wave, ragged), two replicas."""
+    _both(grlx, [3, 4], 2, batch_size=4500, iterations=2, epochs=10, hidden=hidden)
+
+
+@pytest.mark.parametrize("eta", [0.7, 0.05, -0.001, -0.01])
+@pytest.mark.parametrize("hidden", [20, 32])
+def test_fqi_gradient_descent_and_rmsprop_bit_exact(grlx, hidden, eta):
+    """representation/parameterized/ann:eta > 0 (gradient descent: W -= eta Delta / samples, ann.cpp:202-206) and eta < 0 (RMSprop,
+    :214-219: a square root and two divisions per parameter and epoch), against the oracle with the same summation tree."""
+    _both(grlx, [5, 6], 2, batch_size=1300, iterations=3, epochs=30, hidden=hidden, eta=eta)
+
+
 def test_fqi_iteration_loop_stops_per_replica(grlx):
     """gamma = 0: the targets are the rewards and the second iteration changes nothing (fqi.cpp:213); the stop is taken
     on the device, per replica, without a host round trip."""
@@ -111,7 +127,7 @@ def test_fqi_reference_yaml_first_row(grlx):
 
 def test_fqi_validation(grlx):
     capi = grlx.capi
-    for over in (dict(hidden=7), dict(env=1), dict(batch_size=0), dict(timeout=float("nan")), dict(action_steps=0)):
+    for over in (dict(hidden=7), dict(hidden=128), dict(eta=2.5), dict(eta=float("nan")), dict(env=1), dict(batch_size=0), dict(timeout=float("nan")), dict(action_steps=0)):
         with pytest.raises(capi.GrlxError) as ei:
             grlx.FqiRunner(grlx.pendulum_fqi_config(1, **over), [1])
         assert ei.value.code == capi.ERR_INVALID

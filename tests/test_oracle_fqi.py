@@ -56,6 +56,35 @@ def test_summation_order_and_arithmetic_mode_do_not_change_the_weights(oracle, s
         assert info["iterations"] == got[0][2]["iterations"] and rng == got[0][3]
 
 
+@pytest.mark.parametrize("eta", [0.0, 0.7, -0.01])
+def test_one_epoch_of_every_learning_rule_against_numpy(oracle, eta):
+    """ANNRepresentation::finalize (ann.cpp:198-221): eta = 0 RPROP (step 0.1 x 0.5 on the first epoch, against the gradient's sign),
+    eta > 0 gradient descent (W -= eta Delta / samples), eta < 0 RMSprop (eta' = 0.9 + 0.1 (Delta/samples)^2; W += eta Delta / sqrt(eta')).
+    One epoch over 50 transitions, recomputed here from the stored inputs and targets with the network before the epoch."""
+    over = dict(batch_size=50, iterations=1, hidden=8, eta=eta, math=ob.MATH_LIBM, sum_order=ob.SUM_SEQUENTIAL)
+    before = ob.FqiExperiment(ob.pendulum_fqi_spec(epochs=0, **over), seed=9)
+    before.run_batch()
+    w0 = before.params()
+    e = ob.FqiExperiment(ob.pendulum_fqi_spec(epochs=1, **over), seed=9)
+    e.run_batch()
+    x, _, _, tgt = e.transitions()
+    H, n = 8, len(tgt)
+    W1 = w0[:4 * H].reshape(H, 4); W2 = w0[4 * H:]
+    a = 1 / (1 + np.exp(-(x @ W1[:, :3].T + W1[:, 3])))
+    d2 = a @ W2[:H] + W2[H] - tgt
+    d1 = (d2[:, None] * W2[:H]) * a * (1 - a)
+    D = np.concatenate([np.concatenate([d1.T @ x, d1.sum(0)[:, None]], axis=1).ravel(), a.T @ d2, [d2.sum()]])
+    if eta == 0:
+        want = w0 - np.sign(D) * 0.05
+    elif eta > 0:
+        want = w0 - eta * D / n
+    else:
+        want = w0 + eta * D / np.sqrt(0.9 + 0.1 * (D / n) ** 2)
+    np.testing.assert_allclose(e.params(), want, rtol=1e-9, atol=1e-15)
+    assert abs(e.info()["error"] - (d2 ** 2).mean()) <= 1e-9 * (d2 ** 2).mean()
+    before.close(); e.close()
+
+
 def test_iteration_loop_stops_when_the_targets_stop_moving(oracle):
     """fqi.cpp:213: `maxdelta > 0.001`.  With gamma = 0 the targets are the rewards: the second iteration changes nothing."""
     e = ob.FqiExperiment(ob.pendulum_fqi_spec(batch_size=300, iterations=6, epochs=5, gamma=0.0), seed=4)
