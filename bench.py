@@ -68,7 +68,8 @@ GRAPHS = {
     # trial count, which makes every launch wait for its slowest replica (A/B on one box, tools/steps_budget_ab.py: acrobot 246 -> 359 M,
     # walker 181 -> 217 M env-steps/s over the same total)
     "acrobot_q": dict(trials=0, budget=1100, want_kernel=2, pmc_key="acrobot_q",
-                      kernel="rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ, deferred update>",
+                      kernel="rollout_wide_served_kernel<acrobot, SpecAcrobotQ> (8 replicas per wave, deferred update) + env_server_acrobot_pinned_kernel "
+                             "(co-resident pair, one timed launch; rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ> with GRLX_ENV_SERVER=0)",
                       text="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml)"),
     "compass_walker_q": dict(trials=0, budget=12200, want_kernel=2, pmc_key="compass_walker_q",
                              kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, SpecWalkerQ, deferred update>",
@@ -112,6 +113,27 @@ def csrc_hash() -> str:
             with open(p, "rb") as f:
                 h.update(f.read())
     return h.hexdigest()[:16]
+
+
+# Bytes the environment server's mailboxes move per SERVED env-step, by the protocol (grl_amd/csrc/grlx_env_server.h, grlx_env_server_wide.h;
+# 16-byte units {value, sequence}, device scope).  Stored: the candidates of all three actions + the command.  Loaded at least once: the
+# candidate the sampler chose + the command (the server).  Repeated polls of a unit that has not arrived yet are NOT in these figures
+# (a GRLX_ENV_SERVER_STATS build counts them: DESIGN.md 4.1g), nor are the S units a trial start writes and the server reads once per
+# EPISODE (reported beside them).
+MAILBOX = {
+    "pendulum_sarsa": dict(units_per_candidate=5, state_units=3),          # {x0, x1, x2, obs0, reward}
+    "acrobot_q": dict(units_per_candidate=5 + 1, state_units=5),           # {x[0..S), reward}, S = 5
+    "compass_walker_q": dict(units_per_candidate=11 + 1, state_units=11),  # S = 11
+}
+
+
+def mailbox_bytes_per_step(graph: str):
+    m = MAILBOX.get(graph)
+    if not m:
+        return None
+    stored = 3 * m["units_per_candidate"] * 16 + 8
+    loaded = m["units_per_candidate"] * 16 + 8
+    return {"stored": stored, "loaded": loaded, "total": stored + loaded, "per_episode_not_included": 2 * m["state_units"] * 16}
 
 
 def measured_pmc(key: str, n_replicas: int, trials_per_launch: int):
@@ -362,10 +384,22 @@ def run_rollout_workload(name, D, torch, steps, warmup, replicas=None, table_log
         if "oracle_this_run" in bytes_:
             c["report"]["roofline"]["oracle_bytes_per_learn_step_on_these_trials"] = bytes_["oracle_this_run"]
         if c["env_server"] != (0, 0):
-            # the pendulum kernels take their RK4 steps from a second, co-resident kernel (grl_amd/csrc/grlx_env_server.h); kernel_ms_avg spans
-            # the pair.  Its mailboxes add ~0.4 KB per env-step of device-scope traffic (240 B of candidates stored, 80 B loaded, 8 B of command, the polls) that the counters of `traffic` (collected with the
-            # server off: rocprofv3 serialises kernels while it reads counters) do not hold.
+            # the environment steps come from a second, co-resident kernel (grl_amd/csrc/grlx_env_server.h, grlx_env_server_wide.h); kernel_ms_avg
+            # spans the pair.  The counters behind `traffic` are collected with the server off (rocprofv3 serialises kernels while it reads
+            # counters), so the mailboxes' bytes are added here from the protocol: per served env-step, times the steps the served replicas took.
+            served_share = c["env_server"][0] / max(sum(c["env_server"]), 1)
+            env_steps = (c["learn"] + c["test"]) / steps
+            mb = mailbox_bytes_per_step(c["graph"])
             c["report"]["env_server"] = {"replicas_served": c["env_server"][0], "replicas_fell_back": c["env_server"][1]}
+            if mb:
+                mail = mb["total"] * env_steps * served_share
+                c["report"]["env_server"]["mailbox_bytes_per_served_step"] = mb
+                r = c["report"]["roofline"]
+                r["traffic_mailbox"] = mail
+                r["traffic_kernel_alone"] = traffic
+                if traffic is not None:
+                    r["traffic"] = traffic + mail
+                    r["traffic_source"] = src + " (the rollout kernel with the server off) + the mailboxes' bytes by the protocol, polls excluded (traffic_mailbox)"
         if cpu:
             c["report"]["cpu_baseline"] = cpu
     out["config"] = {"workload": "; ".join(text), "replicas_per_gpu": n_rank, "parallelism": out["parallelism"]}

@@ -14,8 +14,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgrlx.so")
 SOURCES = ["grlx_kernels.hip", "grlx_fqi.hip", "grlx_api.cpp"]
 HEADERS = ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", "grlx_policy.h", "grlx_update.h",
-           "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h", "grlx_env_server.h", "grlx_step.h",
+           "grlx_rollout.h", "grlx_rollout_wide.h", "grlx_rollout_ac.h", "grlx_rollout_ac_wide.h", "grlx_rollout_qv.h", "grlx_rollout_acc.h", "grlx_rollout_tgt.h", "grlx_env_server.h", "grlx_env_server_wide.h", "grlx_step.h",
            os.path.join("..", "..", "include", "grlx.h")]
+FQI_HEADERS = ["grlx_math_batch.h"]          # included by grlx_fqi.hip only
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 TAG_DEFINE = "-DGRLX_BUILD_PIPELINE="
 # per-source device flags.  The batch path runs ONE wave per SIMD (92 KB of LDS per block): nothing but instruction-level parallelism
@@ -47,7 +48,7 @@ def _stale() -> bool:
     except OSError:
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "_exec_prologue.py")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + FQI_HEADERS] + [os.path.abspath(__file__), os.path.join(HERE, "_exec_prologue.py")]
     if not os.path.exists(LIB + ".asmfix"):
         return True
     return any(os.path.getmtime(d) > t for d in deps)
@@ -107,7 +108,7 @@ def _build_hip_object(hipcc, src, tmp, flags, verbose, report):
 # (outside the tree: $GRLX_OBJCACHE or /tmp/grlx_objcache), so that editing grlx_api.cpp does not recompile the kernels
 UNIT_DEPS = {
     "grlx_kernels.hip": [h for h in HEADERS],
-    "grlx_fqi.hip": ["grlx_internal.h", "grlx_math.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", os.path.join("..", "..", "include", "grlx.h")],
+    "grlx_fqi.hip": ["grlx_internal.h", "grlx_math.h", "grlx_math_batch.h", "grlx_rng.h", "grlx_tile.h", "grlx_table.h", "grlx_envs.h", os.path.join("..", "..", "include", "grlx.h")],
     "grlx_api.cpp": ["grlx_internal.h", os.path.join("..", "..", "include", "grlx.h")],
 }
 

@@ -272,13 +272,7 @@ int make_params(const grlx_config &c, DevParams *P)
   }
   if (c.test_trials < 0) return fail(GRLX_ERR_INVALID, "experiment/online_learning:test_trials");
   P->test_trials = c.test_trials > 1 ? c.test_trials : 1;
-  if (P->test_trials > 1)
-  {
-    const bool plain_q = !ac && !qv && c.target_interval == 0 && c.projector.safe == 0 && c.trace != GRLX_TRACE_ACCUMULATING && c.agent != GRLX_AGENT_ADVANTAGE;
-    if (!plain_q && !ac)
-      return fail(GRLX_ERR_INVALID, "experiment/online_learning:test_trials > 1 is built for SARSA / Q / Expected SARSA with the replacing trace and for the actor-critic agent");
-    if (c.tap_capacity > 0) return fail(GRLX_ERR_INVALID, "test_trials > 1 is not available with taps");
-  }
+  if (P->test_trials > 1 && c.tap_capacity > 0) return fail(GRLX_ERR_INVALID, "test_trials > 1 is not available with taps");
   P->epsilon = c.epsilon;
   P->decay_rate = c.decay_rate;
   P->decay_min = c.decay_min;
@@ -339,6 +333,7 @@ struct grlx_ctx {
   int          env_server = 1;            // GRLX_ENV_SERVER=0 turns it off
   void         *park = nullptr;           // rotating actor-critic kernel: parked lane state of the third sub-batch, per wave
   EnvMail      *env_mail = nullptr;
+  size_t       env_mail_bytes = 0;        // per replica: kEnvMailBytes (pendulum kernels) or kWideMailBytes (wide kernels)
   hipStream_t  srv_stream = nullptr;
   hipEvent_t   srv_go = nullptr, srv_done = nullptr;
   // per-step entry points (grlx_env_start / _advance, grlx_agent_start / _step / _end): agent state between calls and the staging
@@ -499,9 +494,12 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   *out = nullptr;
   if (cfg->n_replicas < 1) return fail(GRLX_ERR_INVALID, "n_replicas must be >= 1");
   if (cfg->max_rows < 1) return fail(GRLX_ERR_INVALID, "max_rows must be >= 1");
-  if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8 &&
+  // 16 for the TD agents: the four-sub-batch instantiations of rollout_wide_kernel (the acrobot and the compass walker, three actions)
+  const bool td16 = cfg->replicas_per_wave == 16 && (cfg->env == GRLX_ENV_ACROBOT || cfg->env == GRLX_ENV_COMPASS_WALKER) && cfg->action_steps == 3 &&
+                    (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA);
+  if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8 && !td16 &&
       !((cfg->replicas_per_wave == 12 || cfg->replicas_per_wave == 16) && cfg->agent == GRLX_AGENT_AC))
-    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8 (12, 16: actor-critic only)");
+    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8 (12: actor-critic only; 16: actor-critic, and the TD agents on the acrobot / the compass walker with 3 actions)");
   if (cfg->wave_limit < 0) return fail(GRLX_ERR_INVALID, "wave_limit must be 0 (automatic) or positive");
   if (cfg->tap_deferred && cfg->tap_replica >= 0 && cfg->tap_capacity > 0)
   {
@@ -562,6 +560,11 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
       if (per_simd >= 15) rpw = 16;
       else if (per_simd >= 9) rpw = 12;
     }
+    // TD agents on the acrobot / the compass walker (the environment phase is half of a pass), 15 or more replicas per SIMD: four sub-batches
+    // per wave share one environment phase (rollout_wide_kernel<., 3, 4, .>)
+    if (cfg->replicas_per_wave == 0 && cfg->agent != GRLX_AGENT_AC && rpw == 8 && cfg->action_steps == 3 &&
+        (cfg->env == GRLX_ENV_ACROBOT || cfg->env == GRLX_ENV_COMPASS_WALKER) && (N + simds - 1) / simds >= 15)
+      rpw = 16;
     if (!has_wide || P.tap_capacity > 0) rpw = 4;
     P.replicas_per_wave = rpw;
     P.wave_limit = cfg->wave_limit > 0 ? cfg->wave_limit : simds;      // these kernels hold a SIMD's whole register file: one wave per SIMD
@@ -596,6 +599,11 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   if (cfg->agent == GRLX_AGENT_AC && P.replicas_per_wave >= 12)
   { // the sub-batches beyond the second park their lane state here (grlx_rollout_ac_wide.h)
     CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * (size_t)(P.replicas_per_wave / 4 - 2) * (size_t)P.wave_limit));
+    P.park = ctx->park;
+  }
+  else if (P.replicas_per_wave == 16)
+  { // ... and those of the TD agents' four-sub-batch waves (grlx_rollout_wide.h): one wave per 16 replicas, two areas each
+    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * 2 * (((size_t)N + 15) / 16)));
     P.park = ctx->park;
   }
   CTX_TRY(hipMalloc((void **)&ctx->max_load, sizeof(uint32_t)));
@@ -830,7 +838,8 @@ int grlx_reset_run(grlx_ctx *ctx)
 static bool env_server_ready(grlx_ctx *ctx)
 {
   if (ctx->env_mail) return true;
-  bool ok = hipMalloc((void **)&ctx->env_mail, (size_t)ctx->P.n_replicas * kEnvMailBytes) == hipSuccess;
+  ctx->env_mail_bytes = env_server_mail_bytes(ctx->P);
+  bool ok = ctx->env_mail_bytes != 0 && hipMalloc((void **)&ctx->env_mail, (size_t)ctx->P.n_replicas * ctx->env_mail_bytes) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&ctx->srv_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->srv_go, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->srv_done, hipEventDisableTiming) == hipSuccess;
@@ -850,15 +859,8 @@ static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *
   if (!ctx || n_trials < 0) return fail(GRLX_ERR_INVALID, "bad argument");
   if (ctx->cfg.env == GRLX_ENV_EXTERNAL) return fail(GRLX_ERR_INVALID, "this context has no environment (GRLX_ENV_EXTERNAL): drive it through grlx_agent_start / _step / _end");
   if (n_trials == 0) return GRLX_OK;
-  if (steps_budget != 0)
-  {
-    const bool plain_q = ctx->cfg.agent != GRLX_AGENT_AC && ctx->cfg.agent != GRLX_AGENT_QV && ctx->cfg.target_interval == 0 &&
-                         ctx->cfg.projector.safe == 0 && ctx->cfg.trace != GRLX_TRACE_ACCUMULATING && ctx->cfg.agent != GRLX_AGENT_ADVANTAGE;
-    if (!plain_q && ctx->cfg.agent != GRLX_AGENT_AC)
-      return fail(GRLX_ERR_INVALID, "a steps budget is built for SARSA / Q / Expected SARSA with the replacing trace and for the actor-critic agent");
-    if (ctx->P.tap_capacity > 0 || ctx->P.diag_out)
-      return fail(GRLX_ERR_INVALID, "a steps budget is not available with taps or diagnostics");
-  }
+  if (steps_budget != 0 && (ctx->P.tap_capacity > 0 || ctx->P.diag_out))
+    return fail(GRLX_ERR_INVALID, "a steps budget is not available with taps or diagnostics");
   if (!ctx->run_pending && ctx->P.logC < ctx->logC_max)
   { // nothing in flight: how full did the last run leave the fullest table?  Beyond a quarter, grow to an eighth.
     uint32_t used = 0;
@@ -928,12 +930,12 @@ static int run_trials(grlx_ctx *ctx, int n_trials, uint64_t steps_budget, void *
       HIP_TRY(launch_rollout_tgt(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
     else if (ctx->cfg.trace == GRLX_TRACE_ACCUMULATING)
       HIP_TRY(launch_rollout_acc(Pb, n, (hipStream_t)stream, &ctx->last_kernel));
-    else if (ctx->env_server && env_server_serves(Pb) && (size_t)ctx->P.n_replicas * kEnvMailBytes < (1ull << 31) && env_server_ready(ctx))
+    else if (ctx->env_server && env_server_serves(Pb) && (size_t)ctx->P.n_replicas * env_server_mail_bytes(Pb) < (1ull << 31) && env_server_ready(ctx))
     { // the server's launch forks off the caller's stream and joins it again: for the caller, still one stream-ordered operation
       Pb.env_mail = ctx->env_mail;
       Pb.env_tune = 3u;        // the rollout wave is the critical path: it issues first, the server fills its gaps (+0.7 %)
       if (const char *tune = getenv("GRLX_ENV_SERVER_TUNE")) Pb.env_tune = (uint32_t)strtoul(tune, nullptr, 0);
-      HIP_TRY(hipMemsetAsync(ctx->env_mail, 0, (size_t)ctx->P.n_replicas * kEnvMailBytes, (hipStream_t)stream));
+      HIP_TRY(hipMemsetAsync(ctx->env_mail, 0, (size_t)ctx->P.n_replicas * ctx->env_mail_bytes, (hipStream_t)stream));
       HIP_TRY(hipEventRecord(ctx->srv_go, (hipStream_t)stream));
       HIP_TRY(hipStreamWaitEvent(ctx->srv_stream, ctx->srv_go, 0));
       HIP_TRY(launch_env_server(Pb, ctx->srv_stream));
@@ -956,7 +958,7 @@ int grlx_env_server_debug(grlx_ctx *ctx, void *out, size_t bytes)
   if (!ctx || !out) return fail(GRLX_ERR_INVALID, "bad argument");
   if (!ctx->env_mail) return fail(GRLX_ERR_INVALID, "the environment server has not run in this context");
   DRAIN(ctx);
-  const size_t have = (size_t)ctx->P.n_replicas * kEnvMailBytes;
+  const size_t have = (size_t)ctx->P.n_replicas * ctx->env_mail_bytes;
   HIP_TRY(hipMemcpy(out, ctx->env_mail, bytes < have ? bytes : have, hipMemcpyDeviceToHost));
   return GRLX_OK;
 }
@@ -970,7 +972,7 @@ int grlx_env_server_counts(grlx_ctx *ctx, int *served, int *fell_back)
   if (!ctx->env_mail) return GRLX_OK;
   DRAIN(ctx);
   std::vector<unsigned long long> flag((size_t)ctx->P.n_replicas);
-  HIP_TRY(hipMemcpy2D(flag.data(), sizeof(unsigned long long), (const char *)ctx->env_mail + kEnvMailFlagOffset, kEnvMailBytes,
+  HIP_TRY(hipMemcpy2D(flag.data(), sizeof(unsigned long long), (const char *)ctx->env_mail + kEnvMailFlagOffset, ctx->env_mail_bytes,
                       sizeof(unsigned long long), (size_t)ctx->P.n_replicas, hipMemcpyDeviceToHost));
   for (unsigned long long f : flag)
   {

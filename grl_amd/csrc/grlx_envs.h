@@ -18,6 +18,13 @@ struct LaneShare {
   int src[3];          // lane of my replica that evaluates role 0, 1, 2
   int role3, role2;    // my role when three / two evaluations are shared out
 };
+// Two lanes per (replica, action) pair share an equation of motion (the environment server of the wide kernels, grlx_env_server_wide.h:
+// 8 replicas x 3 actions x 2 roles = 48 lanes): the walker's two angles one each, the acrobot's three as 1 + 2.
+struct PairShare {
+  static constexpr bool kSplit = true;
+  int src[2];          // lane that evaluates role 0, 1
+  int role2;           // my role
+};
 __device__ __forceinline__ double lane_fetch(double v, int src) { return __shfl(v, src, 64); }
 
 // dynamics/pendulum + task/pendulum/swingup (pendulum.cpp:40-145)
@@ -130,6 +137,38 @@ template <> struct Env<GRLX_ENV_ACROBOT> {
     psincos(angle, k, sn, cs);                                   // psincos' cosine == pcos (same quadrant logic, same kernels)
     const double s2 = lane_fetch(sn, ls.src[0]), c2 = lane_fetch(cs, ls.src[0]);
     const double cos_elbow = lane_fetch(cs, ls.src[1]), cos_shoulder = lane_fetch(cs, ls.src[2]);
+
+    const double g_elbow = kElbowGrav * cos_elbow;
+    const double bias = kCoriolis * w2 * w2 * s2 - kCoupling * w2 * w1 * s2 + kShoulderGrav * cos_shoulder + g_elbow;
+    const double m_cross = 1.0 * (0.5 * 0.5 + 1.0 * 0.5 * c2) + 1.0;
+    const double m_shoulder = 1.0 * 0.5 * 0.5 + 1.0 * (1.0 * 1.0 + 0.5 * 0.5 + 2 * 1.0 * 0.5 * c2) + 1.0 + 1.0;
+    double a_elbow = (u + m_cross * bias / m_shoulder - 1.0 * 1.0 * 0.5 * w2 * w2 * s2 - g_elbow) /
+                     (kElbowInertia - m_cross * m_cross / m_shoulder);
+    double a_shoulder = -(m_cross * a_elbow + bias) / m_shoulder;
+    if (w1 > 4 * GRLX_PI) a_shoulder = fmin(a_shoulder, 0.);
+    if (w1 < -4 * GRLX_PI) a_shoulder = fmax(a_shoulder, 0.);
+    if (w2 > 9 * GRLX_PI) a_elbow = fmin(a_elbow, 0.);
+    if (w2 < -9 * GRLX_PI) a_elbow = fmax(a_elbow, 0.);
+    xd[0] = w1;
+    xd[1] = w2;
+    xd[2] = a_shoulder;
+    xd[3] = a_elbow;
+    xd[4] = 1;
+  }
+  // ... and shared out over TWO lanes: role 0 evaluates the elbow angle (sine and cosine), role 1 the two gravity cosines
+  __device__ static __forceinline__ void eom(const Consts &k, const double *x, double u, double *xd, const PairShare &ls)
+  {
+    constexpr double kElbowGrav = 1.0 * 0.5 * 9.8;
+    constexpr double kCoriolis = -1.0 * 1.0 * 0.5;
+    constexpr double kCoupling = 2 * 1.0 * 1.0 * 0.5;
+    constexpr double kShoulderGrav = (1.0 * 0.5 + 1.0 * 1.0) * 9.8;
+    constexpr double kElbowInertia = 1.0 * 0.5 * 0.5 + 1.0;
+    const double q1 = x[0], q2 = x[1], w1 = x[2], w2 = x[3];
+    double sn, cs, sn_b, cs_b;
+    psincos(ls.role2 == 0 ? q2 : q1 + q2 - GRLX_PI / 2, k, sn, cs);       // psincos' cosine == pcos (same quadrant logic, same kernels)
+    psincos(q1 - GRLX_PI / 2, k, sn_b, cs_b);                             // (role 0 evaluates it too and does not use it: one instruction stream)
+    const double s2 = lane_fetch(sn, ls.src[0]), c2 = lane_fetch(cs, ls.src[0]);
+    const double cos_elbow = lane_fetch(cs, ls.src[1]), cos_shoulder = lane_fetch(cs_b, ls.src[1]);
 
     const double g_elbow = kElbowGrav * cos_elbow;
     const double bias = kCoriolis * w2 * w2 * s2 - kCoupling * w2 * w1 * s2 + kShoulderGrav * cos_shoulder + g_elbow;
@@ -293,6 +332,18 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
   // the same with the sine constants held in registers by model_step (20 sub-steps x 10 evaluations)
   __device__ static __forceinline__ double hip_x(const SinConsts &k, const St &m) { return m.sfx - psin_s(m.sla, k); }
   __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m) { return pcos_s(m.sla, k) - pcos_s(m.sla - m.ha, k); }
+  // ... its two cosines one each where the lanes of a replica share evaluations (role 0: the stance leg, role 1: the swing leg)
+  template <typename SH>
+  __device__ static __forceinline__ double swing_y(const SinConsts &k, const St &m, const SH &sh)
+  {
+    if constexpr (SH::kSplit)
+    {
+      const double c = pcos_s(sh.role2 == 0 ? m.sla : m.sla - m.ha, k);
+      return lane_fetch(c, sh.src[0]) - lane_fetch(c, sh.src[1]);
+    }
+    else
+      return swing_y(k, m);
+  }
   __device__ static __forceinline__ void wrap(St &m)
   { // SWModel.h:48-59
     if (m.sla >= GRLX_PI) m.sla -= 2*GRLX_PI;
@@ -357,28 +408,31 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
   // and below at `below` (time dt).  A bracketing secant search on the swing-foot height: integrate from the upper
   // bracket by the linearly interpolated time to the zero crossing, replace the bracket on the same side, stop when
   // either bracket is within `tol` of the ground or after ten rounds.  Returns the time LEFT in the sub-step after the
-  // strike; `hit` is the state at the strike.
+  // strike; `hit` is the state at the strike.  The height is a pure function of the state: the text asks for the
+  // brackets' heights again in every round (five evaluations per round); here each state's height is evaluated once,
+  // when the state is reached, and carried with it (y_above, y_below: the caller's detectEvents has them).
   template <typename SH>
-  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &above, const St &below, St &hit, double torque,
-                                                             double tol, double dt, const SH &sh)
+  __device__ static __forceinline__ double heelstrike_moment(const DevParams &P, const SinConsts &k, const St &above, double y_above, const St &below,
+                                                             double y_below, St &hit, double torque, double tol, double dt, const SH &sh)
   {
     St up = above, down = below;                  // brackets: swing foot above / below the ground
+    double y_up = y_above, y_down = y_below, y_hit = y_above;
     double t_up = 0, t_down = dt;
     for (int round = 0; round < 10; ++round)
     {
       hit = up;
-      const double y_up = swing_y(k, up);
-      const double t_cross = (t_down - t_up) * y_up / (y_up - swing_y(k, down));
+      const double t_cross = (t_down - t_up) * y_up / (y_up - y_down);
       rk4(P, k, hit, torque, t_cross, sh);
-      if (swing_y(k, hit) > 0) { up = hit; t_up = t_up + t_cross; }
-      else { down = hit; t_down = t_up + t_cross; }
-      if (swing_y(k, up) < tol) { hit = up; return dt - t_up; }
-      if (-swing_y(k, down) < tol) { hit = down; return dt - t_down; }
+      y_hit = swing_y(k, hit, sh);
+      if (y_hit > 0) { up = hit; y_up = y_hit; t_up = t_up + t_cross; }
+      else { down = hit; y_down = y_hit; t_down = t_up + t_cross; }
+      if (y_up < tol) { hit = up; return dt - t_up; }
+      if (-y_down < tol) { hit = down; return dt - t_down; }
     }
     // not converged: the side the last probe fell on
-    return (swing_y(k, hit) > 0) ? dt - t_up : dt - t_down;
+    return (y_hit > 0) ? dt - t_up : dt - t_down;
   }
-  template <typename SH>
+  template <typename SH, bool PIN = true>
   __device__ static __forceinline__ void model_step(const DevParams &P, const double *x, double torque, double *next, const SH &sh)
   { // CompassWalkerModel::step (compass_walker.cpp:63-94) around CSWModel::singleStep (SWModel.cpp:142-210)
     St st, prev, hs;
@@ -387,8 +441,8 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
     hs = st;
     bool changed = false;
     const double partial = P.walker_dt;
-    const SinConsts k = sin_consts<true>();
-    double y_prev = swing_y(k, prev);            // swing_y(prev) of the next sub-step is this sub-step's swing_y(st)
+    const SinConsts k = sin_consts<PIN>();       // PIN: the sine's constants held in vector registers across the 20 sub-steps
+    double y_prev = swing_y(k, prev, sh);            // swing_y(prev) of the next sub-step is this sub-step's swing_y(st)
     for (int i = 0; i < P.integration_steps; i++)
     {
       rk4(P, k, st, torque, partial, sh);
@@ -396,13 +450,13 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
       // detectEvents (SWModel.cpp:30-45)
       double timeleft = 0;
       bool struck = false;
-      const double y_now = swing_y(k, st);
+      const double y_now = swing_y(k, st, sh);
       if ((y_prev >= 0) && (y_now < 0))
         if (((prev.ha < 0) && (st.ha < 0)) || ((prev.ha > 0) && (st.ha > 0)))
           if ((st.slar < 0) && (st.ha < 0))
           { // processStanceLegChange (:106-124)
             struck = true;
-            timeleft = heelstrike_moment(P, k, prev, st, hs, torque, 1.0E-11, partial, sh);
+            timeleft = heelstrike_moment(P, k, prev, y_prev, st, y_now, hs, torque, 1.0E-11, partial, sh);
             const double c2 = pcos(2.0*hs.sla, k);
             st.har  = hs.slar*(c2*(1.0 - c2));
             st.slar = hs.slar*(c2);
@@ -417,7 +471,7 @@ template <> struct Env<GRLX_ENV_COMPASS_WALKER> {
         wrap(st);
       }
       // a pure function of the state: recomputed only where a heel strike replaced the state
-      y_prev = struck ? swing_y(k, st) : y_now;
+      y_prev = struck ? swing_y(k, st, sh) : y_now;
       prev = st;
     }
 #pragma unroll
@@ -547,7 +601,7 @@ __device__ __forceinline__ void env_step(const DevParams &P, double *x, double a
   constexpr int S = Env<ENV>::S;
   double next[S];
   if constexpr (HasCustomModel<ENV>::value)
-    Env<ENV>::model_step(P, x, Env<ENV>::actuate(action), next, sh);  // model/compass_walker integrates itself
+    Env<ENV>::template model_step<SH, PIN>(P, x, Env<ENV>::actuate(action), next, sh);  // model/compass_walker integrates itself
   else
     rk4_step<ENV, PIN, SH>(P, x, Env<ENV>::actuate(action), next, sh);
   terminal = Env<ENV>::observe(P, next, obs);

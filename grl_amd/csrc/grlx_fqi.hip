@@ -20,6 +20,7 @@
 #include <vector>
 #include "grlx_internal.h"
 #include "grlx_math.h"
+#include "grlx_math_batch.h"
 #include "grlx_rng.h"
 #include "grlx_tile.h"
 #include "grlx_table.h"

@@ -9,6 +9,7 @@ namespace grlx {
 constexpr int kLanesPerReplica = 16;     // one lane per tiling
 constexpr size_t kEnvMailBytes = 1024;    // sizeof(EnvMail), grlx_env_server.h
 constexpr size_t kEnvMailFlagOffset = 128 + 15 * 8;   // offsetof(EnvMail, stats[15]): served to the end 1 / fell back 2
+constexpr size_t kWideMailBytes = 2048;   // >= sizeof(WideMail<ENV>), grlx_env_server_wide.h (the wide kernels' environment server)
 constexpr size_t kAcParkBytes = 12 * 64 * 16 + 3 * 64 * 4;     // grlx_rollout_ac_wide.h: kWideQuads quads + three counters per lane
 constexpr int kReplicasPerWave = 4;      // per sub-batch; a wide wave carries 4*B (grlx_rollout_wide.h)
 constexpr int kMaxTrace = 10;            // replacing trace: (gamma*lambda)^n < 0.01 must hold for n <= 10
@@ -149,6 +150,7 @@ struct DevParams {
 // *variant (optional) receives the GRLX_KERNEL_* instantiation that was launched
 hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 bool       env_server_serves(const DevParams &P);                                   // is this context's rollout kernel one the environment server works for?
+size_t     env_server_mail_bytes(const DevParams &P);                               // ... and the size of a replica's mailbox there (0: not served)
 hipError_t launch_env_server(const DevParams &P, hipStream_t stream);
 hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t stream, int *variant);
 hipError_t launch_rollout_qv(const DevParams &P, int n_trials, hipStream_t stream, int *variant);

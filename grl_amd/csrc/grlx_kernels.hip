@@ -20,6 +20,8 @@
 //
 // Compiled with -ffp-contract=off: the reference's arithmetic is plain IEEE
 // double without fused multiply-add (x86-64 baseline); only grlx_math.h fuses.
+#include <cstdio>
+#include <cstdlib>
 #include "grlx_internal.h"
 #include "grlx_math.h"
 #include "grlx_rng.h"
@@ -41,6 +43,7 @@ namespace grlx {
 
 #include "grlx_update.h"
 #include "grlx_env_server.h"
+#include "grlx_env_server_wide.h"
 #include "grlx_rollout.h"
 #include "grlx_rollout_wide.h"
 #include "grlx_rollout_ac.h"
@@ -169,17 +172,77 @@ hipError_t launch_rollout_ac(const DevParams &P, int n_trials, hipStream_t strea
   return hipGetLastError();
 }
 
-// The environment server works for the deferred-update pendulum instantiations of rollout_kernel with three actions (EXT in grlx_rollout.h).
+// The environment server works for the deferred-update pendulum instantiations of rollout_kernel with three actions (EXT in grlx_rollout.h),
+// and -- its own kernel, grlx_env_server_wide.h -- for the wide kernels of the acrobot and the compass walker (8 replicas per wave, three actions).
+// do a wave of the rollout kernel and a wave of its server fit on one SIMD together (512 registers)?  asked of the runtime once per pair
+template <typename KA, typename KB>
+static bool waves_fit_together(KA rollout, KB server)
+{
+  hipFuncAttributes a, b;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void *>(rollout)) != hipSuccess || hipFuncGetAttributes(&b, reinterpret_cast<const void *>(server)) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return false;
+  }
+  const int gran = 8;                                  // allocation granule of the unified register file
+  const int ra = (a.numRegs + gran - 1) / gran * gran, rb = (b.numRegs + gran - 1) / gran * gran;
+  if (getenv("GRLX_ENV_SERVER_DEBUG"))
+    fprintf(stderr, "grlx: rollout wave %d registers (%zu B scratch, %zu B LDS) + server wave %d registers (%zu B scratch): %s\n", a.numRegs, a.localSizeBytes,
+            a.sharedSizeBytes, b.numRegs, b.localSizeBytes, ra + rb <= 512 ? "resident together" : "do not fit one SIMD");
+  return ra + rb <= 512;
+}
+static bool env_server_wide(const DevParams &P)
+{
+  const bool inplace = P.diag_out != nullptr || (P.tap_replica >= 0 && P.tap_capacity > 0);
+  const bool td = P.agent == GRLX_AGENT_SARSA || P.agent == GRLX_AGENT_Q || P.agent == GRLX_AGENT_EXPECTED_SARSA;
+  if (!(!inplace && P.replicas_per_wave == 8 && (P.env == GRLX_ENV_ACROBOT || P.env == GRLX_ENV_COMPASS_WALKER) && P.A == 3 && td &&
+        P.trace_kind != GRLX_TRACE_ACCUMULATING && P.target_interval == 0 && P.tile_safe == 0))
+    return false;
+  // The walker's server is built and tested but NOT the default: beside the 346-register rollout wave it has 160 registers, too few to hold
+  // the sine's constants and the integrator's stages, and the code it becomes issues more vector instructions than the SIMD has slots left
+  // (measured: 180-213 M env-steps/s with it against 220 M without).  GRLX_ENV_SERVER_WALKER=1 turns it on.
+  if (P.env == GRLX_ENV_COMPASS_WALKER)
+  {
+    const char *w = getenv("GRLX_ENV_SERVER_WALKER");
+    if (!w || atoi(w) == 0) return false;
+  }
+  // a server that cannot be resident beside its rollout wave would only be waited for in vain (8000 polls at the first step)
+  static const bool fit_walker_spec = waves_fit_together(rollout_wide_served_kernel<GRLX_ENV_COMPASS_WALKER, SpecWalkerQ>, env_server_walker_kernel<SpecWalkerQ>);
+  static const bool fit_acrobot_spec = waves_fit_together(rollout_wide_served_kernel<GRLX_ENV_ACROBOT, SpecAcrobotQ>, env_server_acrobot_pinned_kernel<SpecAcrobotQ>);
+  static const bool fit_walker = waves_fit_together(rollout_wide_served_kernel<GRLX_ENV_COMPASS_WALKER, SpecNone>, env_server_walker_kernel<SpecNone>);
+  static const bool fit_acrobot = waves_fit_together(rollout_wide_served_kernel<GRLX_ENV_ACROBOT, SpecNone>, env_server_acrobot_kernel<SpecNone>);
+  if (!P.no_specialisation && SpecWalkerQ::matches(P)) return fit_walker_spec;
+  if (!P.no_specialisation && SpecAcrobotQ::matches(P)) return fit_acrobot_spec;
+  return P.env == GRLX_ENV_ACROBOT ? fit_acrobot : fit_walker;
+}
 bool env_server_serves(const DevParams &P)
 {
   const bool inplace = P.diag_out != nullptr || (P.tap_replica >= 0 && P.tap_capacity > 0);
-  return !inplace && P.replicas_per_wave != 8 && P.env == GRLX_ENV_PENDULUM && P.A == 3 && P.agent != GRLX_AGENT_ADVANTAGE;
+  if (env_server_wide(P)) return true;
+  return !inplace && P.replicas_per_wave == 4 && P.env == GRLX_ENV_PENDULUM && P.A == 3 && P.agent != GRLX_AGENT_ADVANTAGE;
+}
+size_t env_server_mail_bytes(const DevParams &P)
+{
+  return env_server_wide(P) ? kWideMailBytes : env_server_serves(P) ? kEnvMailBytes : 0;
 }
 
 // One block per rollout wave, with the numeric parameters of the instantiation launch_rollout picks (same constants, same folding).
 hipError_t launch_env_server(const DevParams &P, hipStream_t stream)
 {
   if (!P.env_mail || !env_server_serves(P)) return hipErrorInvalidValue;
+  if (env_server_wide(P))
+  { // one block per wide rollout wave (8 replicas), with the numeric parameters of the instantiation launch_rollout picks
+    const int wwaves = (P.n_replicas + 7) / 8;
+    if (!P.no_specialisation && SpecWalkerQ::matches(P))
+      hipLaunchKernelGGL((env_server_walker_kernel<SpecWalkerQ>), dim3(wwaves), dim3(64), 0, stream, P);
+    else if (!P.no_specialisation && SpecAcrobotQ::matches(P))
+      hipLaunchKernelGGL((env_server_acrobot_pinned_kernel<SpecAcrobotQ>), dim3(wwaves), dim3(64), 0, stream, P);
+    else if (P.env == GRLX_ENV_ACROBOT)
+      hipLaunchKernelGGL((env_server_acrobot_kernel<SpecNone>), dim3(wwaves), dim3(64), 0, stream, P);
+    else
+      hipLaunchKernelGGL((env_server_walker_kernel<SpecNone>), dim3(wwaves), dim3(64), 0, stream, P);
+    return hipGetLastError();
+  }
   const int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
 #define GRLX_LAUNCH_SERVER(AGENT)                                                                                      \
   if (!P.no_specialisation && SpecPendulumTcA<AGENT>::matches(P))                                                    \
@@ -199,6 +262,25 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
 {
   if (variant) *variant = GRLX_KERNEL_GENERIC;
   int waves = (P.n_replicas + kReplicasPerWave - 1) / kReplicasPerWave;
+  if (P.env_mail && env_server_wide(P))
+  { // the wide kernels' environment server (launch_env_server picks the same numeric parameters)
+    const int wwaves = (P.n_replicas + 7) / 8;
+#define GRLX_LAUNCH_WSERVED(SPECQ)                                                                                     \
+    if (!P.no_specialisation && SPECQ::matches(P))                                                                   \
+    {                                                                                                                \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                               \
+      hipLaunchKernelGGL((rollout_wide_served_kernel<SPECQ::kEnv, SPECQ>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                      \
+    }
+    GRLX_LAUNCH_WSERVED(SpecWalkerQ)
+    GRLX_LAUNCH_WSERVED(SpecAcrobotQ)
+#undef GRLX_LAUNCH_WSERVED
+    if (P.env == GRLX_ENV_ACROBOT)
+      hipLaunchKernelGGL((rollout_wide_served_kernel<GRLX_ENV_ACROBOT, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+    else
+      hipLaunchKernelGGL((rollout_wide_served_kernel<GRLX_ENV_COMPASS_WALKER, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+    return hipGetLastError();
+  }
   if (P.env_mail)
   { // with the environment server (launch_env_server picks the same numeric parameters)
     if (!env_server_serves(P)) return hipErrorInvalidValue;
@@ -265,6 +347,33 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
     GRLX_LAUNCH_ADV(GRLX_ENV_PENDULUM, 3)
     GRLX_LAUNCH_ADV(GRLX_ENV_ACROBOT, 3)
 #undef GRLX_LAUNCH_ADV
+    return hipErrorInvalidValue;
+  }
+  if (!inplace && P.replicas_per_wave == 16)
+  { // 15 or more replicas per SIMD: FOUR sub-batches per wave share one environment phase (E + 4 T per 16 replicas instead of 2 (E + 2 T));
+    // instantiated where the environment phase is half of a pass: the acrobot and the compass walker with three actions
+    const int wwaves = (P.n_replicas + 15) / 16;
+    if (!P.park) return hipErrorInvalidValue;
+#define GRLX_LAUNCH_WIDE4_SPECQ(SPECQ)                                                                                \
+    if (!P.no_specialisation && SPECQ::matches(P))                                                                  \
+    {                                                                                                               \
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;                                                              \
+      hipLaunchKernelGGL((rollout_wide_kernel<SPECQ::kEnv, 3, 4, SPECQ>), dim3(wwaves), dim3(64), 0, stream, P, n_trials); \
+      return hipGetLastError();                                                                                     \
+    }
+    GRLX_LAUNCH_WIDE4_SPECQ(SpecWalkerQ)
+    GRLX_LAUNCH_WIDE4_SPECQ(SpecAcrobotQ)
+#undef GRLX_LAUNCH_WIDE4_SPECQ
+    if (P.env == GRLX_ENV_ACROBOT && P.A == 3)
+    {
+      hipLaunchKernelGGL((rollout_wide_kernel<GRLX_ENV_ACROBOT, 3, 4, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+      return hipGetLastError();
+    }
+    if (P.env == GRLX_ENV_COMPASS_WALKER && P.A == 3)
+    {
+      hipLaunchKernelGGL((rollout_wide_kernel<GRLX_ENV_COMPASS_WALKER, 3, 4, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+      return hipGetLastError();
+    }
     return hipErrorInvalidValue;
   }
   if (!inplace && P.replicas_per_wave == 8)

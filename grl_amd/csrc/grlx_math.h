@@ -420,108 +420,6 @@ __device__ __forceinline__ double pexp(double x)
   return (e * ppow2(k1)) * ppow2(k2);
 }
 
-// The same function for N independent arguments, written stage by stage and without branches: every element sees exactly the
-// operations of pexp (same bits), but the N dependent chains (rint, two reduction fmas, 12 Horner fmas, scaling) stand side by side, so
-// a wave that is alone on its SIMD can fill the latency of one with the others.  The three special ranges are selected at the end;
-// what the main path computes from such an argument is discarded (no instruction here traps).
-template <int N>
-__device__ __forceinline__ void pexp_batch(const double (&x)[N], double (&out)[N])
-{ // __builtin_amdgcn_sched_barrier(0): nothing is scheduled across it -- the stages stay stages (N independent instructions each)
-  double kd[N], r[N], q[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) kd[i] = __builtin_rint(x[i] * 0x1.71547652b82fep+0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-kd[i], 0x1.62e4200000000p-1, x[i]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-kd[i], 0x1.fdf473de6af28p-22, r[i]);
-  __builtin_amdgcn_sched_barrier(0);
-  const double c[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
-                        1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
-#pragma unroll
-  for (int i = 0; i < N; ++i) q[i] = __builtin_fma(r[i], c[0], c[1]);
-#pragma unroll
-  for (int s = 2; s < 12; ++s)
-  {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = __builtin_fma(r[i], q[i], c[s]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) q[i] = 1.0 + __builtin_fma(r[i] * r[i], q[i], r[i]);
-  __builtin_amdgcn_sched_barrier(0);
-  // the three special ranges (NaN, overflow, underflow) are rare: one wave-uniform test decides whether anybody needs the selects
-  bool special = false;
-#pragma unroll
-  for (int i = 0; i < N; ++i) special |= !(x[i] >= -745.2 && x[i] <= 709.782712893384);
-  if (__builtin_expect(__any(special), 0))
-  {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-    { // kd is within +-1100 wherever the main path is kept; clamped so that the exponent arithmetic of the discarded ones stays defined
-      const int k = (int)__builtin_fmax(__builtin_fmin(kd[i], 2000.0), -2000.0), k1 = k / 2, k2 = k - k1;
-      double v = (q[i] * ppow2(k1)) * ppow2(k2);
-      v = (x[i] < -745.2) ? 0.0 : v;
-      v = (x[i] > 709.782712893384) ? __builtin_inf() : v;
-      v = (x[i] != x[i]) ? __builtin_nan("") : v;
-      out[i] = v;
-    }
-  }
-  else
-  {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-    {
-      const int k = (int)kd[i], k1 = k / 2, k2 = k - k1;
-      out[i] = (q[i] * ppow2(k1)) * ppow2(k2);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// x / y[i] for N independent divisors, stage by stage: the correctly rounded IEEE quotient, by the operations the compiler itself emits
-// for an f64 division on this target (LLVM AMDGPU LowerFDIV64: v_div_scale x2, v_rcp, two Newton steps, the scaled quotient with one
-// residual correction in v_div_fmas, v_div_fixup) -- but with the N dependent chains side by side instead of one after the other.
-template <int N>
-__device__ __forceinline__ void pdiv_batch(double x, const double (&y)[N], double (&out)[N])
-{
-  double sd[N], sn[N], rcp[N], t[N], u[N];
-  bool flag[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-  {
-    bool unused;
-    sd[i] = __builtin_amdgcn_div_scale(x, y[i], false, &unused);      // the divisor, scaled
-    sn[i] = __builtin_amdgcn_div_scale(x, y[i], true, &flag[i]);       // the dividend, scaled; its flag steers v_div_fmas
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) rcp[i] = __builtin_amdgcn_rcp(sd[i]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = __builtin_fma(-sd[i], rcp[i], 1.0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) rcp[i] = __builtin_fma(rcp[i], t[i], rcp[i]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = __builtin_fma(-sd[i], rcp[i], 1.0);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) rcp[i] = __builtin_fma(rcp[i], t[i], rcp[i]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) u[i] = sn[i] * rcp[i];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) t[i] = __builtin_fma(-sd[i], u[i], sn[i]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(t[i], rcp[i], u[i], flag[i]), y[i], x);
-  __builtin_amdgcn_sched_barrier(0);
-}
 
 // fmod(x, y) for finite x, y > 0: exact by definition (IEEE remainder toward
 // zero); long division by exactly representable multiples of y.  Each

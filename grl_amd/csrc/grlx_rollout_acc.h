@@ -128,19 +128,30 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
     value_store(tab, pos, limit ? clampd(v, out_min, out_max) : v);
   };
 
-  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  for (int trial = 0; trial < n_trials; ++trial)
   {
+    // online_learning.cpp:154: a replica whose learning steps have reached the steps budget starts no further trial
+    const bool act = live && !(P.steps_budget != 0u && (uint64_t)ss >= P.steps_budget);
+    if (!__any(act)) break;
     const int ti = N.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
-    double obs[D], reward = 0, total_reward = 0;
+    // a test trial is test_trials greedy episodes (online_learning.cpp:161-170): each starts the environment and the agent anew, while
+    // reward and time keep adding up (:202-203); a learning trial is one episode (its `time` = 0 is the sampler's moment to decay)
+    double total_reward = 0, time = 0;
+    const int subtrials = (test && P.test_trials > 1) ? P.test_trials : 1;
+    for (int st = 0; st < P.test_trials; ++st)
+    {
+    const bool episode = act && st < subtrials;
+    if (!__any(episode)) break;
+    double obs[D], reward = 0;
     int terminal = 0;
-    bool running = live;
-    if (live)
+    bool running = episode;
+    if (episode)
     {
       Env<ENV>::start(N, test, TL, G, x);
       Env<ENV>::observe(N, x, obs);
     }
-    double time = 0, action = 0;
+    double action = 0;
     int action_index = 0;
     uint32_t p_pos = kInvalidPos, p_slot = 0;
     bool p_sh = false;
@@ -456,15 +467,17 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
       tsh = 0; tnh = 0; tlen = 0; ttotal = 1.;
     }
 
-    if (live && (ti >= 0 ? test : 1))
+    }   // episodes of the trial
+
+    if (act && (ti >= 0 ? test : 1))
     {
       if (rows < (uint32_t)P.max_rows)
       {
         if (j == 0)
         {
           size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
-          P.row_reward[at] = total_reward;
-          P.row_time[at] = time;
+          P.row_reward[at] = total_reward / (double)subtrials;              // online_learning.cpp:224-225
+          P.row_time[at] = time / (double)subtrials;
           P.row_steps[at] = ss;
           P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
         }
@@ -473,6 +486,7 @@ __global__ __launch_bounds__(64) void rollout_acc_kernel(DevParams P, int n_tria
       else
         status |= ST_ROWS_FULL;
     }
+    tt += act ? 1 : 0;
   }
 
   uint32_t ins = inserted;

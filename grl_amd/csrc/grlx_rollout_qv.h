@@ -69,19 +69,30 @@ __global__ __launch_bounds__(64) void rollout_qv_kernel(DevParams P, int n_trial
   trace_init(tr);
   int tr_len_ref = 0;           // length as the reference reports it (its trace survives test trials)
 
-  for (int trial = 0; trial < n_trials; ++trial, ++tt)
+  for (int trial = 0; trial < n_trials; ++trial)
   {
+    // online_learning.cpp:154: a replica whose learning steps have reached the steps budget starts no further trial
+    const bool act = live && !(P.steps_budget != 0u && (uint64_t)ss >= P.steps_budget);
+    if (!__any(act)) break;
     const int ti = P.test_interval;
     const int test = (ti >= 0 && tt % (ti + 1) == ti) ? 1 : 0;
-    double obs[D], reward = 0, total_reward = 0;
+    // a test trial is test_trials greedy episodes (online_learning.cpp:161-170): each starts the environment and the agent anew, while
+    // reward and time keep adding up (:202-203); a learning trial is one episode (its `time` = 0 is the sampler's moment to decay)
+    double total_reward = 0, time = 0;
+    const int subtrials = (test && P.test_trials > 1) ? P.test_trials : 1;
+    for (int st = 0; st < P.test_trials; ++st)
+    {
+    const bool episode = act && st < subtrials;
+    if (!__any(episode)) break;
+    double obs[D], reward = 0;
     int terminal = 0;
-    bool running = live;
-    if (live)
+    bool running = episode;
+    if (episode)
     {
       Env<ENV>::start(P, test, TL, G, x);
       Env<ENV>::observe(P, x, obs);
     }
-    double time = 0, action = 0;
+    double action = 0;
     int action_index = 0;
     uint32_t qp_pos = kInvalidPos, qp_slot = 0, vp_pos = kInvalidPos, vp_slot = 0;
     bool qp_sh = false, vp_sh = false;
@@ -285,15 +296,17 @@ __global__ __launch_bounds__(64) void rollout_qv_kernel(DevParams P, int n_trial
     // QVPredictor::finalize clears the trace at the next TDAgent::start (qv.cpp:110-116): write it back now
     if (!test) trace_flush(tr, tabV, true);
 
-    if (live && (ti >= 0 ? test : 1))
+    }   // episodes of the trial
+
+    if (act && (ti >= 0 ? test : 1))
     {
       if (rows < (uint32_t)P.max_rows)
       {
         if (j == 0)
         {
           size_t at = (size_t)rows * (size_t)P.n_replicas + (size_t)r;
-          P.row_reward[at] = total_reward;
-          P.row_time[at] = time;
+          P.row_reward[at] = total_reward / (double)subtrials;              // online_learning.cpp:224-225
+          P.row_time[at] = time / (double)subtrials;
           P.row_steps[at] = ss;
           P.row_trial[at] = (ti >= 0) ? (tt + 1 - (tt + 1) / (ti + 1)) : tt;
         }
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(64) void rollout_qv_kernel(DevParams P, int n_trial
       else
         status |= ST_ROWS_FULL;
     }
+    tt += act ? 1 : 0;
   }
 
   uint32_t iq = ins_q, iv = ins_v;

@@ -154,7 +154,7 @@ __device__ __forceinline__ void wide_unpark_decode(WideLane &c, const uint4 *raw
 // per-replica scalars of the table role, parked as a structure of arrays [field][replica in wave]
 enum { WR_G = 0, WR_TL, WR_S1, WR_EPS, WR_TT, WR_SS, WR_TSTEPS, WR_TOTAL, WR_TIME, WR_ACTION, WR_FIELDS64 };
 enum { WR_AIDX = 0, WR_FLAGS, WR_ROWS, WR_LEFT, WR_SUB, WR_FIELDS32 };
-enum : uint32_t { WF_RUNNING = 1u, WF_FIRST = 2u, WF_TEST = 4u, WF_ENDING = 8u };
+enum : uint32_t { WF_RUNNING = 1u, WF_FIRST = 2u, WF_TEST = 4u, WF_ENDING = 8u, WF_SERVED = 16u };
 
 struct WideRep {
   uint64_t G, TL, S1;
@@ -169,6 +169,7 @@ struct WideRep {
   uint32_t rows;
   int      trials_left;         // trials of this launch the replica has not finished yet
   int      sub_left;            // greedy episodes the running test trial still has to run after this one (test_trials, online_learning.cpp:161-170)
+  bool     served;              // the replica still takes its steps from the environment server (grlx_env_server_wide.h) and sends it a command per pass
 };
 
 template <int R>
@@ -185,7 +186,8 @@ __device__ __forceinline__ void wide_rep_store(const WideRep &s, uint64_t *sh64,
   sh64[WR_TIME * R + q] = (uint64_t)__double_as_longlong(s.time);
   sh64[WR_ACTION * R + q] = (uint64_t)__double_as_longlong(s.action);
   sh32[WR_AIDX * R + q] = (uint32_t)s.action_index;
-  sh32[WR_FLAGS * R + q] = (s.running ? WF_RUNNING : 0u) | (s.first ? WF_FIRST : 0u) | (s.test ? WF_TEST : 0u) | (s.ending ? WF_ENDING : 0u);
+  sh32[WR_FLAGS * R + q] = (s.running ? WF_RUNNING : 0u) | (s.first ? WF_FIRST : 0u) | (s.test ? WF_TEST : 0u) | (s.ending ? WF_ENDING : 0u) |
+                           (s.served ? WF_SERVED : 0u);
   sh32[WR_ROWS * R + q] = s.rows;
   sh32[WR_LEFT * R + q] = (uint32_t)s.trials_left;
   sh32[WR_SUB * R + q] = (uint32_t)s.sub_left;
@@ -210,6 +212,7 @@ __device__ __forceinline__ void wide_rep_load(WideRep &s, const uint64_t *sh64, 
   s.first = (f & WF_FIRST) != 0u;
   s.test = (f & WF_TEST) ? 1 : 0;
   s.ending = (f & WF_ENDING) != 0u;
+  s.served = (f & WF_SERVED) != 0u;
   s.rows = sh32[WR_ROWS * R + q];
   s.trials_left = (int)sh32[WR_LEFT * R + q];
   s.sub_left = (int)sh32[WR_SUB * R + q];
@@ -217,10 +220,12 @@ __device__ __forceinline__ void wide_rep_load(WideRep &s, const uint64_t *sh64, 
 
 // B sub-batches of four replicas per wave.  Production ordering only (deferred TD update, no taps, no stamps): the
 // diagnostic instantiations stay with rollout_kernel.
-template <int ENV, int NA, int B, typename SPEC>
-__global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_trials)
+// SERVED: the environment steps come from the environment server of the wide kernels (grlx_env_server_wide.h) -- rollout_wide_served_kernel below.
+template <int ENV, int NA, int B, typename SPEC, bool SERVED>
+__device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_trials)
 {
   static_assert(B >= 2 && B <= 4, "sub-batches per wave");
+  static_assert(!SERVED || (B == 2 && NA == 3), "what the environment server of the wide kernels works for");
   constexpr int R = 4 * B;
   constexpr int NROWS = NA + 1;
   const DevParams &N = SPEC::numeric(P);
@@ -234,8 +239,12 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   __shared__ uint32_t sh_mail[4];
   __shared__ uint64_t sh_jump6[kJump6Words];        // LCG jump table, 6-bit windows (lazy weight initialisation)
   __shared__ double   sh_res[4 * 16];
-  __shared__ uint4    sh_ctx[B * kWideQuads * 64];      // parked lane state
-  __shared__ uint32_t sh_ins[B * 64];
+  // the sub-batches beyond the second park their lane state in device memory (P.park: kAcParkBytes per wave and sub-batch, rewritten and
+  // re-read by the same wave once per pass), not in LDS: four parked sub-batches would be 50 KB per wave, two waves per CU instead of four
+  constexpr bool GLP = B >= 3;
+  constexpr int BP = GLP ? 2 : B;                       // sub-batches parked in LDS
+  __shared__ uint4    sh_ctx[BP * kWideQuads * 64];     // parked lane state
+  __shared__ uint32_t sh_ins[BP * 64];
   __shared__ uint64_t sh_r64[WR_FIELDS64 * R];          // parked per-replica scalars
   __shared__ uint32_t sh_r32[WR_FIELDS32 * R];
   // exchange between the two lane roles, [field][replica in wave]
@@ -246,6 +255,8 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   __shared__ int      sh_term[R];
   __shared__ uint32_t sh_step[R];                       // 1: the replica takes an environment step in the next pass
   __shared__ uint32_t sh_est[R];                        // status bits raised by the environment role
+  __shared__ uint32_t sh_aidx[R];                       // index of that action (the candidate the environment server holds for it)
+  __shared__ uint32_t sh_srv[R];                        // 1: the replica is served by the environment server; 0: it integrates here
 
   jump_table6_to_lds(sh_jump6);
   const int lane = threadIdx.x & 63;
@@ -265,7 +276,14 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   lshare.src[0] = eq; lshare.src[1] = eq + R; lshare.src[2] = eq + 2 * R;
   lshare.role3 = (lane / R) % 3; lshare.role2 = (lane / R) & 1;
   static_assert(64 / R >= 3, "three lanes per replica share an equation of motion");
-  if (lane < R) { sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0; }
+  if (lane < R)
+  {
+    sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0;
+    sh_aidx[lane] = 0u;
+    sh_srv[lane] = (SERVED && P.env_mail != nullptr && wave0 + lane < P.n_replicas) ? 1u : 0u;
+  }
+  unsigned long long pass = 0;                          // passes of this wave so far = the sequence number of the commands it sends
+  if constexpr (SERVED) mail_setprio(P.env_tune & 3u);
 
   // ---- table role: lane (g, j) of sub-batch b serves tiling j of replica wave0 + 4b + g
   UpdateParams up;
@@ -286,6 +304,10 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     key_act[a] = in_reg(murmur_key(tile_coord<T>(N.tile, D, tile_quant(N.tile, D, N.actions[a]), j)));
   const uint32_t key_j = in_reg(murmur_key(j));
 
+  constexpr int kParkQuads = (int)(kAcParkBytes / sizeof(uint4));
+  uint4 *gl_base = GLP ? (uint4 *)P.park + (size_t)blockIdx.x * (size_t)(kParkQuads * (B - 2)) : nullptr;
+  auto park_ctx = [&](int b) { return (GLP && b >= 2) ? gl_base + (b - 2) * kParkQuads : sh_ctx + b * kWideQuads * 64; };
+  auto park_ins = [&](int b) { return (GLP && b >= 2) ? (uint32_t *)(gl_base + (b - 2) * kParkQuads + kWideQuads * 64) : sh_ins + b * 64; };
   for (int b = 0; b < B; ++b)
   { // initial parked state of every sub-batch
     const int q = 4 * b + g;
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     c.inserted = 0;
     c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
     c.wp_seen = 0; c.wap_seen = 0;
-    wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+    wide_park(c, park_ctx(b), park_ins(b), lane);
     WideRep s;
     s.G = RS.G; s.TL = RS.TL; s.S1 = RS.S1;
     s.eps_decay = RS.eps_decay;
@@ -313,6 +335,13 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     s.rows = RS.rows;
     s.trials_left = (live && !(P.steps_budget != 0u && (uint64_t)RS.ss >= P.steps_budget)) ? n_trials : 0;
     s.sub_left = 0;
+    s.served = SERVED && P.env_mail != nullptr && live;
+    if constexpr (SERVED)
+      if (s.served && s.trials_left <= 0)
+      { // nothing to do in this launch (its steps budget was reached before): the server does not wait for this replica
+        if (j == 0) wide_mail_send<ENV>(P, wave0 + q, 1u, kMailExit);
+        s.served = false;
+      }
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
@@ -320,6 +349,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
   {
     for (;;)
     {
+      ++pass;
 #ifdef GRLX_WIDE_STAMPS
       const unsigned long long st0 = stamp();
 #endif
@@ -342,11 +372,37 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
           int terminal = 0;
 #pragma unroll
           for (int i = 0; i < D; ++i) obs[i] = 0;
-          if (step)
+          bool got = false;
+          if constexpr (SERVED)
+          { // the step was integrated by the environment server while this wave was in its table phases: the candidate of the action taken
+            // (command `pass - 1` named it; the candidates it selects from are the ones of command `pass - 2`)
+            const bool want = step && sh_srv[eq] != 0u;
+            if (__any(want))
+            {
+              double xn[S], rw = 0;
+              got = wide_mail_take<ENV, R>(P, elive ? wave0 + eq : 0, want, pass - 2u, (int)sh_aidx[eq], lane, xn, rw);
+              if (want && !got) sh_srv[eq] = 0u;      // no answer: this replica integrates here from now on (its table lanes send kMailExit)
+              if (got)
+              {
+                terminal = Env<ENV>::observe(N, xn, obs);                     // env_step: observe, domain check
+                reward = rw;
+                if (!Env<ENV>::in_domain(xn)) estatus |= ST_DOMAIN;
+#pragma unroll
+                for (int i = 0; i < S; ++i) x[i] = xn[i];
+              }
+            }
+          }
+          const bool local = step && !got;
+          if (__any(local))
           {
-            const double action = sh_act[eq];
-            env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, estatus, lshare);     // online_learning.cpp:196
-            // the 64/R lanes of a replica hold identical values: all of them store (same address, same bits)
+            if (local)
+            {
+              const double action = sh_act[eq];
+              env_step<ENV, true, LaneShare>(N, x, action, obs, reward, terminal, estatus, lshare);     // online_learning.cpp:196
+            }
+          }
+          if (step)
+          { // the 64/R lanes of a replica hold identical values: all of them store (same address, same bits)
 #pragma unroll
             for (int i = 0; i < D; ++i) sh_obs[i * R + eq] = obs[i];
             sh_reward[eq] = reward;
@@ -362,6 +418,9 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
 #endif
       // ================= table phase, one sub-batch after the other
       bool more = false;
+      // GLP: the parked lane state of the sub-batch after the running one is requested from device memory a whole turn before it is unpacked
+      uint4 raw_next[kWideQuads];
+      uint32_t rawi_next[3];
       for (int b = 0; b < B; ++b)
       {
         const int q = 4 * b + g;
@@ -370,7 +429,9 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
         const ReplicaState &RS = P.states[r];
         const Table tab = table_of(P, 0, r);
         WideLane c;
-        wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+        if (GLP && b >= 2) wide_unpark_decode(c, raw_next, rawi_next);       // requested during the previous sub-batch's turn
+        else wide_unpark(c, park_ctx(b), park_ins(b), lane);
+        if (GLP && b + 1 >= 2 && b + 1 < B) wide_unpark_load(raw_next, rawi_next, park_ctx(b + 1), park_ins(b + 1), lane);
         WideRep s;
         wide_rep_load<R>(s, sh_r64, sh_r32, q);
         if (!__any(s.running || c.pd || s.trials_left > 0)) continue;        // this sub-batch has finished its trials
@@ -639,6 +700,13 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
             for (int i = 0; i < S; ++i) sh_x[i * R + q] = xs[i];
 #pragma unroll
             for (int i = 0; i < D; ++i) sh_obs[i * R + q] = ob0[i];
+            if constexpr (SERVED)
+              if (s.served && live)
+              { // the environment server starts on the first step of this trial, for every action, while this wave looks up Q(s0, .)
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+                  if (j == i) wide_mail_reset_unit<ENV>(P, r, pass, i, xs[i]);
+              }
             if (!again)
             { // (reward and time keep adding up across the episodes of one test trial, :202-203)
               s.total_reward = 0;
@@ -656,11 +724,21 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
         if (j == 0 && live)
         {
           sh_act[q] = s.action;
+          sh_aidx[q] = (uint32_t)s.action_index;
           sh_step[q] = step_next;
         }
+        if constexpr (SERVED)
+          if (s.served)
+          { // this pass's command to the environment server: exactly one per replica and pass
+            const bool fin = !s.running && !c.pd && s.trials_left <= 0;
+            const bool lost = sh_srv[q] == 0u;
+            const unsigned op = (fin || lost) ? kMailExit : step_next == 1u ? (unsigned)s.action_index : step_next == 2u ? kMailReset : kWideSkip;
+            if (j == 0 && live) wide_mail_send<ENV>(P, r, pass, op);
+            if (fin || lost) s.served = false;
+          }
         more = more || s.running || c.pd || s.trials_left > 0;
         wide_rep_store<R>(s, sh_r64, sh_r32, q);
-        wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+        wide_park(c, park_ctx(b), park_ins(b), lane);
       }
       wave_sync();
 #ifdef GRLX_WIDE_STAMPS
@@ -685,7 +763,7 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     const int q = 4 * b + g;
     const bool live = wave0 + q < P.n_replicas;
     WideLane c;
-    wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+    wide_unpark(c, park_ctx(b), park_ins(b), lane);
     WideRep s;
     wide_rep_load<R>(s, sh_r64, sh_r32, q);
     uint32_t ins = c.inserted;
@@ -694,6 +772,8 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
     uint32_t st = c.status | sh_est[q];
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) st |= __shfl_xor(st, off, 16);
+    if (SERVED && live && j == 0 && P.env_mail)      // (grlx_env_server_counts: served to the end / fell back)
+      wide_mail_of<ENV>(P, wave0 + q)->stats[15] = sh_srv[q] ? 1u : 2u;
     if (live && j == 0)
     {
       ReplicaState &RS = P.states[wave0 + q];
@@ -709,6 +789,20 @@ __global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_tri
       RS.status = st;
     }
   }
+}
+
+template <int ENV, int NA, int B, typename SPEC>
+__global__ __launch_bounds__(64) void rollout_wide_kernel(DevParams P, int n_trials)
+{
+  rollout_wide_body<ENV, NA, B, SPEC, false>(P, n_trials);
+}
+
+// The instantiation the environment server of the wide kernels works for (grlx_env_server_wide.h): the same body, its environment
+// phase fetching what the server integrated.  Its registers leave room for the server's wave on the same SIMD.
+template <int ENV, typename SPEC>
+__global__ __launch_bounds__(64) void rollout_wide_served_kernel(DevParams P, int n_trials)
+{
+  rollout_wide_body<ENV, 3, 2, SPEC, true>(P, n_trials);
 }
 
 } // namespace grlx

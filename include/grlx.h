@@ -166,7 +166,7 @@ typedef struct {
   double   target_tau;
   /* experiment/online_learning:test_trials (online_learning.cpp:160-225): a test trial is `test_trials` greedy episodes, each begun with
    * environment start and agent start; reward and time keep adding up across them and the row holds their means.  0 and 1 = one episode.
-   * Built for SARSA / Q / Expected SARSA with the replacing trace and for the actor-critic agent. */
+   * Every kernel family has it (round 4: QV, advantage, the accumulating trace, target networks / safe too); not with taps. */
   int32_t  test_trials;
   int32_t  reserved0;
 } grlx_config;
@@ -271,8 +271,8 @@ int  grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2);
 /* The trial loop of OnlineLearningExperiment::run with BOTH of its bounds (online_learning.cpp:154: `(!trials_ || tt < trials_) &&
  * (!steps_ || ss < steps_)`): every replica runs at most max_trials further trials and starts none once its learning steps of the run
  * (since grlx_create / grlx_reset_run) have reached `steps` (> 0).  Replicas stop at trials of their own, so their rows are ragged:
- * grlx_replica_rows gives a replica's count, grlx_curve_stats counts per row.  One launch per call.  Built for SARSA / Q / Expected SARSA
- * with the replacing trace and for the actor-critic agent; GRLX_ERR_INVALID otherwise. */
+ * grlx_replica_rows gives a replica's count, grlx_curve_stats counts per row.  One launch per call.  Every kernel family has it
+ * (round 4); GRLX_ERR_INVALID with taps or diagnostics. */
 int  grlx_run_steps(grlx_ctx *ctx, int max_trials, uint64_t steps, void *stream);
 int  grlx_replica_rows(grlx_ctx *ctx, int replica);          /* rows replica `replica` has written (grlx_rows: replica 0) */
 /* Experiment::reset() between two runs of `runs: N` (online_learning.cpp:307-308; Configurable::reset, configurable.h:770-776):

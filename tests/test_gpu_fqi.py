@@ -68,6 +68,13 @@ def test_fqi_several_rounds_of_chunks_on_several_replicas_bit_exact(grlx):
     _both(grlx, [11, 12, 13, 14, 15], 2, batch_size=6500, iterations=2, epochs=25)
 
 
+def test_fqi_at_the_bench_s_size_bit_exact(grlx):
+    """The shape bench.py times -- 16 replicas (256 resident blocks: every CU), 100 000 transitions per batch = 1563 chunks of 64 with a
+    ragged last one, 24 or 25 chunks per wave -- with few epochs so that the scalar oracle finishes in seconds: transitions, targets, all
+    101 parameters, error, rows and streams of every replica against the oracle."""
+    _both(grlx, list(range(101, 117)), 1, batch_size=100000, iterations=2, epochs=3)
+
+
 def test_fqi_more_replicas_than_one_launch_holds(grlx):
     """18 replicas need 288 resident blocks: more than the 256 CUs hold, so the epochs run as two cooperative launches
     (16 + 2 replicas) per iteration; results per replica do not depend on the grouping."""

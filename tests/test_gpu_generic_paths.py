@@ -200,6 +200,66 @@ def test_wide_waves_bit_exact(grlx, name, n, trials, agent, generic):
                     [trials // 3, trials - trials // 3])
 
 
+@pytest.mark.parametrize("name,n,agent,generic", [("acrobot", 37, 1, 0), ("compass_walker", 21, 1, 0), ("acrobot", 19, 0, 0),
+                                                  ("acrobot", 18, 1, 1), ("compass_walker", 17, 1, 1)])
+def test_sixteen_replicas_per_wave_bit_exact(grlx, name, n, agent, generic):
+    """Round 4: four sub-batches per wave (rollout_wide_kernel<., 3, 4, .>: one environment phase per 16 replicas, the lane state of the third
+    and fourth sub-batch parked in device memory between their turns).  Ragged batches (37 = 2 full waves + 5: a wave with one and a quarter
+    sub-batches), trials in two launches, then two successive steps budgets with test trials of two episodes; every replica against the
+    oracle: rows (returns and times), streams, environment state, sampled weights, step counts, table loads == the 8-per-wave layout's."""
+    from tests import configs
+    make = {"acrobot": configs.acrobot, "compass_walker": configs.compass_walker}[name]
+    trials = 14 if name == "acrobot" else 9
+    got = {}
+    seeds = np.arange(201, 201 + n)
+    for rpw in (16, 8):
+        cfg, spec = make(grlx, n, agent=agent, force_generic=generic, replicas_per_wave=rpw, max_rows=400, test_trials=2)
+        spec.test_trials = 2
+        spec.math = ob.MATH_PORTABLE
+        r = grlx.Runner(cfg, seeds)
+        assert r.replicas_per_wave() == rpw
+        r.run(trials // 2); r.run(trials - trials // 2)
+        for b in (500, 1100):
+            r.run_steps(100000, b)
+        r.sync()
+        assert r.last_kernel() == (1 if (generic or agent != 1) else 2)
+        rng = np.random.default_rng(5)
+        slots = rng.integers(0, cfg.projector.memory, 1000).astype(np.uint32)
+        got[rpw] = dict(rows=[r.rows(k) for k in range(n)], times=[r.row_times(k, 0, len(r.rows(k)[0])) for k in range(n)], rng=[list(r.rng(k))[:4] for k in range(n)],
+                        state=[r.env_state(k) for k in range(n)], w=[r.weights(k, slots) for k in range(n)], counts=r.step_counts(),
+                        load=[r.table_load(k) for k in range(n)])
+        r.close()
+    assert got[16]["counts"] == got[8]["counts"] and got[16]["load"] == got[8]["load"]
+    learn = test = 0
+    for k in range(n):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows = e.run(trials)[0]
+        for b in (500, 1100):
+            e.set_steps_budget(b)
+            rows += e.run(100000)[0]
+        t, s_, rew = got[16]["rows"][k]
+        assert list(t) == [x.trial for x in rows] and list(s_) == [x.steps for x in rows], f"replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
+        assert_bit_equal(got[16]["times"][k][:len(rows)], [x.time for x in rows], f"episode times of replica {k}")
+        assert got[16]["rng"][k] == list(e.rng())[:4], f"RNG positions of replica {k}"
+        assert_bit_equal(got[16]["state"][k], e.state(), f"env state of replica {k}")
+        assert_bit_equal(got[16]["w"][k], e.weights(slots), f"weights of replica {k}")
+        st = e.stats()
+        learn += int(st.learn_steps); test += int(st.test_steps)
+        e.close()
+    assert got[16]["counts"] == (learn, test)
+
+
+def test_sixteen_replicas_per_wave_is_chosen_and_refused(grlx):
+    """Automatic layout: 16 for the TD agents on the acrobot / the walker from 15 replicas per SIMD on; an explicit 16 elsewhere is refused."""
+    capi = grlx.capi
+    r = grlx.Runner(grlx.acrobot_q_config(16384, table_log2_capacity=10), np.arange(16384)); assert r.replicas_per_wave() == 16; r.close()
+    r = grlx.Runner(grlx.acrobot_q_config(8192, table_log2_capacity=10), np.arange(8192)); assert r.replicas_per_wave() == 8; r.close()
+    with pytest.raises(capi.GrlxError) as ei:
+        grlx.Runner(grlx.pendulum_sarsa_config(64, replicas_per_wave=16), np.arange(64))
+    assert ei.value.code == capi.ERR_INVALID
+
+
 def test_wide_waves_generic_parameters_and_tiny_memory(grlx):
     """The generic wide instantiation with the knobs of the generic-parameter tests, and a 2048-slot hash memory where
     nearly every slot is shared between tilings (write-through entries, cross-lane aliases, reloads after the update)."""
@@ -781,6 +841,82 @@ def test_test_trials_runs_several_greedy_episodes_per_test_trial(grlx, graph, n,
         learn += int(st.learn_steps); test += int(st.test_steps)
         e.close()
     assert r.step_counts() == (learn, test)
+    r.close()
+
+
+@pytest.mark.parametrize("family", ["qv", "advantage", "accumulating", "accumulating_acrobot", "target_network", "target_network_acrobot",
+                                    "safe", "target_network_walker", "target_network_cart_pole"])
+def test_steps_budget_and_test_trials_in_the_other_kernel_families(grlx, family):
+    """Round 4: the second bound of the trial loop (`steps`, online_learning.cpp:154) and test trials of several greedy episodes
+    (:160-225) in the kernels that did not have them -- predictor/critic/qv, advantage learning, the accumulating trace, and the plain
+    kernel of target networks / `safe` projections (all four environments).  23 trials, then two successive budgets; rows (trial, steps,
+    mean return AND mean time, ragged across replicas of one wave for the absorbing tasks), streams, states, step counts and table values
+    against the oracle."""
+    from tests import configs
+    n, tables = 7, 1
+    over, agent, make = {}, None, configs.pendulum
+    if family == "qv":
+        make, tables = configs.pendulum_qv, 2
+    elif family == "advantage":
+        agent, over = grlx.capi.AGENT_ADVANTAGE, dict(kappa=0.2)
+    elif family.startswith("accumulating"):
+        over = dict(trace=2)
+    elif family.startswith("target_network"):
+        over = dict(target_interval=200, target_tau=0.5)
+    elif family == "safe":
+        over = dict(safe=1)
+    if family.endswith("acrobot"):
+        make = configs.acrobot
+    elif family.endswith("walker"):
+        make = configs.compass_walker
+    elif family.endswith("cart_pole"):
+        make = lambda g, k, **o: configs.cart_pole_q(g, k, end_stop_penalty=1, **o)
+    kw = dict(max_rows=300, test_trials=3)
+    if agent is not None:
+        kw.update(agent=agent, kappa=over["kappa"])
+    cfg, spec = make(grlx, n, **kw)
+    for k, v in over.items():
+        if k == "safe":
+            cfg.projector.safe = v; spec.safe = v
+        elif k != "kappa":
+            setattr(cfg, k, v); setattr(spec, k, v)
+    if agent is not None:
+        spec.kappa = over["kappa"]
+    spec.test_trials = 3
+    spec.math = ob.MATH_PORTABLE
+    seeds = np.arange(71, 71 + n)
+    r = grlx.Runner(cfg, seeds)
+    budgets = (1200, 2600)
+    r.run(12)
+    for b in budgets:
+        r.run_steps(100000, b)
+    r.sync()
+    rng = np.random.default_rng(17)
+    slots = rng.integers(0, 8388608, 600).astype(np.uint32)
+    learn = test = 0
+    rows_seen = set()
+    for k in range(n):
+        e = ob.Experiment(spec, seed=int(seeds[k]))
+        rows = e.run(12)[0]
+        for b in budgets:
+            e.set_steps_budget(b)
+            rows += e.run(100000)[0]
+        t, s_, rew = r.rows(k)
+        assert list(t) == [x.trial for x in rows] and list(s_) == [x.steps for x in rows], f"{family}: replica {k}"
+        assert_bit_equal(rew, [x.reward for x in rows], f"{family}: mean returns of replica {k}")
+        assert_bit_equal(r.row_times(k, 0, len(rows)), [x.time for x in rows], f"{family}: mean episode times of replica {k}")
+        assert list(r.rng(k))[:4] == list(e.rng())[:4], f"{family}: replica {k}"
+        assert_bit_equal(r.env_state(k), e.state(), f"{family}: env state of replica {k}")
+        for tb in range(tables):
+            assert_bit_equal(r.weights(k, slots, tb), e.weights(slots, tb), f"{family}: table {tb} of replica {k}")
+        st = e.stats()
+        assert st.learn_steps >= budgets[-1]
+        learn += int(st.learn_steps); test += int(st.test_steps)
+        rows_seen.add(len(rows))
+        e.close()
+    assert r.step_counts() == (learn, test)
+    if family.endswith(("acrobot", "walker")):
+        assert len(rows_seen) > 1                     # the replicas did stop at different trials
     r.close()
 
 
