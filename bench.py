@@ -72,7 +72,7 @@ GRAPHS = {
                              "(co-resident pair, one timed launch; rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ> with GRLX_ENV_SERVER=0)",
                       text="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml)"),
     "compass_walker_q": dict(trials=0, budget=12200, want_kernel=2, pmc_key="compass_walker_q",
-                             kernel="rollout_wide_kernel<compass_walker, 3 actions, 8 replicas per wave, SpecWalkerQ, deferred update>",
+                             kernel="rollout_wide_kernel<compass_walker, 3 actions, 16 replicas per wave (four sub-batches, two parked in device memory), SpecWalkerQ, deferred update>",
                              text="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml)"),
 }
 
@@ -81,11 +81,13 @@ WORKLOADS = {
     "pendulum_sarsa": dict(replicas=REPLICAS_PER_GPU, steps=20, warmup=3, dominant="pendulum_sarsa", baseline_config=1),
     "cart_pole_ac": dict(replicas=16384, steps=5, warmup=1, dominant="cart_pole_ac", baseline_config=2),
     "acrobot_q": dict(replicas=8192, steps=5, warmup=1, dominant="acrobot_q", baseline_config=3),
-    "compass_walker_q": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
-    # both halves on every rank, each as 512 waves of 8 replicas: together one wave per SIMD, both kernels resident for the whole launch.
+    # 16 replicas per SIMD: four sub-batches per wave share one environment phase (A/B on one box, tools/wide16_ab.sh: 239 M with 8 per wave,
+    # 279 M with 16, 302 M with the parked state of the next sub-batch requested a turn ahead, at 16384 replicas; 233 M at 8192 replicas with 8 per wave)
+    "compass_walker_q": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
+    # both halves on every rank, each as 512 waves of 16 replicas (8 until round 4): together one wave per SIMD, both kernels resident for the whole launch.
     # The acrobot's budget per launch is set so that its kernel lasts about as long as the walkers' (an acrobot step costs a twentieth of a
     # launch's walker work): otherwise its half of the chip idles for 95 % of every launch.
-    "acrobot_walker": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=8,
+    "acrobot_walker": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=16,
                            budget={"acrobot_q": 22000}),
 }
 SECONDARY_ORDER = ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker"]

@@ -24,7 +24,9 @@ WORKLOADS = [("rollout_kernel<0, 3, false, grlx::SpecPendulumTcA<0>", "pendulum_
              ("env_server_kernel<0, 3, grlx::SpecPendulumTcA<0>", "pendulum_sarsa_env_server", 4096, 11, 20),
              ("rollout_ac_wide_kernel<1, 4, grlx::SpecCartPoleAc>", "cart_pole_ac", 16384, 11, 5),
              ("rollout_wide_kernel<2, 3, 2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 1100, 5),          # (steps budget per launch)
-             ("rollout_wide_kernel<3, 3, 2, grlx::SpecWalkerQ>", "compass_walker_q", 8192, 12200, 5)]
+             ("rollout_wide_served_kernel<2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 1100, 5),         # (the stats pass: beside its server)
+             ("env_server_acrobot_pinned_kernel<grlx::SpecAcrobotQ>", "acrobot_q_env_server", 8192, 1100, 5),
+             ("rollout_wide_kernel<3, 3, 4, grlx::SpecWalkerQ>", "compass_walker_q", 16384, 12200, 5)]
 
 
 def workload_of(name):
@@ -133,6 +135,13 @@ def main():
             e["wait_any"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
         if key in stats and "timed_ms" in stats[key]:
             e["kernel_ms_trace"] = stats[key]["timed_ms"]
+        if "SQ_THREAD_CYCLES_VALU" in m and m.get("SQ_ACTIVE_INST_VALU"):
+            # lanes enabled per issued vector instruction (exec mask), of 64: rocprof's VALUUtilization.  (Copies of one replica in several
+            # lanes count as enabled: the number of DISTINCT integrations per stream is in DESIGN.md 4.1h.)
+            e["valu_lanes_enabled"] = m["SQ_THREAD_CYCLES_VALU"] / (m["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if key == "acrobot_q":
+            e["note"] = ("counters collected with GRLX_ENV_SERVER=0 (rollout_wide_kernel integrating itself: the same table accesses); "
+                         "kernel_ms_trace is rollout_wide_served_kernel beside env_server_acrobot_pinned_kernel")
         if key == "pendulum_sarsa":
             e["note"] = ("counters collected with GRLX_ENV_SERVER=0 (rollout_kernel integrating itself: the same table accesses); "
                          "kernel_ms_trace is rollout_served_kernel beside env_server_kernel" +

@@ -22,7 +22,7 @@ echo "fqi stats pass done"
 # (counter passes of the rollout workloads: GRLX_ENV_SERVER=0 -- rocprofv3 serialises kernels while it reads counters, and the headline's
 #  pair of kernels only exists together; the table accesses of rollout_kernel are the ones of rollout_served_kernel)
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64" "SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES"; do
   i=$((i+1))
   GRLX_ENV_SERVER=0 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- $BENCH > $OUT/bench_under_pmc$i.json 2> $OUT/pmc$i.err
   echo "pass $i done: $set"
