@@ -166,9 +166,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-HOST_SOURCES = ["configurable.cpp", "objects.cpp", "grlxd.cpp"]
-OPS_SOURCES = ["configurable.cpp", "objects.cpp", "grlx_ops.cpp"]      # grlx_ops: Projector::project / Environment::step from the command line
-HOST_HEADERS = ["configurable.h", "objects.h"]
+HOST_SOURCES = ["configurable.cpp", "objects.cpp", "multi_gpu.cpp", "grlxd.cpp"]       # multi_gpu.cpp: `grlxd -g N` (HIP runtime API + RCCL)
+OPS_SOURCES = ["configurable.cpp", "objects.cpp", "multi_gpu.cpp", "grlx_ops.cpp"]    # grlx_ops: Projector::project / Environment::step from the command line
+HOST_HEADERS = ["configurable.h", "objects.h", "multi_gpu.h"]
 BINDIR = os.path.join(HERE, "bin")
 GRLXD = os.path.join(BINDIR, "grlxd")
 GRLX_OPS = os.path.join(BINDIR, "grlx_ops")
@@ -183,8 +183,10 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         return GRLXD
     os.makedirs(BINDIR, exist_ok=True)
     for out, sources in ((GRLXD, HOST_SOURCES), (GRLX_OPS, OPS_SOURCES)):
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", out] + [os.path.join(hostdir, f) for f in sources] + \
-              ["-L" + LIBDIR, "-lgrlx", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", out] + \
+              [os.path.join(hostdir, f) for f in sources] + \
+              ["-L" + LIBDIR, "-lgrlx", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib",
+               "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -17,6 +17,7 @@
 #include "../../../include/grlx.h"
 #include "configurable.h"
 #include "objects.h"
+#include "multi_gpu.h"
 
 namespace grlx_host {
 
@@ -1364,7 +1365,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment, StepwiseExperime
     // the trial loop of online_learning.cpp:154 ends a run at the first trial boundary with `ss >= steps`, and save_every: test | trial
     // writes the policy between trials: both need the host between trials, so such runs launch one trial at a time
     const bool by_trial = steps > 0 || save_every == "test" || save_every == "trial";
-    if (steps > 0 && opt.replicas > 1)
+    if (steps > 0 && opt.replicas * opt.world > 1)
       throw Exception(path() + ": a steps budget ends every clone at a trial of its own; on the accelerated path it is built for one replica");
     // rows a run can write: with a steps budget alone, a trial has at least one learning step
     const int trial_cap = trials > 0 ? trials : steps * (test_interval >= 0 ? 2 : 1) + 1;
@@ -1394,8 +1395,10 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment, StepwiseExperime
     }
     // ONE instantiation for all runs, as in the reference: between two runs the experiment is reset (online_learning.cpp:307-308),
     // not re-created -- the random streams continue, so run 1 differs from a fresh process with another seed
+    const int first_clone = opt.rank * opt.replicas;              // `grlxd -g N`: this rank's clones among those of the whole job
+    const bool many = opt.replicas * opt.world > 1;
     std::vector<int64_t> seeds((size_t)opt.replicas);
-    for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + i;
+    for (int i = 0; i < opt.replicas; ++i) seeds[(size_t)i] = opt.seed + first_clone + i;
     grlx_ctx *ctx = nullptr;
     if (grlx_create(&c, seeds.data(), &ctx) != GRLX_OK) throw Exception(grlx_last_error());
     for (int rr = run_offset; rr < runs + run_offset; ++rr)
@@ -1528,7 +1531,7 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment, StepwiseExperime
         grlx_read_row_times(ctx, i, 0, n, episode_time.data());
         std::ostringstream name;                       // <output>-<run><identity>.txt, identity "@i" for clones (multi.cpp:52-56)
         name << output << "-" << rr;
-        if (opt.replicas > 1) name << "@" << i;
+        if (many) name << "@" << first_clone + i;
         name << ".txt";
         std::ofstream ofs;
         if (!output.empty()) ofs.open(name.str());
@@ -1542,9 +1545,34 @@ struct OnlineLearningExperimentImpl : OnlineLearningExperiment, StepwiseExperime
                 << reward[(size_t)k] << std::setw(15) << std::setprecision(3) << episode_time[(size_t)k] << std::setw(15) << std::setprecision(3)
                 << reward[(size_t)k] / episode_time[(size_t)k] << std::setw(15) << std::setprecision(3) << wall;
           if (ofs.is_open()) ofs << oss.str() << std::endl;
-          if (i == 0 && opt.print_rows) std::cout << oss.str() << std::endl;
+          if (i == 0 && opt.rank == 0 && opt.print_rows) std::cout << oss.str() << std::endl;
         }
         if (i == 0) curve = reward;
+      }
+      if (opt.reducer && n > 0)
+      { // the learning curve over the clones of ALL ranks: per row {sum, sum of squares, count} of this device's replicas (grlx_curve_stats,
+        // fixed reduction order), ONE all-reduce over the ranks, mean and standard deviation on rank 0.  (Trial-bounded runs write the same
+        // rows on every rank; a steps budget with more than one clone is refused above.)
+        double *dev = opt.reducer->device_buffer((size_t)n * 3);
+        if (grlx_curve_stats(ctx, 0, n, dev, nullptr) != GRLX_OK || grlx_sync(ctx, nullptr) != GRLX_OK)
+        { std::string e = grlx_last_error(); grlx_destroy(ctx); throw Exception(e); }
+        opt.reducer->all_reduce_sum(dev, (size_t)n * 3);
+        std::vector<double> st((size_t)n * 3);
+        opt.reducer->to_host(st.data(), dev, st.size());
+        if (opt.rank == 0 && !output.empty())
+        {
+          std::ostringstream name;
+          name << output << "-" << rr << "-mean.txt";
+          std::ofstream ofs(name.str());
+          grlx_read_rows(ctx, 0, 0, n, trial.data(), stp.data(), reward.data());
+          for (int k = 0; k < n; ++k)
+          { // trial, clones that wrote the row, mean return, standard deviation over the clones (population)
+            const double sum = st[(size_t)k * 3], sq = st[(size_t)k * 3 + 1], cntk = st[(size_t)k * 3 + 2];
+            const double mean = cntk > 0 ? sum / cntk : 0., var = cntk > 0 ? std::max(0., sq / cntk - mean * mean) : 0.;
+            ofs << std::setw(15) << trial[(size_t)k] << std::setw(15) << (long long)cntk << std::setw(20) << std::setprecision(12) << mean
+                << std::setw(20) << std::setprecision(12) << std::sqrt(var) << std::endl;
+          }
+        }
       }
       // Save policy every run (online_learning.cpp:294-302 -> ParameterizedRepresentation {action: save},
       // representation.h:201-229): raw double[memory] to <output>-run<rr>-<config path with '/'->'_'>.dat

@@ -6,9 +6,15 @@
 
 namespace grlx_host {
 
+struct CurveReducer;            // multi_gpu.h
 struct RunOptions {
   int64_t seed = 1;             // deployer -s (replica i uses seed + i)
   int replicas = 1;             // clones of the experiment (experiment/multi analogue)
+  // `grlxd -g N`: this process is rank `rank` of `world`, one per GPU.  Its replicas are the clones rank * replicas .. + replicas - 1 of the
+  // whole job (seeds and "@i" identities count over all ranks); after every run the ranks reduce their learning curves with ONE all-reduce
+  // (reducer->all_reduce_sum over grlx_curve_stats' device buffer) and rank 0 writes <output>-<run>-mean.txt.
+  int rank = 0, world = 1;
+  CurveReducer *reducer = nullptr;
   int table_log2_capacity = 0;
   bool legacy_rows = false;     // 3-column rows as in the reference's committed golden files
   bool print_rows = true;

@@ -942,6 +942,33 @@ def test_deployer_test_trials(grlx, tmp_path):
     e.close()
 
 
+def test_deployer_one_process_per_gpu_reduces_the_curve_with_rccl(grlx, tmp_path):
+    """`grlxd -g 1 -r 5`: the multi-GPU path of the C++ host on the one GPU this box has -- a world-1 RCCL communicator (ncclGetUniqueId,
+    ncclCommInitRank), grlx_curve_stats into device memory, ONE ncclAllReduce per run, mean and standard deviation written by rank 0.  The
+    per-clone files are the oracle's rows (`-l` layout), and <output>-0-mean.txt is their mean / population standard deviation.  More ranks
+    need more GPUs (RCCL refuses two ranks on one device): unmeasured on hardware, as DESIGN.md section 6 says."""
+    import subprocess
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    y = tmp_path / "mg.yaml"
+    y.write_text(_golden_yaml().replace("trials: 2000", "trials: 22"))
+    res = subprocess.run([grlxd, "-g", "1", "-r", "5", "-s", "40", "-l", "-q", "-v", "-v", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr + res.stdout
+    assert "communicator ready" in res.stdout + res.stderr
+    returns = []
+    for i in range(5):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(), seed=40 + i)
+        rows, _ = e.run(22)
+        assert (tmp_path / f"pendulum-sarsa-tc-0@{i}.txt").read_text() == e.format_rows(rows)
+        returns.append([x.reward for x in rows])
+        e.close()
+    returns = np.asarray(returns)
+    mean = [ln.split() for ln in (tmp_path / "pendulum-sarsa-tc-0-mean.txt").read_text().strip().split("\n")]
+    assert [int(f[0]) for f in mean] == [10, 20] and [int(f[1]) for f in mean] == [5, 5]
+    np.testing.assert_allclose([float(f[2]) for f in mean], returns.mean(axis=0), rtol=1e-11)
+    np.testing.assert_allclose([float(f[3]) for f in mean], returns.std(axis=0), rtol=1e-6)
+
+
 @pytest.mark.parametrize("agent", [0, 1, 3])
 def test_discrete_actions_on_the_cart_pole(grlx, agent):
     """The fused Q kernels on the fourth environment of the path with DISCRETE actions (SARSA / Q / Expected SARSA over 3 forces on the

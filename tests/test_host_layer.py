@@ -239,3 +239,21 @@ def test_expressions_over_references(grlxd, tmp_path):
     p.write_text(bad)
     res = run(grlxd, ["-s", "1", "-q", str(p)], tmp_path)
     assert res.returncode == 1 and "vector size mismatch" in res.stderr
+
+
+def test_deployer_multi_gpu_ranks_fail_cleanly_without_devices(tmp_path):
+    """`grlxd -g 2` where no GPU exists (this suite runs without one): both ranks are forked before HIP starts, each fails to find its device
+    and says so, the parent waits for both, removes the rendezvous file and returns 1 -- no hang, no fallback."""
+    import shutil
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    from grl_amd import _build
+    grlxd = _build.build_host()
+    y = tmp_path / "p.yaml"
+    shutil.copy(os.path.join(os.path.dirname(__file__), "golden", "pendulum-sarsa-tc.yaml"), y)
+    res = subprocess.run([grlxd, "-g", "2", "-s", "1", "-q", str(y)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 1
+    assert "2 of 2 ranks failed" in res.stderr + res.stdout and "multi-GPU" in res.stderr + res.stdout
+    assert not list(tmp_path.glob("*.txt"))
