@@ -21,7 +21,8 @@ statistics [rows][3], inside the timed region.
   --workload cart_pole_ac               BASELINE configs[2]: 16384 replicas per GPU
   --workload acrobot_walker             BASELINE configs[3]: 8192 rollouts per GPU = 4096 acrobot + 4096 compass walker,
                                         both halves on every rank, two contexts on two HIP streams
-  --workload acrobot_q | compass_walker_q   one half of configs[3] alone, 8192 replicas per GPU
+  --workload acrobot_walker_x2          the same composite with twice the rollouts per GPU (8192 + 8192, 16 replicas per wave)
+  --workload acrobot_q | compass_walker_q   one half of configs[3] alone, 8192 / 16384 replicas per GPU
   --workload pendulum_fqi_ann           BASELINE configs[4]: replicas only (16 independent-seed batch experiments per GPU)
 """
 import argparse
@@ -84,13 +85,18 @@ WORKLOADS = {
     # 16 replicas per SIMD: four sub-batches per wave share one environment phase (A/B on one box, tools/wide16_ab.sh: 239 M with 8 per wave,
     # 279 M with 16, 302 M with the parked state of the next sub-batch requested a turn ahead, at 16384 replicas; 233 M at 8192 replicas with 8 per wave)
     "compass_walker_q": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
-    # both halves on every rank, each as 512 waves of 16 replicas (8 until round 4): together one wave per SIMD, both kernels resident for the whole launch.
+    # both halves on every rank, each as 512 waves of 8 replicas: together one wave per SIMD, both kernels resident for the whole launch
+    # (the acrobot's waves beside their environment server's).
     # The acrobot's budget per launch is set so that its kernel lasts about as long as the walkers' (an acrobot step costs a twentieth of a
     # launch's walker work): otherwise its half of the chip idles for 95 % of every launch.
-    "acrobot_walker": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=16,
-                           budget={"acrobot_q": 22000}),
+    "acrobot_walker": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=8,
+                           budget={"acrobot_q": 27000}),
+    # the same composite with TWICE BASELINE's rollouts per GPU (131072 over 8 GPUs): 8192 + 8192, 512 waves of 16 replicas each -- four
+    # sub-batches per wave share one environment phase (round 4); sized for the GPU, not for the reference's rollout count
+    "acrobot_walker_x2": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=16,
+                              budget={"acrobot_q": 22000}),
 }
-SECONDARY_ORDER = ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker"]
+SECONDARY_ORDER = ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker", "acrobot_walker_x2"]
 
 # The batch path (BASELINE.json configs[4], per-GPU share): tests/pendulum-fqi-ann.yaml scaled to 100,000 transitions per
 # batch, 16 independent-seed replicas per GPU.  A step = one batch (100,000 new transitions, FQIPredictor::rebuild over the
@@ -548,7 +554,7 @@ def main():
         # the other configurations BASELINE.json names, each sharded over the same ranks and timed the same way
         sec = []
         for name in SECONDARY_ORDER:
-            if name == "acrobot_walker" and args.no_composite:
+            if name.startswith("acrobot_walker") and args.no_composite:
                 continue
             w = WORKLOADS[name]
             sec.append(run_rollout_workload(name, D, torch, w["steps"], w["warmup"], args.secondary_replicas or None, None, cpu))

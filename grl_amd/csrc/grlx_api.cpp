@@ -596,16 +596,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMemset(ctx->row_time, 0, sizeof(double) * (size_t)N * (size_t)cfg->max_rows));
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->queue, sizeof(uint32_t)));
-  if (cfg->agent == GRLX_AGENT_AC && P.replicas_per_wave >= 12)
-  { // the sub-batches beyond the second park their lane state here (grlx_rollout_ac_wide.h)
-    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * (size_t)(P.replicas_per_wave / 4 - 2) * (size_t)P.wave_limit));
-    P.park = ctx->park;
-  }
-  else if (P.replicas_per_wave == 16)
-  { // ... and those of the TD agents' four-sub-batch waves (grlx_rollout_wide.h): one wave per 16 replicas, two areas each
-    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * 2 * (((size_t)N + 15) / 16)));
-    P.park = ctx->park;
-  }
+  // (the sub-batches beyond the second of a 12- / 16-replica wave park their lane state in registers since round 4: no buffer)
   CTX_TRY(hipMalloc((void **)&ctx->max_load, sizeof(uint32_t)));
   CTX_TRY(hipMemset(ctx->max_load, 0, sizeof(uint32_t)));
   CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));

@@ -353,7 +353,6 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
   { // 15 or more replicas per SIMD: FOUR sub-batches per wave share one environment phase (E + 4 T per 16 replicas instead of 2 (E + 2 T));
     // instantiated where the environment phase is half of a pass: the acrobot and the compass walker with three actions
     const int wwaves = (P.n_replicas + 15) / 16;
-    if (!P.park) return hipErrorInvalidValue;
 #define GRLX_LAUNCH_WIDE4_SPECQ(SPECQ)                                                                                \
     if (!P.no_specialisation && SPECQ::matches(P))                                                                  \
     {                                                                                                               \

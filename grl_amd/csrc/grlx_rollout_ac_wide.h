@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
   static_assert(B >= 2 && B <= 4, "sub-batches per wave");
   constexpr int R = 4 * B;
   constexpr bool ROT = B == 3;               // rotation per trial over an owned set of replicas
-  constexpr bool GLP = B >= 3;               // the sub-batches beyond the second park their lane state in device memory (P.park), not in LDS
+  constexpr bool GLP = B >= 3;               // the sub-batches beyond the second park their lane state in registers (WideRegPark, grlx_rollout_wide.h), not in LDS
   constexpr int BP = GLP ? 2 : B;            // sub-batches parked in LDS
   const DevParams &N = SPEC::numeric(P);
   constexpr int S = Env<ENV>::S, D = Env<ENV>::D, T = kLanesPerReplica;
@@ -225,12 +225,14 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     }
   };
 
-  // GLP: where the lane state of sub-batch b >= 2 is parked (B - 2 areas per wave)
-  constexpr int kParkQuads = kWideQuads * 64 + 3 * 64 / 4;
-  static_assert(kAcParkBytes == kParkQuads * sizeof(uint4), "grlx_api.cpp sizes DevParams.park with kAcParkBytes per wave and area");
-  uint4 *gl_base = GLP ? (uint4 *)P.park + (size_t)blockIdx.x * (size_t)(kParkQuads * (B - 2)) : nullptr;
-  auto gl_ctx = [&](int b) { return gl_base + (b - 2) * kParkQuads; };
-  auto gl_ins = [&](int b) { return (uint32_t *)(gl_base + (b - 2) * kParkQuads + kWideQuads * 64); };
+  // GLP: the lane state of sub-batch 2 / 3 between its turns (b is wave-uniform: the branches below are scalar).  Round 3 kept it in device
+  // memory (P.park): 13 KB per wave, sub-batch and pass written and read back, 132 GB of the bench's 237 GB per launch.
+  WideRegPark rp2, rp3;
+  auto park_state = [&](const WideLane &c, int b) __attribute__((always_inline)) {
+    if (GLP && b == 2) wide_pack<true>(c, rp2);
+    else if (GLP && b == 3) wide_pack<true>(c, rp3);
+    else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+  };
   for (int b = 0; b < B; ++b)
   {
     const int q = 4 * b + g;
@@ -238,8 +240,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
     WideRep s;
     if (q < own) slot_load(wave0 + q, c, s, n_trials);
     else slot_empty(c, s);
-    if (GLP && b >= 2) wide_park<true>(c, gl_ctx(b), gl_ins(b), lane);
-    else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+    park_state(c, b);
     wide_rep_store<R>(s, sh_r64, sh_r32, q);
   }
   wave_sync();
@@ -307,16 +308,20 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       RS.lazy_base[1] = RSg.lazy_base[1];
       const Table tabC = table_of(P, 0, r), tabA = table_of(P, 1, r);
       WideLane c;
-      // GLP: the loads now, the unpacking after the hashing -- those of the sub-batches beyond the second come from the L2, not from LDS
+      // GLP: the LDS loads of the first two sub-batches now, the unpacking after the hashing; those beyond are unpacked from their registers
       uint4 raw[kWideQuads];
       uint32_t rawi[3];
       if constexpr (GLP)
       {
-        if (b >= 2) wide_unpark_load<true>(raw, rawi, gl_ctx(b), gl_ins(b), lane);
-        else wide_unpark_load<true>(raw, rawi, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+        if (b < 2) wide_unpark_load<true>(raw, rawi, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
       }
       else
         wide_unpark<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      auto decode_state = [&](WideLane &cc) __attribute__((always_inline)) {
+        if (b == 2) wide_unpark_decode<true>(cc, rp2.q, rp2.i);
+        else if (b == 3) wide_unpark_decode<true>(cc, rp3.q, rp3.i);
+        else wide_unpark_decode<true>(cc, raw, rawi);
+      };
       WideRep s;
       wide_rep_load<R>(s, sh_r64, sh_r32, q);
       if (!__any(live)) continue;                     // (a live slot always has something to do: it retires the moment it has not)
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
           slotA[0] = tile_slot_obs<T>(N.tile_actor, obs, D, j);
           slotC[0] = tile_slot_obs<T>(N.tile, obs, D, j);
         }
-        if constexpr (GLP) wide_unpark_decode<true>(c, raw, rawi);
+        if constexpr (GLP) decode_state(c);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (update)
         { // as looked up one pass ago (the actor's: or as written by the last actor update to the same slot); slots shared
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
         }
       }
       else if constexpr (GLP)
-        wide_unpark_decode<true>(c, raw, rawi);
+        decode_state(c);
 
       GRLX_AC_STAMP(3)
       // the PREVIOUS step's critic update, in the shadow of the loads just issued
@@ -676,8 +681,7 @@ __global__ __launch_bounds__(64) void rollout_ac_wide_kernel(DevParams P, int n_
       s.S1 = (uint64_t)__double_as_longlong(ac_noise);
       s.eps_decay = ac_decay;
       wide_rep_store<R>(s, sh_r64, sh_r32, q);
-      if (GLP && b >= 2) wide_park<true>(c, gl_ctx(b), gl_ins(b), lane);
-      else wide_park<true>(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 3 * 64, lane);
+      park_state(c, b);
       GRLX_AC_STAMP(7)
     }
     wave_sync();

@@ -47,33 +47,49 @@ __device__ __forceinline__ void unpack2d(const uint4 &q, double &a, double &b)
   b = __longlong_as_double((long long)((uint64_t)q.z | ((uint64_t)q.w << 32)));
 }
 
+// The parked form of a lane's state: kWideQuads 16-byte quads + three counters.  Held in LDS ([quad][lane]: conflict-free b128 accesses) for
+// the first two sub-batches of a wave and in REGISTERS (WideRegPark) for the third and fourth: a wave that is alone on its SIMD has a hundred
+// registers to spare, and what round 3 parked in device memory (13 KB per wave, sub-batch and pass, written and read back: 132 GB per launch
+// of the actor-critic bench, 3 KB per env-step of the 16-replica walker waves) stays in the register file.
+struct WideRegPark { uint4 q[kWideQuads]; uint32_t i[3]; };
+template <bool AC = false>
+__device__ __forceinline__ void wide_pack(const WideLane &c, WideRegPark &p)
+{
+  static_assert(kMaxTrace == 10 && kWideQuads == 12, "the parked layout holds ten trace entries");
+  p.q[0] = make_uint4(c.tr.pos[0], c.tr.pos[1], c.tr.pos[2], c.tr.pos[3]);
+  p.q[1] = make_uint4(c.tr.pos[4], c.tr.pos[5], c.tr.pos[6], c.tr.pos[7]);
+  p.q[2] = make_uint4(c.tr.pos[8], c.tr.pos[9], c.tr.cnt2, c.tr.wt | (c.tr.dup ? 1u << 16 : 0u) | ((uint32_t)c.tr.len << 20));
+#pragma unroll
+  for (int k = 0; k < 5; ++k) p.q[3 + k] = pack2d(c.tr.val[2 * k], c.tr.val[2 * k + 1]);
+  {
+    const uint64_t ut = (uint64_t)__double_as_longlong(c.tr.total);
+    p.q[8] = make_uint4((uint32_t)ut, (uint32_t)(ut >> 32), c.pd_pos, c.p_pos);
+  }
+  p.q[9] = pack2d(c.pd_dW, c.pd_dT);
+  {
+    const uint64_t uw = (uint64_t)__double_as_longlong(c.pd_wp);
+    p.q[10] = make_uint4((uint32_t)uw, (uint32_t)(uw >> 32),
+                         (c.pd ? 1u : 0u) | (c.pd_sh ? 2u : 0u) | (c.p_sh ? 4u : 0u) | ((AC && c.ap_sh) ? 8u : 0u), c.status);
+  }
+  p.q[11] = pack2d(c.wp_seen, c.wap_seen);
+  p.i[0] = c.inserted;
+  p.i[1] = AC ? c.inserted2 : 0u;
+  p.i[2] = AC ? c.ap_pos : kInvalidPos;
+}
+
 // sh_ctx: [quad][lane] of this sub-batch; sh_ins: [lane] (AC: [3][lane])
 template <bool AC = false>
 __device__ __forceinline__ void wide_park(const WideLane &c, uint4 *sh_ctx, uint32_t *sh_ins, int lane)
 {
-  static_assert(kMaxTrace == 10, "the parked layout holds ten trace entries");
-  sh_ctx[0 * 64 + lane] = make_uint4(c.tr.pos[0], c.tr.pos[1], c.tr.pos[2], c.tr.pos[3]);
-  sh_ctx[1 * 64 + lane] = make_uint4(c.tr.pos[4], c.tr.pos[5], c.tr.pos[6], c.tr.pos[7]);
-  sh_ctx[2 * 64 + lane] = make_uint4(c.tr.pos[8], c.tr.pos[9], c.tr.cnt2,
-                                     c.tr.wt | (c.tr.dup ? 1u << 16 : 0u) | ((uint32_t)c.tr.len << 20));
+  WideRegPark p;
+  wide_pack<AC>(c, p);
 #pragma unroll
-  for (int k = 0; k < 5; ++k) sh_ctx[(3 + k) * 64 + lane] = pack2d(c.tr.val[2 * k], c.tr.val[2 * k + 1]);
-  {
-    const uint64_t ut = (uint64_t)__double_as_longlong(c.tr.total);
-    sh_ctx[8 * 64 + lane] = make_uint4((uint32_t)ut, (uint32_t)(ut >> 32), c.pd_pos, c.p_pos);
-  }
-  sh_ctx[9 * 64 + lane] = pack2d(c.pd_dW, c.pd_dT);
-  {
-    const uint64_t uw = (uint64_t)__double_as_longlong(c.pd_wp);
-    sh_ctx[10 * 64 + lane] = make_uint4((uint32_t)uw, (uint32_t)(uw >> 32),
-                                        (c.pd ? 1u : 0u) | (c.pd_sh ? 2u : 0u) | (c.p_sh ? 4u : 0u) | ((AC && c.ap_sh) ? 8u : 0u), c.status);
-  }
-  sh_ctx[11 * 64 + lane] = pack2d(c.wp_seen, c.wap_seen);
-  sh_ins[lane] = c.inserted;
+  for (int k = 0; k < kWideQuads; ++k) sh_ctx[k * 64 + lane] = p.q[k];
+  sh_ins[lane] = p.i[0];
   if (AC)
   {
-    sh_ins[64 + lane] = c.inserted2;
-    sh_ins[128 + lane] = c.ap_pos;
+    sh_ins[64 + lane] = p.i[1];
+    sh_ins[128 + lane] = p.i[2];
   }
 }
 
@@ -239,8 +255,8 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
   __shared__ uint32_t sh_mail[4];
   __shared__ uint64_t sh_jump6[kJump6Words];        // LCG jump table, 6-bit windows (lazy weight initialisation)
   __shared__ double   sh_res[4 * 16];
-  // the sub-batches beyond the second park their lane state in device memory (P.park: kAcParkBytes per wave and sub-batch, rewritten and
-  // re-read by the same wave once per pass), not in LDS: four parked sub-batches would be 50 KB per wave, two waves per CU instead of four
+  // the sub-batches beyond the second park their lane state in registers (WideRegPark), not in LDS: four parked sub-batches would be 50 KB
+  // per wave, two waves per CU instead of four
   constexpr bool GLP = B >= 3;
   constexpr int BP = GLP ? 2 : B;                       // sub-batches parked in LDS
   __shared__ uint4    sh_ctx[BP * kWideQuads * 64];     // parked lane state
@@ -304,10 +320,17 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
     key_act[a] = in_reg(murmur_key(tile_coord<T>(N.tile, D, tile_quant(N.tile, D, N.actions[a]), j)));
   const uint32_t key_j = in_reg(murmur_key(j));
 
-  constexpr int kParkQuads = (int)(kAcParkBytes / sizeof(uint4));
-  uint4 *gl_base = GLP ? (uint4 *)P.park + (size_t)blockIdx.x * (size_t)(kParkQuads * (B - 2)) : nullptr;
-  auto park_ctx = [&](int b) { return (GLP && b >= 2) ? gl_base + (b - 2) * kParkQuads : sh_ctx + b * kWideQuads * 64; };
-  auto park_ins = [&](int b) { return (GLP && b >= 2) ? (uint32_t *)(gl_base + (b - 2) * kParkQuads + kWideQuads * 64) : sh_ins + b * 64; };
+  WideRegPark rp2, rp3;                                 // GLP: the parked state of sub-batch 2 / 3 (b is wave-uniform: the branches below are scalar)
+  auto park_state = [&](const WideLane &c, int b) __attribute__((always_inline)) {
+    if (GLP && b == 2) wide_pack(c, rp2);
+    else if (GLP && b == 3) wide_pack(c, rp3);
+    else wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+  };
+  auto unpark_state = [&](WideLane &c, int b) __attribute__((always_inline)) {
+    if (GLP && b == 2) wide_unpark_decode(c, rp2.q, rp2.i);
+    else if (GLP && b == 3) wide_unpark_decode(c, rp3.q, rp3.i);
+    else wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
+  };
   for (int b = 0; b < B; ++b)
   { // initial parked state of every sub-batch
     const int q = 4 * b + g;
@@ -322,7 +345,7 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
     c.inserted = 0;
     c.ap_pos = kInvalidPos; c.inserted2 = 0; c.ap_sh = false;
     c.wp_seen = 0; c.wap_seen = 0;
-    wide_park(c, park_ctx(b), park_ins(b), lane);
+    park_state(c, b);
     WideRep s;
     s.G = RS.G; s.TL = RS.TL; s.S1 = RS.S1;
     s.eps_decay = RS.eps_decay;
@@ -418,9 +441,6 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
 #endif
       // ================= table phase, one sub-batch after the other
       bool more = false;
-      // GLP: the parked lane state of the sub-batch after the running one is requested from device memory a whole turn before it is unpacked
-      uint4 raw_next[kWideQuads];
-      uint32_t rawi_next[3];
       for (int b = 0; b < B; ++b)
       {
         const int q = 4 * b + g;
@@ -429,9 +449,7 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
         const ReplicaState &RS = P.states[r];
         const Table tab = table_of(P, 0, r);
         WideLane c;
-        if (GLP && b >= 2) wide_unpark_decode(c, raw_next, rawi_next);       // requested during the previous sub-batch's turn
-        else wide_unpark(c, park_ctx(b), park_ins(b), lane);
-        if (GLP && b + 1 >= 2 && b + 1 < B) wide_unpark_load(raw_next, rawi_next, park_ctx(b + 1), park_ins(b + 1), lane);
+        unpark_state(c, b);
         WideRep s;
         wide_rep_load<R>(s, sh_r64, sh_r32, q);
         if (!__any(s.running || c.pd || s.trials_left > 0)) continue;        // this sub-batch has finished its trials
@@ -738,7 +756,7 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
           }
         more = more || s.running || c.pd || s.trials_left > 0;
         wide_rep_store<R>(s, sh_r64, sh_r32, q);
-        wide_park(c, park_ctx(b), park_ins(b), lane);
+        park_state(c, b);
       }
       wave_sync();
 #ifdef GRLX_WIDE_STAMPS
@@ -763,7 +781,7 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
     const int q = 4 * b + g;
     const bool live = wave0 + q < P.n_replicas;
     WideLane c;
-    wide_unpark(c, park_ctx(b), park_ins(b), lane);
+    unpark_state(c, b);
     WideRep s;
     wide_rep_load<R>(s, sh_r64, sh_r32, q);
     uint32_t ins = c.inserted;

@@ -26,6 +26,7 @@ WORKLOAD_PARTS = {
     "acrobot_q": [("acrobot_q", 1.0)],
     "compass_walker_q": [("compass_walker_q", 1.0)],
     "acrobot_walker": [("acrobot_q", 0.5), ("compass_walker_q", 0.5)],
+    "acrobot_walker_x2": [("acrobot_q", 0.5), ("compass_walker_q", 0.5)],
     "pendulum_fqi_ann": [("pendulum_fqi_ann", 1.0)],
 }
 

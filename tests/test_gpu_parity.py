@@ -884,7 +884,7 @@ def test_bench_two_ranks_share_the_replica_range(grlx):
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
 
 
-@pytest.mark.parametrize("workload,replicas", [("cart_pole_ac", 64), ("acrobot_q", 64), ("compass_walker_q", 64), ("acrobot_walker", 64)])
+@pytest.mark.parametrize("workload,replicas", [("cart_pole_ac", 64), ("acrobot_q", 64), ("compass_walker_q", 64), ("acrobot_walker", 64), ("acrobot_walker_x2", 64)])
 def test_bench_every_rollout_workload_on_two_ranks(grlx, workload, replicas):
     """BASELINE configs[2] and [3] have a multi-rank entry point: contiguous replica ids per rank, one all-reduce of the
     curve statistics, env-steps counted by the devices and summed over the ranks."""
@@ -892,8 +892,9 @@ def test_bench_every_rollout_workload_on_two_ranks(grlx, workload, replicas):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["workload"] == workload
     assert out["replicas_per_gpu"] == replicas and out["learn_steps"] > 0 and out["test_steps"] >= 0
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_learn_step"}
-    if workload == "acrobot_walker":
+    if workload.startswith("acrobot_walker"):
         assert [p["graph"] for p in out["parts"]] == ["acrobot_q", "compass_walker_q"]
+        assert [p["replicas_per_wave"] for p in out["parts"]] == ([16, 16] if workload.endswith("x2") else [8, 8])
         assert [p["replicas"] for p in out["parts"]] == [replicas // 2, replicas // 2]
         assert all(p["curve_replicas"] == replicas for p in out["parts"])   # 2 ranks x replicas/2 per graph
         assert "both halves" in out["parallelism"]
@@ -915,7 +916,7 @@ def test_bench_default_line_with_all_secondaries_on_two_ranks(grlx):
                             "--fqi-batch-size", "2000", "--fqi-epochs", "20"], timeout=1500)
     assert out["n_gpus"] == 2 and out["metric"].startswith("env-steps/sec")
     names = [s["workload"] for s in out["secondary"]]
-    assert names == ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker", "pendulum_fqi_ann"]
+    assert names == ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker", "acrobot_walker_x2", "pendulum_fqi_ann"]
     assert all(s["n_gpus"] == 2 and s["value"] > 0 and "roofline" in s for s in out["secondary"])
 
 
