@@ -90,11 +90,11 @@ WORKLOADS = {
     # The acrobot's budget per launch is set so that its kernel lasts about as long as the walkers' (an acrobot step costs a twentieth of a
     # launch's walker work): otherwise its half of the chip idles for 95 % of every launch.
     "acrobot_walker": dict(replicas=8192, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=8,
-                           budget={"acrobot_q": 27000}),
+                           budget={"acrobot_q": 36000}),
     # the same composite with TWICE BASELINE's rollouts per GPU (131072 over 8 GPUs): 8192 + 8192, 512 waves of 16 replicas each -- four
     # sub-batches per wave share one environment phase (round 4); sized for the GPU, not for the reference's rollout count
     "acrobot_walker_x2": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3, replicas_per_wave=16,
-                              budget={"acrobot_q": 22000}),
+                              budget={"acrobot_q": 24000}),
 }
 SECONDARY_ORDER = ["cart_pole_ac", "acrobot_q", "compass_walker_q", "acrobot_walker", "acrobot_walker_x2"]
 
