@@ -137,9 +137,10 @@ typedef struct {
   /* GPU-side layout (no reference counterpart): replicas carried by one wavefront.  0 = automatic: 4 (16 lanes per
    * replica, lane = tiling) while the batch has no more than 4 replicas per SIMD of the device, else 8 (two sub-batches
    * of four share one environment phase; grlx_rollout_wide.h).  4 / 8 force the choice (tests); the actor-critic kernel also
-   * takes 12 and 16 (three / four sub-batches, the lane state of those beyond the second parked in device memory; with 12 a wave
+   * takes 12 and 16 (three / four sub-batches, the lane state of those beyond the second parked in registers; with 12 a wave
    * owns ceil(replicas / waves) replicas and rotates them through its slots trial by trial -- grlx_rollout_ac_wide.h; batches that
    * would give a wave more than 64 replicas run with 8).  Automatic for the actor-critic: 16 from 15 replicas per SIMD up, 12 for 9-14.
+   * 16 also for the TD agents on the acrobot / the compass walker with three actions (round 4; automatic from 15 replicas per SIMD up).
    * Results are identical. */
   int32_t  replicas_per_wave;
   /* 1: the taps are recorded by the PRODUCTION ordering of the rollout kernel (TD update applied one pass later, under the
