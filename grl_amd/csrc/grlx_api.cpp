@@ -322,6 +322,7 @@ struct grlx_ctx {
   // an image no replica refers to any more is freed at the next load, the rest with the context
   std::vector<double *> images;
   std::vector<int>      image_of[2];
+  std::vector<double *> target_images;    // per replica: the target network's dense vector after a load with tau != 0 (ReplicaState::target_base)
   hipStream_t  run_stream = nullptr;      // stream of the last grlx_run / grlx_curve_stats
   bool         run_pending = false;       // ... with work possibly still in flight on it
   int          n_tables = 1;
@@ -693,6 +694,8 @@ int grlx_destroy(grlx_ctx *ctx)
   (void)hipFree(ctx->diag);
   (void)hipFree(ctx->trace_state);
   (void)hipFree(ctx->tvals);
+  for (double *timg : ctx->target_images)
+    if (timg) (void)hipFree(timg);
   for (double *img : ctx->images)
     if (img) (void)hipFree(img);
   delete ctx;
@@ -783,8 +786,6 @@ int grlx_grow_tables(grlx_ctx *ctx, uint32_t new_log2)
 int grlx_reset_run(grlx_ctx *ctx)
 {
   if (!ctx) return fail(GRLX_ERR_INVALID, "null ctx");
-  if (ctx->cfg.target_interval > 0 || ctx->cfg.projector.safe != 0)
-    return fail(GRLX_ERR_INVALID, "experiment reset (runs > 1) is not built for representations with a target network (interval) or projectors with safe >= 1");
   DRAIN(ctx);
   HIP_TRY(hipDeviceSynchronize());
   const size_t N = (size_t)ctx->P.n_replicas;
@@ -792,8 +793,14 @@ int grlx_reset_run(grlx_ctx *ctx)
   HIP_TRY(hipMemcpy(hs.data(), ctx->states, sizeof(ReplicaState) * N, hipMemcpyDeviceToHost));
   uint64_t table_draws = (uint64_t)ctx->cfg.projector.memory;
   if (ctx->cfg.agent == GRLX_AGENT_AC || ctx->cfg.agent == GRLX_AGENT_QV) table_draws += (uint64_t)ctx->cfg.actor_projector.memory;
+  // a target network is reached by the walk too (a provided object is a child configurator, visited before the representation itself:
+  // configurable.cpp:690-712, 754-757): it draws again first, the representation next, synchronize() blends the two fresh vectors -- the
+  // sequence of construction, from the continuing stream; ParameterizedRepresentation::count_ = 0
+  if (ctx->cfg.target_interval > 0) table_draws += (uint64_t)ctx->cfg.projector.memory;
   for (ReplicaState &s : hs)
   {
+    s.sync_count = 0;
+    s.syncs = 0;
     s.TL0 = s.TL;                         // the re-draw starts where the stream stands
     s.TL = h_jump(s.TL, table_draws);
     s.eps_decay = 1;
@@ -806,9 +813,13 @@ int grlx_reset_run(grlx_ctx *ctx)
     s.rows = 0;
     s.n_slots[0] = s.n_slots[1] = 0;
     s.lazy_base[0] = s.lazy_base[1] = nullptr;      // a loaded policy is overwritten by the re-draw like every other parameter
+    s.target_base = nullptr;
+    s.syncs_base = 0;
   }
   HIP_TRY(hipMemcpy(ctx->states, hs.data(), sizeof(ReplicaState) * N, hipMemcpyHostToDevice));
+  // (emptying the tables drops the claims of projector/tile_coding:safe with them: tile_coding.cpp:82-89)
   HIP_TRY(hipMemset(ctx->tables, 0, (N * (size_t)ctx->n_tables * sizeof(Entry)) << ctx->P.logC));
+  if (ctx->tvals) HIP_TRY(hipMemset(ctx->tvals, 0xFF, (N * sizeof(double)) << ctx->P.logC));      // kTvalUnset: not materialised
   HIP_TRY(hipMemset(ctx->max_load, 0, sizeof(uint32_t)));
   if (ctx->trace_state)
   {
@@ -820,6 +831,8 @@ int grlx_reset_run(grlx_ctx *ctx)
   if (ctx->tap_count) HIP_TRY(hipMemset(ctx->tap_count, 0, sizeof(uint32_t)));
   if (ctx->agent_rep) HIP_TRY(hipMemset(ctx->agent_rep, 0, sizeof(AgentRep) * N));
   if (ctx->agent_lane) HIP_TRY(hipMemset(ctx->agent_lane, 0, sizeof(uint32_t) * N * 16 * 2));
+  for (double *&timg : ctx->target_images)
+    if (timg) { (void)hipFree(timg); timg = nullptr; }
   ctx->trials_run = 0;
   return GRLX_OK;
 }
@@ -1178,8 +1191,14 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
     return fail(GRLX_ERR_INVALID, "configuration mismatch: %llu weights given, the table has %zu", (unsigned long long)count, memory);
   if (ctx->cfg.agent == GRLX_AGENT_AC && ctx->trials_run != 0)
     return fail(GRLX_ERR_INVALID, "actor-critic: load before the first run (the critic's trace refers to table positions)");
-  if (ctx->cfg.target_interval > 0)
-    return fail(GRLX_ERR_INVALID, "loading parameters into a representation with a target network is not built");
+  // a target network (table 0 of a SARSA / Q context): setParams is followed by synchronize() (representation.h:256-257) -- target <- tau * image
+  // + (1 - tau) * target over the WHOLE parameter vector.  With tau = 0 the target is the image; otherwise every replica needs its own dense
+  // vector of the result (its old target differs), `memory` doubles each, held until the next load or reset.
+  const bool with_target = ctx->cfg.target_interval > 0 && table == 0;
+  const bool target_images = with_target && ctx->cfg.target_tau != 0.;
+  if (target_images && (double)n_replicas * (double)memory * sizeof(double) > 8.0 * 1024 * 1024 * 1024)
+    return fail(GRLX_ERR_OOM, "loading into a target network with tau != 0 keeps one dense target vector per replica (%zu doubles each): %d replicas exceed the 8 GiB this entry point allows",
+                memory, n_replicas);
   if (n_replicas == 0) return GRLX_OK;
   HIP_TRY(hipDeviceSynchronize());
   ctx->run_pending = false;
@@ -1193,6 +1212,31 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
     for (int r = first_replica; r < first_replica + n_replicas; ++r) of[(size_t)r] = mine;
   }
   HIP_TRY(hipMemcpy(img, dense, sizeof(double) * memory, hipMemcpyHostToDevice));
+  if (with_target)
+  { // the target's new values, from its values NOW (entries and lazily defined ones alike), BEFORE the tables are emptied
+    if (ctx->target_images.empty()) ctx->target_images.assign((size_t)N, nullptr);
+    std::vector<ReplicaState> hs((size_t)n_replicas);
+    HIP_TRY(hipMemcpy(hs.data(), ctx->states + first_replica, sizeof(ReplicaState) * (size_t)n_replicas, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n_replicas; ++k)
+    {
+      const int r = first_replica + k;
+      double *timg = nullptr;
+      if (target_images)
+      {
+        if (hipMalloc((void **)&timg, sizeof(double) * memory) != hipSuccess) return fail(GRLX_ERR_OOM, "no device memory for the target vector of replica %d", r);
+        HIP_TRY(launch_target_after_load(ctx->P, r, img, timg, nullptr));
+      }
+      HIP_TRY(hipDeviceSynchronize());
+      if (ctx->target_images[(size_t)r]) (void)hipFree(ctx->target_images[(size_t)r]);      // (read by the kernel above for the last time)
+      ctx->target_images[(size_t)r] = timg;
+      hs[(size_t)k].target_base = timg;
+      hs[(size_t)k].syncs += 1;                     // the load's synchronize() (count_ = 0, representation.h:284-296)
+      hs[(size_t)k].syncs_base = hs[(size_t)k].syncs;
+      hs[(size_t)k].sync_count = 0;
+    }
+    HIP_TRY(hipMemcpy(ctx->states + first_replica, hs.data(), sizeof(ReplicaState) * (size_t)n_replicas, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(ctx->tvals + ((size_t)first_replica << ctx->P.logC), 0xFF, ((size_t)n_replicas * sizeof(double)) << ctx->P.logC));      // kTvalUnset
+  }
   // setParams() overwrites every weight: forget the sparse tables of these replicas; every slot is
   // re-created on first touch from the image
   const size_t per_replica = sizeof(Entry) << ctx->P.logC;

@@ -57,7 +57,10 @@ struct __attribute__((aligned(16))) ReplicaState {
   // target network of table 0 (rollout_tgt_kernel): ParameterizedRepresentation::count_ and the synchronisations so far
   int64_t  sync_count;
   uint32_t syncs;
-  uint32_t pad1;
+  // ... after a load into it ({action: load}: setParams + synchronize, representation.h:231-263): the target's value of EVERY slot right
+  // after that synchronisation (dense, per replica; NULL = none) and the number of synchronisations it already holds
+  uint32_t syncs_base;
+  const double *target_base;
 };
 
 // Per-replica state of the per-step agent entry points (grlx_step.h) between two calls: TDAgent::time_ (td.h) and the
@@ -184,6 +187,7 @@ hipError_t launch_env_step(const DevParams &P, double *state_dev, const double *
 hipError_t launch_table_op(const DevParams &P, int table, int op, const int32_t *replica_dev, const uint32_t *idx_dev, int n,
                            const double *arg_dev, double alpha, double *out_dev, hipStream_t stream);
 hipError_t launch_set_lazy_base(const DevParams &P, int table, int first, int count, const double *image_dev, hipStream_t stream);
+hipError_t launch_target_after_load(const DevParams &P, int replica, const double *image_dev, double *out_dev, hipStream_t stream);
 hipError_t launch_export_weights(const DevParams &P, int table, int replica, double *out_dev, hipStream_t stream);
 hipError_t launch_get_weights(const DevParams &P, int table, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream);
 hipError_t launch_math(int op, const double *x, const double *y, int n, double *out, hipStream_t stream);

@@ -23,12 +23,19 @@ constexpr unsigned long long kTvalUnset = 0xFFFFFFFFFFFFFFFFull;       // tvals[
 // target value of a slot that has had no entry during the first K synchronisations (its parameter is its initial draw)
 __device__ inline double target_from_init(const DevParams &P, const ReplicaState &rs, uint32_t slot, uint32_t K)
 {
+  const double tau = P.target_tau;
+  const double p0 = initial_weight(rs, 0, P.lin, slot);                 // the slot's parameter: its draw, or a loaded image's value
+  if (tau == 0.) return p0;                                             // setParams(params()) at reset, at a load and ever after
+  if (rs.target_base)
+  { // loaded (grlx_load_weights): the target of every slot right after the load's synchronize(), then the recurrence with the image's value
+    double tl = rs.target_base[slot];
+    if (tau == 1.) return tl;
+    for (uint32_t k = rs.syncs_base; k < K; ++k) tl = tau * p0 + (1 - tau) * tl;
+    return tl;
+  }
   LinearParams first = P.lin;
   first.draws_before = 0;                                               // the target table's own draws come first
   double t = lazy_weight(rs.TL0, first, slot);
-  const double p0 = lazy_weight(rs.TL0, P.lin, slot);
-  const double tau = P.target_tau;
-  if (tau == 0.) return p0;                                             // setParams(params()) at reset and ever after
   t = tau * p0 + (1 - tau) * t;                                         // synchronize() at the end of reset (linear.cpp:122)
   if (tau == 1.) return t;                                              // (1 - tau) * t == +-0: every later round returns the same bits
   for (uint32_t k = 0; k < K; ++k) t = tau * p0 + (1 - tau) * t;
@@ -654,6 +661,45 @@ __global__ void get_target_weights_kernel(DevParams P, int replica, const uint32
     b = (b + 1u) & tab.bmask;
   }
   out[i] = v;
+}
+
+// {action: load} into a representation with a target network (representation.h:231-263): setParams(image), then synchronize() --
+// target <- tau * image + (1 - tau) * target over the WHOLE parameter vector.  out[slot] = that value for every slot of one replica, from the
+// target's value NOW (its table entry, or what target_from_init gives an untouched slot); the caller then empties the replica's table.
+__global__ void target_after_load_kernel(DevParams P, int replica, const double *image, double *out)
+{
+  const uint32_t n = (uint32_t)P.tile.memory;
+  const Table tab = table_of(P, 0, replica);
+  const ReplicaState &rs = P.states[replica];
+  const double *tv = P.tvals + ((size_t)replica << P.logC);
+  const double tau = P.target_tau;
+  for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x)
+  {
+    if (tau == 0.) { out[slot] = image[slot]; continue; }
+    uint32_t b = table_home(tab, slot);
+    double v = target_from_init(P, rs, slot, rs.syncs);
+    for (int it = 0; it < kMaxProbe; ++it)
+    {
+      const BucketRegs br = bucket_load(tab, b);
+      uint32_t empty;
+      const int way = bucket_find(br.k, slot, empty);
+      if (way >= 0)
+      {
+        const double t = tv[(b << 2) | (uint32_t)way];
+        if ((unsigned long long)__double_as_longlong(t) != kTvalUnset) v = t;
+        break;
+      }
+      if (empty != 0u) break;
+      b = (b + 1u) & tab.bmask;
+    }
+    out[slot] = tau * image[slot] + (1 - tau) * v;
+  }
+}
+
+hipError_t launch_target_after_load(const DevParams &P, int replica, const double *image_dev, double *out_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(target_after_load_kernel, dim3(2048), dim3(256), 0, stream, P, replica, image_dev, out_dev);
+  return hipGetLastError();
 }
 
 hipError_t launch_get_target_weights(const DevParams &P, int replica, const uint32_t *slots_dev, int n, double *out_dev, hipStream_t stream)

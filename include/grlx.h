@@ -279,8 +279,9 @@ int  grlx_replica_rows(grlx_ctx *ctx, int replica);          /* rows replica `re
 /* Experiment::reset() between two runs of `runs: N` (online_learning.cpp:307-308; Configurable::reset, configurable.h:770-776):
  * the representations' parameters are drawn again from the CONTINUING thread-local stream (linear.cpp:104-125), predictors clear
  * their traces (sarsa.cpp:60-66), epsilon-greedy and the action policy set decay_ = 1 (greedy.cpp:140-141, action.cpp:93-97); the
- * run's step / trial counters and rows start again; no stream is reseeded.  GRLX_ERR_INVALID for contexts with a target network
- * (interval) or safe >= 1. */
+ * run's step / trial counters and rows start again; no stream is reseeded.  A target network draws again too, before its representation
+ * (the walk visits the provided `target` object first: configurable.cpp:690-712, 754-757), and is synchronised from the two fresh vectors as
+ * at construction; the claims of projector/tile_coding:safe are dropped (tile_coding.cpp:82-89). */
 int  grlx_reset_run(grlx_ctx *ctx);
 /* Replaces reading target()->params() (representation.h:266-282): the target network's current value of the given
  * reference slots of the Q table, and the number of synchronisations so far; contexts with target_interval > 0 only. */

@@ -695,10 +695,22 @@ int orc_reset_run(orc_exp *e)
    *   predictor/critic/{sarsa,q,...} (sarsa.cpp:60-66, advantage.cpp:67, qv.cpp:71, td.cpp:64): finalize() = the trace is cleared;
    *   sampler/epsilon_greedy (greedy.cpp:140-141) and mapping/policy/action (action.cpp:93-97): decay_ = 1;
    *   sampler/greedy, the environment, the tile coding without a claim table: nothing (greedy.cpp:43-45).
-   * The run's own counters (ss, tt: loop variables of online_learning.cpp:154) start again.  Returns -1 for the two options whose
-   * reset is not restated here (a target network: synchronize() blends the re-drawn parameters into the OLD target; safe >= 1). */
+   *   a target network (round 4): the walk reaches the target too -- ObjectConfigurator::instantiate adds every PROVIDED parameter that is
+   *     an object as a child configurator (configurable.cpp:690-712: `target`), and ObjectConfigurator::reconfigure visits the children
+   *     BEFORE the object itself (configurable.cpp:754-757) -- so the target draws its parameters again first, the representation next, and
+   *     its synchronize() then blends the two fresh vectors: the sequence of construction (representation.h:186-190, linear.cpp:104-125),
+   *     from the continuing stream; count_ = 0;
+   *   projector/tile_coding with a claim table (tile_coding.cpp:82-89): every claim is dropped.
+   * The run's own counters (ss, tt: loop variables of online_learning.cpp:154) start again. */
   const orc_spec *s = &e->spec;
-  if (e->wt || e->claim || s->agent == ORC_AGENT_PID) return -1;
+  if (s->agent == ORC_AGENT_PID) return -1;
+  if (e->claim) memset(e->claim, 0xFF, (size_t)s->projector.memory * sizeof(int32_t));
+  if (e->wt)
+  {
+    const size_t n = (size_t)s->projector.memory;
+    for (size_t i = 0; i < n; ++i)
+      e->wt[i] = s->representation.init_min + orc_drand48(&e->TL) * (s->representation.init_max - s->representation.init_min);
+  }
   const int first = (s->agent == ORC_AGENT_AC) ? 1 : 0, second = (s->agent == ORC_AGENT_AC) ? 0 : 1;
   const orc_tile_spec *ts[2] = {&s->projector, &s->actor_projector};
   const orc_linear_spec *ls[2] = {&s->representation, &s->actor_representation};
@@ -711,6 +723,7 @@ int orc_reset_run(orc_exp *e)
     for (size_t i = 0; i < n; ++i)
       e->w[t][i] = ls[t]->init_min + orc_drand48(&e->TL) * (ls[t]->init_max - ls[t]->init_min);
   }
+  if (e->wt) { target_synchronize(e); e->syncs = 0; }
   trace_clear(&e->trace);
   e->eps_decay = 1;
   e->ac_decay = 1;
@@ -946,6 +959,7 @@ int orc_set_weights(orc_exp *e, int table, const double *w, size_t n)
   const size_t mem = (size_t)(table == 1 ? e->spec.actor_projector.memory : e->spec.projector.memory);
   if ((table != 0 && table != 1) || !e->w[table] || !w || n != mem) return -1;
   memcpy(e->w[table], w, n * sizeof(double));
+  if (table == 0 && e->wt) target_synchronize(e);      /* {action: load}: setParams(p); synchronize() (representation.h:256-257) */
   return 0;
 }
 void orc_set_state(orc_exp *e, const double *state) { memcpy(e->state, state, sizeof(double) * (size_t)orc_env_state_dims(e->spec.env)); }

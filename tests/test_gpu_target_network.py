@@ -206,3 +206,44 @@ def test_deployer_safe_tile_coding(grlx, tmp_path):
     e = ob.Experiment(spec, seed=7)
     rows, _ = e.run(33)
     assert (tmp_path / "pendulum-sarsa-tc-0.txt").read_text() == e.format_rows(rows)
+
+
+@pytest.mark.parametrize("agent,tau", [(0, 0.3), (1, 0.0), (1, 1.0)])
+def test_load_into_a_representation_with_a_target_network(grlx, agent, tau):
+    """Round 4: ParameterizedRepresentation {action: load} with a target network (representation.h:231-263): setParams(image) is followed
+    by synchronize() -- target <- tau * image + (1 - tau) * target over the WHOLE parameter vector, created slots and untouched ones alike
+    (tau = 0: the image).  A policy trained elsewhere is loaded into replicas 1 and 2 in mid-run, TWICE (the second load blends into what
+    the first one and 12 more trials left); replica 0 is not touched.  Rows, streams, the main table, the target table at 6000 sampled
+    slots and the number of synchronisations against the oracle's set_weights() at the same points."""
+    src = ob.Experiment(ob.pendulum_sarsa_spec(agent=agent), seed=77)
+    src.run(25)
+    image = src.all_weights()
+    image2 = image[::-1].copy()
+    seeds = [31, 32, 33]
+    cfg = grlx.pendulum_sarsa_config(len(seeds), agent=agent, target_interval=190, target_tau=tau)
+    r = grlx.Runner(cfg, seeds)
+    r.run(9); r.sync()
+    r.load_weights(image, first_replica=1, n_replicas=2)
+    r.run(12); r.sync()
+    r.load_weights(image2, first_replica=1, n_replicas=2)
+    r.run(8); r.sync()
+    slots = np.random.default_rng(9).integers(0, 8388608, 6000).astype(np.uint32)
+    for k, seed in enumerate(seeds):
+        e = ob.Experiment(ob.pendulum_sarsa_spec(agent=agent, target_interval=190, target_tau=tau), seed=seed)
+        rows = list(e.run(9)[0])
+        if k >= 1:
+            e.set_weights(image)
+        rows += list(e.run(12)[0])
+        if k >= 1:
+            e.set_weights(image2)
+        rows += list(e.run(8)[0])
+        t, s, rew = r.rows(k)
+        assert list(s) == [x.steps for x in rows]
+        assert_bit_equal(rew, [x.reward for x in rows], f"returns of seed {seed}")
+        assert list(r.rng(k))[:4] == list(e.rng())[:4]
+        assert_bit_equal(r.weights(k, slots), e.weights(slots), f"main table of replica {k}")
+        tw, syncs = r.target_weights(k, slots)
+        assert syncs == e.L.orc_target_syncs(e.h)
+        assert_bit_equal(tw, e.weights(slots, table=2), f"target table of replica {k}")
+        e.close()
+    r.close()
