@@ -22,7 +22,7 @@ statistics [rows][3], inside the timed region.
   --workload acrobot_walker             BASELINE configs[3]: 8192 rollouts per GPU = 4096 acrobot + 4096 compass walker,
                                         both halves on every rank, two contexts on two HIP streams
   --workload acrobot_walker_x2          the same composite with twice the rollouts per GPU (8192 + 8192, 16 replicas per wave)
-  --workload acrobot_q | compass_walker_q   one half of configs[3] alone, 8192 / 16384 replicas per GPU
+  --workload acrobot_q | compass_walker_q   one half of configs[3] alone, 8192 / 32768 replicas per GPU
   --workload pendulum_fqi_ann           BASELINE configs[4]: replicas only (16 independent-seed batch experiments per GPU)
 """
 import argparse
@@ -73,7 +73,7 @@ GRAPHS = {
                              "(co-resident pair, one timed launch; rollout_wide_kernel<acrobot, 3 actions, 8 replicas per wave, SpecAcrobotQ> with GRLX_ENV_SERVER=0)",
                       text="acrobot balancing Q-learning tile coding (agent block of cfg/pendulum/q_tc.yaml)"),
     "compass_walker_q": dict(trials=0, budget=12200, want_kernel=2, pmc_key="compass_walker_q",
-                             kernel="rollout_wide_kernel<compass_walker, 3 actions, 16 replicas per wave (four sub-batches, two parked in device memory), SpecWalkerQ, deferred update>",
+                             kernel="rollout_wide_kernel<compass_walker, 3 actions, 32 replicas per wave (eight sub-batches: one parked in LDS, two in registers, five in device memory), SpecWalkerQ, deferred update>",
                              text="compass walker Q-learning tile coding (cfg/compass_walker/qlearning_walk.yaml)"),
 }
 
@@ -82,9 +82,9 @@ WORKLOADS = {
     "pendulum_sarsa": dict(replicas=REPLICAS_PER_GPU, steps=20, warmup=3, dominant="pendulum_sarsa", baseline_config=1),
     "cart_pole_ac": dict(replicas=16384, steps=5, warmup=1, dominant="cart_pole_ac", baseline_config=2),
     "acrobot_q": dict(replicas=8192, steps=5, warmup=1, dominant="acrobot_q", baseline_config=3),
-    # 16 replicas per SIMD: four sub-batches per wave share one environment phase (A/B on one box, tools/wide16_ab.sh: 239 M with 8 per wave,
-    # 279 M with 16, 302 M with the parked state of the next sub-batch requested a turn ahead, at 16384 replicas; 233 M at 8192 replicas with 8 per wave)
-    "compass_walker_q": dict(replicas=16384, steps=5, warmup=1, dominant="compass_walker_q", baseline_config=3),
+    # 32 replicas per SIMD: EIGHT sub-batches per wave share one environment phase (A/B on one box, tools/wide16_ab.sh / wide32_ab.sh: 233 M at 8192
+    # replicas with 8 per wave; 239 / 309 M at 16384 with 8 / 16 per wave; 311 / 364 M at 32768 with 16 / 32 per wave)
+    "compass_walker_q": dict(replicas=32768, steps=4, warmup=1, dominant="compass_walker_q", baseline_config=3),
     # both halves on every rank, each as 512 waves of 8 replicas: together one wave per SIMD, both kernels resident for the whole launch
     # (the acrobot's waves beside their environment server's).
     # The acrobot's budget per launch is set so that its kernel lasts about as long as the walkers' (an acrobot step costs a twentieth of a

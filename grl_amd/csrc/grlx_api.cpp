@@ -498,9 +498,12 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   // 16 for the TD agents: the four-sub-batch instantiations of rollout_wide_kernel (the acrobot and the compass walker, three actions)
   const bool td16 = cfg->replicas_per_wave == 16 && (cfg->env == GRLX_ENV_ACROBOT || cfg->env == GRLX_ENV_COMPASS_WALKER) && cfg->action_steps == 3 &&
                     (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA);
-  if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8 && !td16 &&
+  // 32: the eight-sub-batch instantiation (the compass walker: two lanes per replica suffice for its environment phase)
+  const bool td32 = cfg->replicas_per_wave == 32 && cfg->env == GRLX_ENV_COMPASS_WALKER && cfg->action_steps == 3 &&
+                    (cfg->agent == GRLX_AGENT_SARSA || cfg->agent == GRLX_AGENT_Q || cfg->agent == GRLX_AGENT_EXPECTED_SARSA);
+  if (cfg->replicas_per_wave != 0 && cfg->replicas_per_wave != 4 && cfg->replicas_per_wave != 8 && !td16 && !td32 &&
       !((cfg->replicas_per_wave == 12 || cfg->replicas_per_wave == 16) && cfg->agent == GRLX_AGENT_AC))
-    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8 (12: actor-critic only; 16: actor-critic, and the TD agents on the acrobot / the compass walker with 3 actions)");
+    return fail(GRLX_ERR_INVALID, "replicas_per_wave must be 0 (automatic), 4 or 8 (12: actor-critic only; 16: actor-critic, and the TD agents on the acrobot / the compass walker with 3 actions; 32: the TD agents on the compass walker)");
   if (cfg->wave_limit < 0) return fail(GRLX_ERR_INVALID, "wave_limit must be 0 (automatic) or positive");
   if (cfg->tap_deferred && cfg->tap_replica >= 0 && cfg->tap_capacity > 0)
   {
@@ -565,7 +568,7 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
     // per wave share one environment phase (rollout_wide_kernel<., 3, 4, .>)
     if (cfg->replicas_per_wave == 0 && cfg->agent != GRLX_AGENT_AC && rpw == 8 && cfg->action_steps == 3 &&
         (cfg->env == GRLX_ENV_ACROBOT || cfg->env == GRLX_ENV_COMPASS_WALKER) && (N + simds - 1) / simds >= 15)
-      rpw = 16;
+      rpw = (cfg->env == GRLX_ENV_COMPASS_WALKER && (N + simds - 1) / simds >= 30) ? 32 : 16;
     if (!has_wide || P.tap_capacity > 0) rpw = 4;
     P.replicas_per_wave = rpw;
     P.wave_limit = cfg->wave_limit > 0 ? cfg->wave_limit : simds;      // these kernels hold a SIMD's whole register file: one wave per SIMD
@@ -598,6 +601,11 @@ int grlx_create(const grlx_config *cfg, const int64_t *seeds, grlx_ctx **out)
   CTX_TRY(hipMalloc((void **)&ctx->scratch, sizeof(uint64_t) * 8));
   CTX_TRY(hipMalloc((void **)&ctx->queue, sizeof(uint32_t)));
   // (the sub-batches beyond the second of a 12- / 16-replica wave park their lane state in registers since round 4: no buffer)
+  if (P.replicas_per_wave == 32)
+  { // ... five of the eight sub-batches of a 32-replica wave here (grlx_rollout_wide.h: MEMP)
+    CTX_TRY(hipMalloc(&ctx->park, kAcParkBytes * 5 * (((size_t)N + 31) / 32)));
+    P.park = ctx->park;
+  }
   CTX_TRY(hipMalloc((void **)&ctx->max_load, sizeof(uint32_t)));
   CTX_TRY(hipMemset(ctx->max_load, 0, sizeof(uint32_t)));
   CTX_TRY(hipMalloc((void **)&ctx->tap_count, sizeof(uint32_t)));

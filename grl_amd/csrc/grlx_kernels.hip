@@ -349,6 +349,20 @@ hipError_t launch_rollout(const DevParams &P, int n_trials, hipStream_t stream, 
 #undef GRLX_LAUNCH_ADV
     return hipErrorInvalidValue;
   }
+  if (!inplace && P.replicas_per_wave == 32)
+  { // 30 or more compass walkers per SIMD: EIGHT sub-batches per wave (two lanes per replica in the environment phase: the walker's two sines);
+    // the sub-batches beyond the fourth park in P.park
+    const int wwaves = (P.n_replicas + 31) / 32;
+    if (!P.park || P.env != GRLX_ENV_COMPASS_WALKER || P.A != 3) return hipErrorInvalidValue;
+    if (!P.no_specialisation && SpecWalkerQ::matches(P))
+    {
+      if (variant) *variant = GRLX_KERNEL_SPECIALISED;
+      hipLaunchKernelGGL((rollout_wide_kernel<GRLX_ENV_COMPASS_WALKER, 3, 8, SpecWalkerQ>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+      return hipGetLastError();
+    }
+    hipLaunchKernelGGL((rollout_wide_kernel<GRLX_ENV_COMPASS_WALKER, 3, 8, SpecNone>), dim3(wwaves), dim3(64), 0, stream, P, n_trials);
+    return hipGetLastError();
+  }
   if (!inplace && P.replicas_per_wave == 16)
   { // 15 or more replicas per SIMD: FOUR sub-batches per wave share one environment phase (E + 4 T per 16 replicas instead of 2 (E + 2 T));
     // instantiated where the environment phase is half of a pass: the acrobot and the compass walker with three actions

@@ -240,7 +240,7 @@ __device__ __forceinline__ void wide_rep_load(WideRep &s, const uint64_t *sh64, 
 template <int ENV, int NA, int B, typename SPEC, bool SERVED>
 __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_trials)
 {
-  static_assert(B >= 2 && B <= 4, "sub-batches per wave");
+  static_assert(B == 2 || B == 3 || B == 4 || B == 8, "sub-batches per wave");
   static_assert(!SERVED || (B == 2 && NA == 3), "what the environment server of the wide kernels works for");
   constexpr int R = 4 * B;
   constexpr int NROWS = NA + 1;
@@ -258,7 +258,8 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
   // the sub-batches beyond the second park their lane state in registers (WideRegPark), not in LDS: four parked sub-batches would be 50 KB
   // per wave, two waves per CU instead of four
   constexpr bool GLP = B >= 3;
-  constexpr int BP = GLP ? 2 : B;                       // sub-batches parked in LDS
+  constexpr bool MEMP = B > 4;                          // (32 replicas per wave: see below)
+  constexpr int BP = MEMP ? 1 : GLP ? 2 : B;            // sub-batches parked in LDS (four waves per CU must keep fitting its 160 KB)
   __shared__ uint4    sh_ctx[BP * kWideQuads * 64];     // parked lane state
   __shared__ uint32_t sh_ins[BP * 64];
   __shared__ uint64_t sh_r64[WR_FIELDS64 * R];          // parked per-replica scalars
@@ -291,7 +292,7 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
   LaneShare lshare;
   lshare.src[0] = eq; lshare.src[1] = eq + R; lshare.src[2] = eq + 2 * R;
   lshare.role3 = (lane / R) % 3; lshare.role2 = (lane / R) & 1;
-  static_assert(64 / R >= 3, "three lanes per replica share an equation of motion");
+  static_assert(64 / R >= (ENV == GRLX_ENV_COMPASS_WALKER ? 2 : 3), "the lanes of a replica share out an equation of motion's sines (walker: two, else three)");
   if (lane < R)
   {
     sh_step[lane] = 0u; sh_est[lane] = 0u; sh_term[lane] = 0; sh_reward[lane] = 0; sh_act[lane] = 0;
@@ -321,14 +322,24 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
   const uint32_t key_j = in_reg(murmur_key(j));
 
   WideRegPark rp2, rp3;                                 // GLP: the parked state of sub-batch 2 / 3 (b is wave-uniform: the branches below are scalar)
+  // MEMP (B = 8, 32 replicas per wave): sub-batch 0 parks in LDS, 2 and 3 in registers, 1 and 4..7 in device memory (P.park: kAcParkBytes per
+  // wave and sub-batch, written at the end of a turn, requested again one turn before it is unpacked)
+  constexpr int kParkQuads = (int)(kAcParkBytes / sizeof(uint4));
+  constexpr int kMemAreas = MEMP ? B - 3 : 0;
+  uint4 *gl_base = MEMP ? (uint4 *)P.park + (size_t)blockIdx.x * (size_t)(kParkQuads * kMemAreas) : nullptr;
+  auto in_memory = [&](int b) __attribute__((always_inline)) { return MEMP && (b == 1 || b >= 4); };
+  auto gl_ctx = [&](int b) __attribute__((always_inline)) { return gl_base + (b == 1 ? 0 : b - 3) * kParkQuads; };
+  auto gl_ins = [&](int b) __attribute__((always_inline)) { return (uint32_t *)(gl_ctx(b) + kWideQuads * 64); };
   auto park_state = [&](const WideLane &c, int b) __attribute__((always_inline)) {
     if (GLP && b == 2) wide_pack(c, rp2);
     else if (GLP && b == 3) wide_pack(c, rp3);
+    else if (in_memory(b)) wide_park(c, gl_ctx(b), gl_ins(b), lane);
     else wide_park(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
   };
   auto unpark_state = [&](WideLane &c, int b) __attribute__((always_inline)) {
     if (GLP && b == 2) wide_unpark_decode(c, rp2.q, rp2.i);
     else if (GLP && b == 3) wide_unpark_decode(c, rp3.q, rp3.i);
+    else if (in_memory(b)) wide_unpark(c, gl_ctx(b), gl_ins(b), lane);
     else wide_unpark(c, sh_ctx + b * kWideQuads * 64, sh_ins + b * 64, lane);
   };
   for (int b = 0; b < B; ++b)
@@ -441,6 +452,7 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
 #endif
       // ================= table phase, one sub-batch after the other
       bool more = false;
+      WideRegPark nxt;                                  // MEMP: the parked state of the sub-batch after the running one, on its way from memory
       for (int b = 0; b < B; ++b)
       {
         const int q = 4 * b + g;
@@ -449,7 +461,9 @@ __device__ __forceinline__ void rollout_wide_body(const DevParams &P, int n_tria
         const ReplicaState &RS = P.states[r];
         const Table tab = table_of(P, 0, r);
         WideLane c;
-        unpark_state(c, b);
+        if (in_memory(b)) wide_unpark_decode(c, nxt.q, nxt.i);               // requested during the previous sub-batch's turn
+        else unpark_state(c, b);
+        if (b + 1 < B && in_memory(b + 1)) wide_unpark_load(nxt.q, nxt.i, gl_ctx(b + 1), gl_ins(b + 1), lane);
         WideRep s;
         wide_rep_load<R>(s, sh_r64, sh_r32, q);
         if (!__any(s.running || c.pd || s.trials_left > 0)) continue;        // this sub-batch has finished its trials

@@ -140,8 +140,8 @@ typedef struct {
    * takes 12 and 16 (three / four sub-batches, the lane state of those beyond the second parked in registers; with 12 a wave
    * owns ceil(replicas / waves) replicas and rotates them through its slots trial by trial -- grlx_rollout_ac_wide.h; batches that
    * would give a wave more than 64 replicas run with 8).  Automatic for the actor-critic: 16 from 15 replicas per SIMD up, 12 for 9-14.
-   * 16 also for the TD agents on the acrobot / the compass walker with three actions (round 4; automatic from 15 replicas per SIMD up).
-   * Results are identical. */
+   * 16 also for the TD agents on the acrobot / the compass walker with three actions (round 4; automatic from 15 replicas per SIMD up),
+   * 32 for the TD agents on the compass walker (eight sub-batches; automatic from 30 replicas per SIMD up).  Results are identical. */
   int32_t  replicas_per_wave;
   /* 1: the taps are recorded by the PRODUCTION ordering of the rollout kernel (TD update applied one pass later, under the
    * next step's table loads) instead of the in-place diagnostic ordering: per-step parity of the kernel that is benchmarked.
@@ -293,7 +293,10 @@ int  grlx_get_target_weights(grlx_ctx *ctx, int replica, const uint32_t *slots, 
  * and counters are untouched, as in the reference.  The image (count must equal the table's
  * memory, else GRLX_ERR_INVALID like the reference's "Configuration mismatch") is copied once to
  * the device and shared by those replicas; their sparse tables are cleared and re-created on
- * first touch from it.  Actor-critic contexts accept it only before the first grlx_run. */
+ * first touch from it.  Actor-critic contexts accept it only before the first grlx_run.  With a target network (table 0 of a context with
+ * target_interval > 0) the load is followed by synchronize() as in the reference (representation.h:256-257): the target becomes
+ * tau * image + (1 - tau) * target for EVERY slot -- one dense vector of `memory` doubles per replica on the device while tau != 0
+ * (GRLX_ERR_OOM beyond 8 GiB of them). */
 int  grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replicas, const double *dense, uint64_t count);
 /* Replaces ParameterizedRepresentation's {action: save} (representation.h:201-229): the DENSE
  * parameter vector double[memory] of one replica's table, little-endian as grl's .dat files hold it

@@ -200,19 +200,22 @@ def test_wide_waves_bit_exact(grlx, name, n, trials, agent, generic):
                     [trials // 3, trials - trials // 3])
 
 
-@pytest.mark.parametrize("name,n,agent,generic", [("acrobot", 37, 1, 0), ("compass_walker", 21, 1, 0), ("acrobot", 19, 0, 0),
-                                                  ("acrobot", 18, 1, 1), ("compass_walker", 17, 1, 1)])
-def test_sixteen_replicas_per_wave_bit_exact(grlx, name, n, agent, generic):
+@pytest.mark.parametrize("name,n,agent,generic,wide", [("acrobot", 37, 1, 0, 16), ("compass_walker", 21, 1, 0, 16), ("acrobot", 19, 0, 0, 16),
+                                                       ("acrobot", 18, 1, 1, 16), ("compass_walker", 17, 1, 1, 16),
+                                                       ("compass_walker", 41, 1, 0, 32), ("compass_walker", 35, 0, 1, 32)])
+def test_sixteen_replicas_per_wave_bit_exact(grlx, name, n, agent, generic, wide):
     """Round 4: four sub-batches per wave (rollout_wide_kernel<., 3, 4, .>: one environment phase per 16 replicas, the lane state of the third
     and fourth sub-batch parked in device memory between their turns).  Ragged batches (37 = 2 full waves + 5: a wave with one and a quarter
     sub-batches), trials in two launches, then two successive steps budgets with test trials of two episodes; every replica against the
-    oracle: rows (returns and times), streams, environment state, sampled weights, step counts, table loads == the 8-per-wave layout's."""
+    oracle: rows (returns and times), streams, environment state, sampled weights, step counts, table loads == the 8-per-wave layout's.
+    wide = 32: EIGHT sub-batches per wave for the compass walker (two lanes per replica in the environment phase; one sub-batch parked in LDS,
+    two in registers, five in device memory requested a turn ahead); 41 = one full wave + 9: two and a quarter sub-batches."""
     from tests import configs
     make = {"acrobot": configs.acrobot, "compass_walker": configs.compass_walker}[name]
     trials = 14 if name == "acrobot" else 9
     got = {}
     seeds = np.arange(201, 201 + n)
-    for rpw in (16, 8):
+    for rpw in (wide, 8):
         cfg, spec = make(grlx, n, agent=agent, force_generic=generic, replicas_per_wave=rpw, max_rows=400, test_trials=2)
         spec.test_trials = 2
         spec.math = ob.MATH_PORTABLE
@@ -229,7 +232,7 @@ def test_sixteen_replicas_per_wave_bit_exact(grlx, name, n, agent, generic):
                         state=[r.env_state(k) for k in range(n)], w=[r.weights(k, slots) for k in range(n)], counts=r.step_counts(),
                         load=[r.table_load(k) for k in range(n)])
         r.close()
-    assert got[16]["counts"] == got[8]["counts"] and got[16]["load"] == got[8]["load"]
+    assert got[wide]["counts"] == got[8]["counts"] and got[wide]["load"] == got[8]["load"]
     learn = test = 0
     for k in range(n):
         e = ob.Experiment(spec, seed=int(seeds[k]))
@@ -237,17 +240,17 @@ def test_sixteen_replicas_per_wave_bit_exact(grlx, name, n, agent, generic):
         for b in (500, 1100):
             e.set_steps_budget(b)
             rows += e.run(100000)[0]
-        t, s_, rew = got[16]["rows"][k]
+        t, s_, rew = got[wide]["rows"][k]
         assert list(t) == [x.trial for x in rows] and list(s_) == [x.steps for x in rows], f"replica {k}"
         assert_bit_equal(rew, [x.reward for x in rows], f"returns of replica {k}")
-        assert_bit_equal(got[16]["times"][k][:len(rows)], [x.time for x in rows], f"episode times of replica {k}")
-        assert got[16]["rng"][k] == list(e.rng())[:4], f"RNG positions of replica {k}"
-        assert_bit_equal(got[16]["state"][k], e.state(), f"env state of replica {k}")
-        assert_bit_equal(got[16]["w"][k], e.weights(slots), f"weights of replica {k}")
+        assert_bit_equal(got[wide]["times"][k][:len(rows)], [x.time for x in rows], f"episode times of replica {k}")
+        assert got[wide]["rng"][k] == list(e.rng())[:4], f"RNG positions of replica {k}"
+        assert_bit_equal(got[wide]["state"][k], e.state(), f"env state of replica {k}")
+        assert_bit_equal(got[wide]["w"][k], e.weights(slots), f"weights of replica {k}")
         st = e.stats()
         learn += int(st.learn_steps); test += int(st.test_steps)
         e.close()
-    assert got[16]["counts"] == (learn, test)
+    assert got[wide]["counts"] == (learn, test)
 
 
 def test_sixteen_replicas_per_wave_is_chosen_and_refused(grlx):
@@ -255,9 +258,11 @@ def test_sixteen_replicas_per_wave_is_chosen_and_refused(grlx):
     capi = grlx.capi
     r = grlx.Runner(grlx.acrobot_q_config(16384, table_log2_capacity=10), np.arange(16384)); assert r.replicas_per_wave() == 16; r.close()
     r = grlx.Runner(grlx.acrobot_q_config(8192, table_log2_capacity=10), np.arange(8192)); assert r.replicas_per_wave() == 8; r.close()
-    with pytest.raises(capi.GrlxError) as ei:
-        grlx.Runner(grlx.pendulum_sarsa_config(64, replicas_per_wave=16), np.arange(64))
-    assert ei.value.code == capi.ERR_INVALID
+    for make, rpw in ((grlx.pendulum_sarsa_config, 16), (grlx.acrobot_q_config, 32)):
+        with pytest.raises(capi.GrlxError) as ei:
+            grlx.Runner(make(64, replicas_per_wave=rpw), np.arange(64))
+        assert ei.value.code == capi.ERR_INVALID
+    r = grlx.Runner(grlx.compass_walker_q_config(32768, table_log2_capacity=10), np.arange(32768)); assert r.replicas_per_wave() == 32; r.close()
 
 
 def test_wide_waves_generic_parameters_and_tiny_memory(grlx):

@@ -26,7 +26,7 @@ WORKLOADS = [("rollout_kernel<0, 3, false, grlx::SpecPendulumTcA<0>", "pendulum_
              ("rollout_wide_kernel<2, 3, 2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 1100, 5),          # (steps budget per launch)
              ("rollout_wide_served_kernel<2, grlx::SpecAcrobotQ>", "acrobot_q", 8192, 1100, 5),         # (the stats pass: beside its server)
              ("env_server_acrobot_pinned_kernel<grlx::SpecAcrobotQ>", "acrobot_q_env_server", 8192, 1100, 5),
-             ("rollout_wide_kernel<3, 3, 4, grlx::SpecWalkerQ>", "compass_walker_q", 16384, 12200, 5)]
+             ("rollout_wide_kernel<3, 3, 8, grlx::SpecWalkerQ>", "compass_walker_q", 32768, 12200, 4)]
 
 
 def workload_of(name):
