@@ -933,7 +933,7 @@ def _check_sampled_replicas(grlx, r, spec, seeds, sample, trials):
 
 
 @pytest.mark.parametrize("name,n,trials", [("pendulum", 4096, 44), ("cart_pole_ac", 16384, 22), ("cart_pole_ac", 13312, 22), ("compass_walker", 8192, 22),
-                                           ("acrobot", 8192, 33)])
+                                           ("acrobot", 8192, 33), ("acrobot", 16384, 22), ("compass_walker", 16384, 14), ("compass_walker", 32768, 12)])
 def test_full_size_batches(grlx, name, n, trials):
     """The replica counts BASELINE.json quotes (configs[1..3], per-GPU share of configs[3]): replicas are
     independent, so ANY replica of the big batch must equal the scalar oracle run with its seed
@@ -946,6 +946,8 @@ def test_full_size_batches(grlx, name, n, trials):
     r = grlx.Runner(cfg, seeds)
     if name == "cart_pole_ac":                                 # 16 per SIMD: four sub-batches per wave; 13: twelve slots, rotated (grlx_rollout_ac_wide.h)
         assert r.replicas_per_wave() == (16 if n == 16384 else 12)
+    else:                                                      # TD agents: 8 beyond 4 per SIMD; acrobot / walker 16 from 15 per SIMD on; the walker 32 from 30 on (the bench's layout)
+        assert r.replicas_per_wave() == {4096: 4, 8192: 8, 16384: 16, 32768: 32}[n]
     r.run(trials // 2); r.run(trials - trials // 2)
     r.sync()                                                   # raises if any replica flagged an error
     learn, test = r.step_counts()
