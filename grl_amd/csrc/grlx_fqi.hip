@@ -91,10 +91,7 @@ __device__ __forceinline__ double ann_forward(const double *w, const double (&in
       v += w[(h0 + h) * (kFqiNIn + 1) + kFqiNIn];
       net[h] = -v;
     }
-    pexp_batch<CH>(net, e);
-#pragma unroll
-    for (int h = 0; h < CH; ++h) net[h] = 1. + e[h];
-    pdiv_batch<CH>(1., net, e);                                   // a = 1 / (1 + exp(-net)), ann.h:108-111
+    plogistic_batch<CH>(net, e);                                  // a = 1 / (1 + exp(-net)), ann.h:108-111; -net clamped to +-690 (fqi.c D5)
 #pragma unroll
     for (int h = 0; h < CH; ++h)
     {

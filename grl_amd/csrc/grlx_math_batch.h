@@ -107,4 +107,72 @@ __device__ __forceinline__ void pdiv_batch(double x, const double (&y)[N], doubl
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// The batch path's logistic, a = 1 / (1 + exp(x)) with x = -net clamped to [-690, 690] (oracle/fqi.c, deviation D5: beyond the clamp the
+// reference's value is within 1e-299 of 0 or of 1), for N independent arguments.  Inside the clamp exp(x) is normal and below 2^996, so
+// (i) 2^k is applied by one exact v_ldexp_f64 and the special ranges of exp need no selects, and (ii) the divisor y = 1 + e lies in
+// [1, 2^997): for a numerator of 1 and such a divisor V_DIV_SCALE_F64 scales neither operand and raises no flag, V_DIV_FMAS_F64 is a plain
+// fma and V_DIV_FIXUP_F64 returns its first operand -- the compiler's correctly rounded division sequence (pdiv_batch) reduces to v_rcp, two
+// Newton steps and one residual correction, 7 instructions instead of 12, the same bits as `1.0 / y` on the host.  The clamp is C's
+// fmin(fmax(x, -690), 690) -- v_max_f64, v_min_f64 -- so a NaN net input gives a = 1 here and in the oracle (compares and selects: 6
+// instructions per unit instead of 2, 13.95 instead of 15.87 G).  12.7 -> 15.9 G sample-epochs/s on the bench (the same arithmetic beside
+// a second, general path in one function was 20 % SLOWER than pexp_batch + pdiv_batch; the clamp makes the second path unnecessary).
+template <int N>
+__device__ __forceinline__ void plogistic_batch(const double (&xin)[N], double (&a)[N])
+{
+  double x[N], kd[N], r[N], q[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = __builtin_fmin(__builtin_fmax(xin[i], -690.0), 690.0);      // (C's fmax / fmin: a NaN argument becomes -690)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) kd[i] = __builtin_rint(x[i] * 0x1.71547652b82fep+0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-kd[i], 0x1.62e4200000000p-1, x[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-kd[i], 0x1.fdf473de6af28p-22, r[i]);
+  __builtin_amdgcn_sched_barrier(0);
+  const double c[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+                        1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
+#pragma unroll
+  for (int i = 0; i < N; ++i) q[i] = __builtin_fma(r[i], c[0], c[1]);
+#pragma unroll
+  for (int s = 2; s < 12; ++s)
+  {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_fma(r[i], q[i], c[s]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) q[i] = 1.0 + __builtin_fma(r[i] * r[i], q[i], r[i]);
+  __builtin_amdgcn_sched_barrier(0);
+  double y[N], rcp[N], t[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] = 1. + __builtin_ldexp(q[i], (int)kd[i]);      // 1 + exp(x); |k| <= 996: the scaling is exact
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) rcp[i] = __builtin_amdgcn_rcp(y[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = __builtin_fma(-y[i], rcp[i], 1.0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) rcp[i] = __builtin_fma(rcp[i], t[i], rcp[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = __builtin_fma(-y[i], rcp[i], 1.0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) rcp[i] = __builtin_fma(rcp[i], t[i], rcp[i]);
+  __builtin_amdgcn_sched_barrier(0);
+  // (the scaled quotient u = sn * rcp with sn = 1 is rcp itself, exactly)  the residual of the quotient and its correction
+#pragma unroll
+  for (int i = 0; i < N; ++i) t[i] = __builtin_fma(-y[i], rcp[i], 1.0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = __builtin_fma(t[i], rcp[i], rcp[i]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 } // namespace grlx

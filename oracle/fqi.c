@@ -31,6 +31,10 @@
  *  D4  tests/pendulum-fqi-ann.yaml gives input_min as "observation_min+action_min": with the current parser `+`
  *      is an element-wise sum (parser.cpp:49-134), which would make the projector reject its 3-dimensional input
  *      (normalizing.cpp:80-84).  HERE: the role default of normalizing.cpp:50-51, the concatenation (`++`).
+ *  D5  (portable arithmetic only) the logistic's argument is clamped to [-690, 690] before exp: 1 / (1 + exp(-net)) is within 1e-299 of 0 or
+ *      of 1 beyond it, and inside it exp neither overflows nor leaves the normal range, which lets the GPU evaluate it without range
+ *      handling (grlx_math_batch.h: plogistic_batch).  With libm arithmetic (the reference's own formula) nothing is clamped; the
+ *      cross-mode test (tests/test_oracle_fqi.py) holds both to 1e-5 relative.
  *  pow(gamma, tau) with tau = control_step (DynamicalModel::step returns tau_, modeled.cpp:275; the batch path has no
  *  discrete_time) is evaluated ONCE with libm by the caller and passed in as gamma_tau in both math modes.
  */
@@ -75,7 +79,9 @@ static double ann_forward(const orc_fqi *f, const double *in, double *a_out)
     double net = 0;
     for (int i = 0; i < n_in; ++i) net += W1[(size_t)h * (n_in + 1) + i] * in[i];
     net += W1[(size_t)h * (n_in + 1) + n_in];                     /* bias row */
-    const double a = 1. / (1. + fq_exp(f, -net));                 /* ann.h:108-111 */
+    double x = -net;
+    if (f->spec.base.math == ORC_MATH_PORTABLE) x = fmin(fmax(x, -690.), 690.);                      /* D5 (a NaN becomes -690) */
+    const double a = 1. / (1. + fq_exp(f, x));                    /* ann.h:108-111 */
     if (a_out) a_out[h] = a;
     out += W2[h] * a;
   }

@@ -108,6 +108,14 @@ def test_fqi_gradient_descent_and_rmsprop_bit_exact(grlx, hidden, eta):
     _both(grlx, [5, 6], 2, batch_size=1300, iterations=3, epochs=30, hidden=hidden, eta=eta)
 
 
+@pytest.mark.parametrize("hidden", [20, 64])
+def test_fqi_saturated_logistic_bit_exact(grlx, hidden):
+    """The logistic's argument is clamped to +-690 (oracle/fqi.c D5), which is what lets the kernel evaluate it without range handling.  Gradient
+    descent with eta = 2 blows the weights up to 10^4 within the first iteration: net inputs in the thousands, the clamp is taken on both
+    sides and the units saturate to exactly 1 and to 1 / (1 + exp(690)); all of it bit-exact against the oracle."""
+    _both(grlx, [5, 6, 7], 2, batch_size=500, iterations=3, epochs=40, eta=2.0, hidden=hidden)
+
+
 def test_fqi_iteration_loop_stops_per_replica(grlx):
     """gamma = 0: the targets are the rewards and the second iteration changes nothing (fqi.cpp:213); the stop is taken
     on the device, per replica, without a host round trip."""
