@@ -310,9 +310,12 @@ template <int H> struct FqiShape {
   static constexpr int COLS = 2 * H + kFqiNIn + 2;        // in[3], d1[H], a[H], d2, 1.0
   static constexpr int WAVES = ((size_t)4 * 64 * COLS * 8 + 3 * P * 8 + 64 <= 160 * 1024) ? 4 : 2;
   static constexpr int BLOCKS = 64 / WAVES;               // per replica
-  static constexpr int SPB = (KP == 1) ? 4 : (KP == 2) ? 3 : (KP == 3) ? 2 : 1;
+  // KP == 2 (16 and 20 hidden units): a lane's two terms SHARE a factor (below), three LDS reads per sample instead of four
+  static constexpr bool SHARED = KP == 2 && 2 * H + (H + 3) / 2 <= 64;
+  static constexpr int RS = SHARED ? 3 : 2 * KP;          // LDS reads per sample and lane
+  static constexpr int SPB = 12 / RS;
   static constexpr int QSPLIT = (63 * COLS * 8 <= 65535) ? 64 : 32;      // ds_read offsets are 16 bits: a second base address beyond
-  static_assert(KP <= 6 && 2 * KP * SPB <= 12, "reads per batch");
+  static_assert(KP <= 6 && RS * SPB <= 12 && SPB >= 1, "reads per batch");
   static_assert((size_t)WAVES * 64 * COLS * 8 + 3 * P * 8 + 64 <= 160 * 1024, "factor tiles exceed the LDS");
 };
 constexpr int kFqiStampBlocks = 16;
@@ -356,21 +359,55 @@ __global__ __launch_bounds__(FqiShape<H>::WAVES * 64) void fqi_epochs_kernel(Fqi
     sh_eta[k] = net[F.P + k];
     sh_prev[k] = net[3 * F.P + k];
   }
-  // the two factors of the per-sample gradient terms this lane sums (parameters lane, lane + 64, ...; x * 1.0 is exact)
-  int cx[KP], cy[KP];
-#pragma unroll
-  for (int k = 0; k < KP; ++k)
+  // the two factors of the per-sample gradient terms this lane sums (x * 1.0 is exact) and the parameter each sum belongs to (P: the squared
+  // error, ann.cpp:240; -1: none).  General layout: parameters lane, lane + 64, ...  SHARED layout (two terms per lane): the two share one
+  // factor, so a sample costs three LDS reads instead of four -- layer 1: lane (h, pair) sums Delta1(2 pair, h) and Delta1(2 pair + 1, h),
+  // both times d1[h]; layer 2, its bias and the error: neighbours two by two, all times d2.  Which lane sums a parameter does not touch the
+  // order of its sum (samples of a chunk in order, then the fixed tree).
+  constexpr bool SHARED = Sh::SHARED;
+  int cx[KP], cy[KP], pidx[KP];
+  if constexpr (SHARED)
   {
-    const int p = lane + 64 * k;
-    if (p < (kFqiNIn + 1) * H)
+    constexpr int L1 = 2 * H, E2 = H + 2, L2 = (E2 + 1) / 2;
+    static_assert(L1 + L2 <= 64, "lanes of the shared-factor layout");
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
     {
-      const int h = p / (kFqiNIn + 1), i = p % (kFqiNIn + 1);
-      cx[k] = (i < kFqiNIn) ? C_IN + i : C_ONE;                    // Delta1(i, h) += a0[i] * d1[h]; bias row: d1[h]
-      cy[k] = C_D1 + h;
+      if (lane < L1)
+      {
+        const int h = lane >> 1, i = 2 * (lane & 1) + k;
+        cx[k] = (i < kFqiNIn) ? C_IN + i : C_ONE;                  // Delta1(i, h) += a0[i] * d1[h]; bias row: d1[h]
+        cy[k] = C_D1 + h;
+        pidx[k] = h * (kFqiNIn + 1) + i;
+      }
+      else
+      {
+        const int q = 2 * (lane - L1) + k;
+        cy[k] = C_D2;
+        if (lane < L1 + L2 && q < H) { cx[k] = C_A + q; pidx[k] = (kFqiNIn + 1) * H + q; }   // Delta2(h) += a1[h] * d2
+        else if (lane < L1 + L2 && q == H) { cx[k] = C_ONE; pidx[k] = P - 1; }                // bias: d2
+        else if (lane < L1 + L2 && q == H + 1) { cx[k] = C_D2; pidx[k] = P; }                 // squared error
+        else { cx[k] = C_D2; pidx[k] = -1; }
+      }
     }
-    else if (p < P - 1) { cx[k] = C_A + (p - (kFqiNIn + 1) * H); cy[k] = C_D2; }   // Delta2(h) += a1[h] * d2
-    else if (p == P - 1) { cx[k] = C_ONE; cy[k] = C_D2; }                          // bias: d2
-    else { cx[k] = C_D2; cy[k] = C_D2; }                                           // p == P: squared error (ann.cpp:240); beyond: unused
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+    {
+      const int p = lane + 64 * k;
+      pidx[k] = (p <= P) ? p : -1;
+      if (p < (kFqiNIn + 1) * H)
+      {
+        const int h = p / (kFqiNIn + 1), i = p % (kFqiNIn + 1);
+        cx[k] = (i < kFqiNIn) ? C_IN + i : C_ONE;                  // Delta1(i, h) += a0[i] * d1[h]; bias row: d1[h]
+        cy[k] = C_D1 + h;
+      }
+      else if (p < P - 1) { cx[k] = C_A + (p - (kFqiNIn + 1) * H); cy[k] = C_D2; }   // Delta2(h) += a1[h] * d2
+      else if (p == P - 1) { cx[k] = C_ONE; cy[k] = C_D2; }                          // bias: d2
+      else { cx[k] = C_D2; cy[k] = C_D2; }                                           // p == P: squared error (ann.cpp:240); beyond: unused
+    }
   }
   row[C_ONE] = 1.;                                        // the constant factor of the bias terms: written once
   const size_t base = (size_t)r * (size_t)F.cap;
@@ -458,7 +495,7 @@ __global__ __launch_bounds__(FqiShape<H>::WAVES * 64) void fqi_epochs_kernel(Fqi
         { // 128 KP LDS reads per wave and chunk: issued as plain ds_read_b64 (2 LDS cycles each; the compiler pairs neighbouring rows
           // into ds_read2_b64, 8 cycles per pair: MI355X_MICROARCH.md, LDS table), SPB samples (<= 12 reads) per batch, the next
           // batch in flight while the current one is multiplied and added (lgkmcnt counts at most 15 operations)
-          constexpr int RPB = 2 * KP * SPB, NB = 64 / SPB, REM = 64 % SPB;
+          constexpr int RS = Sh::RS, RPB = RS * SPB, NB = 64 / SPB, REM = 64 % SPB;
           double x[2][12];
           const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) double *)tile;
           unsigned a_cx[64 / QSPLIT][KP], a_cy[64 / QSPLIT][KP];
@@ -473,18 +510,39 @@ __global__ __launch_bounds__(FqiShape<H>::WAVES * 64) void fqi_epochs_kernel(Fqi
 #define FQI_RD(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define FQI_ISSUE(buf, q0, cnt)                                                                                           \
           _Pragma("unroll") for (int t = 0; t < (cnt); ++t)                                                                \
-            _Pragma("unroll") for (int k = 0; k < KP; ++k)                                                                 \
+          {                                                                                                               \
+            if constexpr (SHARED)                                                                                         \
             {                                                                                                             \
-              FQI_RD(x[buf][2 * (t * KP + k) + 0], a_cx[((q0) + t) / QSPLIT][k], (((q0) + t) % QSPLIT) * COLS * 8);          \
-              FQI_RD(x[buf][2 * (t * KP + k) + 1], a_cy[((q0) + t) / QSPLIT][k], (((q0) + t) % QSPLIT) * COLS * 8);          \
-            }
+              FQI_RD(x[buf][3 * t + 0], a_cy[((q0) + t) / QSPLIT][0], (((q0) + t) % QSPLIT) * COLS * 8);                   \
+              FQI_RD(x[buf][3 * t + 1], a_cx[((q0) + t) / QSPLIT][0], (((q0) + t) % QSPLIT) * COLS * 8);                   \
+              FQI_RD(x[buf][3 * t + 2], a_cx[((q0) + t) / QSPLIT][1], (((q0) + t) % QSPLIT) * COLS * 8);                   \
+            }                                                                                                             \
+            else                                                                                                          \
+            {                                                                                                             \
+              _Pragma("unroll") for (int k = 0; k < KP; ++k)                                                               \
+              {                                                                                                           \
+                FQI_RD(x[buf][2 * (t * KP + k) + 0], a_cx[((q0) + t) / QSPLIT][k], (((q0) + t) % QSPLIT) * COLS * 8);        \
+                FQI_RD(x[buf][2 * (t * KP + k) + 1], a_cy[((q0) + t) / QSPLIT][k], (((q0) + t) % QSPLIT) * COLS * 8);        \
+              }                                                                                                           \
+            }                                                                                                             \
+          }
 #define FQI_USE(buf, cnt)                                                                                                 \
           _Pragma("unroll") for (int t = 0; t < (cnt); ++t)                                                                \
-            _Pragma("unroll") for (int k = 0; k < KP; ++k) v[k] += x[buf][2 * (t * KP + k) + 0] * x[buf][2 * (t * KP + k) + 1];
+          {                                                                                                               \
+            if constexpr (SHARED)                                                                                         \
+            {                                                                                                             \
+              v[0] += x[buf][3 * t + 1] * x[buf][3 * t + 0];                                                              \
+              v[1] += x[buf][3 * t + 2] * x[buf][3 * t + 0];                                                              \
+            }                                                                                                             \
+            else                                                                                                          \
+            {                                                                                                             \
+              _Pragma("unroll") for (int k = 0; k < KP; ++k) v[k] += x[buf][2 * (t * KP + k) + 0] * x[buf][2 * (t * KP + k) + 1]; \
+            }                                                                                                             \
+          }
 #define FQI_BATCH(cur, nxt)                                                                                               \
           {                                                                                                               \
             if (b + 1 < NB) { FQI_ISSUE(nxt, SPB * (b + 1), SPB); fqi_lds_wait<RPB>(x[cur]); }                             \
-            else if (REM) { FQI_ISSUE(nxt, SPB * NB, REM); fqi_lds_wait<2 * KP * REM>(x[cur]); }                           \
+            else if (REM) { FQI_ISSUE(nxt, SPB * NB, REM); fqi_lds_wait<RS * REM>(x[cur]); }                               \
             else fqi_lds_wait<0>(x[cur]);                                                                                 \
             FQI_USE(cur, SPB);                                                                                            \
           }
@@ -522,7 +580,7 @@ __global__ __launch_bounds__(FqiShape<H>::WAVES * 64) void fqi_epochs_kernel(Fqi
     double *vL = F.vL + ((size_t)(e & 1) * (size_t)F.R + (size_t)r) * 64 * (size_t)(P + 1);
 #pragma unroll
     for (int k = 0; k < KP; ++k)                                     // [parameter][L]: the 64 leaves of a tree are 512 contiguous bytes
-      if (lane + 64 * k <= P) fqi_publish(vL + (size_t)(lane + 64 * k) * 64 + L, acc[k]);
+      if (pidx[k] >= 0) fqi_publish(vL + (size_t)pidx[k] * 64 + L, acc[k]);
     if (!fqi_meet(counter, (unsigned)(e + 1) * BLOCKS, &sh_ok))
     {
       if (threadIdx.x == 0) atomicOr(&rep.status, ST_SYNC_TIMEOUT);
