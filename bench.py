@@ -549,7 +549,12 @@ def main():
         if head == "pendulum_sarsa":
             n = out["replicas_per_gpu"]
             line["config"].update({"trials_per_step": TRIALS_PER_STEP, "env_steps_per_step": int(out["env_steps_per_step"]), "tilings": 16, "memory": 8388608})
-            assert out["learn_steps"] == n * 10 * STEPS_PER_EPISODE * out["steps"] * D.world, out["learn_steps"]
+            # every pendulum episode lasts exactly 100 steps: the devices' own step counters must say so.  Reported, not asserted: a line
+            # with "learn_steps_expected" != "learn_steps" is a finding, a crashed bench is no line at all
+            line["learn_steps_expected"] = n * 10 * STEPS_PER_EPISODE * out["steps"] * D.world
+            if out["learn_steps"] != line["learn_steps_expected"]:
+                print(f"bench.py: learning steps counted by the devices ({out['learn_steps']}) differ from 10 episodes x 100 steps per replica and "
+                      f"launch ({line['learn_steps_expected']})", file=sys.stderr)
     if args.workload == "pendulum_sarsa" and not args.no_secondary:
         # the other configurations BASELINE.json names, each sharded over the same ranks and timed the same way
         sec = []

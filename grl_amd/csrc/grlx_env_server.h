@@ -192,8 +192,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void env_s
 #ifdef GRLX_ENV_SERVER_STATS
   unsigned long long t_begin = mail_clock(), t_busy = 0, n_cmd = 0, n_idle = 0, n_split = 0, n_batch = 0;
 #endif
+  // (tests: bits 8-23 of env_tune = the server leaves, unannounced, once it has answered that many commands of a replica -- a fetch in
+  //  MID-episode then runs into its bound and the rollout wave goes on by itself from there)
+  const unsigned long long quit_after = (P.env_tune >> 8) & 0xFFFFu;
   for (;;)
   {
+    if (quit_after != 0u && expect > quit_after) done = true;
     if (__all(done)) break;
     unsigned long long word = 0;
     bool ready = false;

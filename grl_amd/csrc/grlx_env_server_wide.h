@@ -159,8 +159,10 @@ __device__ __forceinline__ void env_server_wide_body(const DevParams &P)
   unsigned idle = 0;
   bool seen = false;
   mail_setprio((P.env_tune >> 2) & 3u);
+  const unsigned long long quit_after = (P.env_tune >> 8) & 0xFFFFu;      // (tests: the server leaves, unannounced, after that many passes)
   for (;;)
   {
+    if (quit_after != 0u && expect > quit_after) done = true;
     if (__all(done)) break;
     unsigned long long word = 0;
     bool ready = false;

@@ -251,7 +251,7 @@ double orc_lazy_weight(uint32_t tl_seed, uint64_t draws_before, uint32_t slot,
 
 /* ------------------------------------------------------- batch path (FQI) -- */
 /* experiment/batch_learning + predictor/fqi + representation/iterative + representation/parameterized/ann over
- * projector/pre/normalizing (tests/pendulum-fqi-ann.yaml; BASELINE configs[4]).  fqi.c: PARITY UNPINNED, deviations D1-D4. */
+ * projector/pre/normalizing (tests/pendulum-fqi-ann.yaml; BASELINE configs[4]).  fqi.c: PARITY UNPINNED, deviations D1-D5. */
 typedef struct {
   orc_spec base;          /* env (pendulum), control_step, integration_steps, timeout, action_min/max/steps, gamma, math */
   int      batch_size;    /* experiment/batch_learning:batch_size: transitions drawn per batch                          */

@@ -323,3 +323,33 @@ def test_the_walker_s_server_is_opt_in(grlx, monkeypatch):
     r.run(3); r.sync()
     assert r.last_kernel() == 2 and r.replicas_per_wave() == 8 and r.env_server_counts() == (0, 0)
     r.close()
+
+
+@pytest.mark.parametrize("agent,quit_after", [(0, 37), (1, 101), (0, 250), (3, 777)])
+def test_a_server_that_leaves_in_mid_episode(grlx, monkeypatch, agent, quit_after):
+    """The bound of a fetch is there for a server that is late or gone; `GRLX_ENV_SERVER_TUNE` bits 8-23 make the server leave, unannounced, after
+    it has answered that many commands of a replica: in the MIDDLE of an episode (37: the first; 101: exactly at a trial boundary, the reset is
+    answered and nothing after it; 250: the third trial; 777: the eighth -- every launch counts its commands from 1, so both launches of 25 + 10
+    trials lose their server).  The rollout wave's next fetch runs into its bound, the wave integrates that step itself from the state it holds and goes on alone.
+    Same bits as with the server off; every replica reports that it fell back."""
+    seeds = np.arange(21, 34)
+    monkeypatch.setenv("GRLX_ENV_SERVER", "0")
+    off = _snapshot(grlx, seeds, [25, 10], agent=agent)
+    monkeypatch.delenv("GRLX_ENV_SERVER")
+    monkeypatch.setenv("GRLX_ENV_SERVER_TUNE", str((quit_after << 8) | 3))
+    on = _snapshot(grlx, seeds, [25, 10], agent=agent)
+    assert on["counts"] == (0, len(seeds)), on["counts"]
+    _same(on, off)
+
+
+@pytest.mark.parametrize("env,quit_after", [("acrobot", 45), ("acrobot", 88), ("walker", 29)])
+def test_a_wide_server_that_leaves_in_mid_episode(grlx, monkeypatch, env, quit_after):
+    seeds = np.arange(3, 16)
+    chunks = [12, 5] if env == "acrobot" else [5, 3]
+    monkeypatch.setenv("GRLX_ENV_SERVER", "0")
+    off = _wide_snapshot(grlx, env, seeds, chunks)
+    monkeypatch.delenv("GRLX_ENV_SERVER")
+    monkeypatch.setenv("GRLX_ENV_SERVER_TUNE", str(quit_after << 8))
+    on = _wide_snapshot(grlx, env, seeds, chunks)
+    assert on["counts"][1] > 0, on["counts"]      # (a replica whose last launch had fewer passes than that was served to its end)
+    _same_wide(on, off)

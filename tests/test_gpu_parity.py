@@ -879,6 +879,7 @@ def _bench_two_ranks(extra, timeout=900):
 def test_bench_two_ranks_share_the_replica_range(grlx):
     out = _bench_two_ranks(["--steps", "3", "--warmup", "1", "--replicas", "256", "--no-secondary"])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["learn_steps"] == out["learn_steps_expected"] == 2 * 256 * 1000 * 3, (out["learn_steps"], out.get("env_server"))
     assert out["config"]["env_steps_per_step"] == 2 * 256 * 1100
     assert out["curve_replicas"] == 512                                   # the all-reduced curve counts both ranks' replicas
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"}
@@ -933,7 +934,7 @@ def _check_sampled_replicas(grlx, r, spec, seeds, sample, trials):
 
 
 @pytest.mark.parametrize("name,n,trials", [("pendulum", 4096, 44), ("cart_pole_ac", 16384, 22), ("cart_pole_ac", 13312, 22), ("compass_walker", 8192, 22),
-                                           ("acrobot", 8192, 33), ("acrobot", 16384, 12), ("compass_walker", 32768, 8)])
+                                           ("acrobot", 8192, 33), ("acrobot", 16384, 12), ("compass_walker", 32768, 11)])
 def test_full_size_batches(grlx, name, n, trials):
     """The replica counts BASELINE.json quotes (configs[1..3], per-GPU share of configs[3]): replicas are
     independent, so ANY replica of the big batch must equal the scalar oracle run with its seed
