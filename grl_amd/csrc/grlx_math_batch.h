@@ -132,12 +132,14 @@ __device__ __forceinline__ void plogistic_batch(const double (&xin)[N], double (
 #pragma unroll
   for (int i = 0; i < N; ++i) r[i] = __builtin_fma(-kd[i], 0x1.fdf473de6af28p-22, r[i]);
   __builtin_amdgcn_sched_barrier(0);
-  const double c[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
-                        1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
+  // the kernel 1 + r + r^2 q(r), q of degree 9: a Chebyshev fit of (e^r - 1 - r) / r^2 on |r| <= ln2 / 2, 0.07 ulp from exp before rounding
+  // (oracle/fqi.c: logistic_exp; pexp_batch keeps the Taylor polynomial of degree 11 the other paths' parity is pinned on)
+  const double c[10] = {0x1.af389ecfc4b9cp-26, 0x1.28917c89a43a7p-22, 0x1.71de0db2f6b19p-19, 0x1.a019b9149a41cp-16, 0x1.a01a01a7c2efep-13,
+                        0x1.6c16c17889ef1p-10, 0x1.11111111109b5p-7, 0x1.5555555553d68p-5, 0x1.5555555555556p-3, 0x1.0000000000001p-1};
 #pragma unroll
   for (int i = 0; i < N; ++i) q[i] = __builtin_fma(r[i], c[0], c[1]);
 #pragma unroll
-  for (int s = 2; s < 12; ++s)
+  for (int s = 2; s < 10; ++s)
   {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

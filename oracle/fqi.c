@@ -66,7 +66,23 @@ struct orc_fqi {
   double       last_error;        /* error_/samples_ of the last epoch (ann.cpp:201) */
 };
 
-static double fq_exp(const orc_fqi *f, double x) { return f->spec.base.math == ORC_MATH_PORTABLE ? orc_pexp(x) : exp(x); }
+/* exp(x) for the logistic's clamped argument, |x| <= 690 (D5): the reduction and scaling of orc_pexp (portable_math.c), the kernel
+ * 1 + r + r^2 q(r) with q of degree 9 instead of orc_pexp's Taylor polynomial of degree 11 -- a Chebyshev fit of (e^r - 1 - r) / r^2 on
+ * |r| <= ln2/2 (mpmath, 200 bits), 0.07 ulp from exp before rounding; the result is normal, so the two-step scaling is exact.  GPU:
+ * plogistic_batch, grlx_math_batch.h (same operations, same order). */
+double orc_logistic_exp(double x)
+{
+  static const double c[10] = {0x1.af389ecfc4b9cp-26, 0x1.28917c89a43a7p-22, 0x1.71de0db2f6b19p-19, 0x1.a019b9149a41cp-16, 0x1.a01a01a7c2efep-13,
+                               0x1.6c16c17889ef1p-10, 0x1.11111111109b5p-7, 0x1.5555555553d68p-5, 0x1.5555555555556p-3, 0x1.0000000000001p-1};
+  const double kd = rint(x * 0x1.71547652b82fep+0);
+  double r = fma(-kd, 0x1.62e4200000000p-1, x);
+  r = fma(-kd, 0x1.fdf473de6af28p-22, r);
+  double q = fma(r, c[0], c[1]);
+  for (int s = 2; s < 10; ++s) q = fma(r, q, c[s]);
+  const double e = 1.0 + fma(r * r, q, r);
+  return ldexp(e, (int)kd);                                         /* exact: the result is normal */
+}
+static double fq_exp(const orc_fqi *f, double x) { return f->spec.base.math == ORC_MATH_PORTABLE ? orc_logistic_exp(x) : exp(x); }
 
 /* ANNRepresentation::read (ann.cpp:133-160) for one normalised input; hidden activations to a[] when given */
 static double ann_forward(const orc_fqi *f, const double *in, double *a_out)

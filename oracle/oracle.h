@@ -59,7 +59,8 @@ void     orc_rand48_jump(orc_rand48 *g, uint64_t n);
 double orc_psin(double x);
 double orc_pcos(double x);
 double orc_plog(double x);
-double orc_pexp(double x);     /* logistic activation of the ANN representation (ann.h:108-111) */
+double orc_pexp(double x);     /* portable exp (policies; the batch path until round 4) */
+double orc_logistic_exp(double x);  /* exp of the batch path's clamped logistic argument, |x| <= 690 (fqi.c D5) */
 
 enum { ORC_MATH_LIBM = 0, ORC_MATH_PORTABLE = 1 };
 

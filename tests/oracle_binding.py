@@ -121,6 +121,7 @@ def load():
     L.orc_lazy_weight.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_double, C.c_double]
     L.orc_lazy_weight.restype = C.c_double
     L.orc_pexp.argtypes = [C.c_double]; L.orc_pexp.restype = C.c_double
+    L.orc_logistic_exp.argtypes = [C.c_double]; L.orc_logistic_exp.restype = C.c_double
     L.orc_fqi_spec_pendulum.argtypes = [P(FqiSpec)]
     L.orc_fqi_create.argtypes = [P(FqiSpec), C.c_long]; L.orc_fqi_create.restype = C.c_void_p
     L.orc_fqi_destroy.argtypes = [C.c_void_p]

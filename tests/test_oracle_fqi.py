@@ -103,3 +103,20 @@ def test_portable_exp_against_libm(oracle):
     ulp = np.abs(got - want) / np.spacing(want)
     assert ulp.max() <= 1.0
     assert oracle.orc_pexp(0.0) == 1.0 and oracle.orc_pexp(800.0) == np.inf and oracle.orc_pexp(-800.0) == 0.0
+
+
+def test_the_logistic_s_exp_is_within_one_ulp(oracle):
+    """oracle/fqi.c: logistic_exp (D5: arguments within +-690; a degree-9 kernel polynomial fitted with mpmath) against mpmath's exp at 200 bits:
+    the error stays below one unit in the last place over the whole range, at the clamp's ends and at zero."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-690, 690, 3000), rng.uniform(-1, 1, 1500), [0.0, -690.0, 690.0, 0.34657359027997264, -0.34657359027997264]])
+    worst = 0.0
+    for x in xs:
+        got = mp.mpf(oracle.orc_logistic_exp(float(x)))
+        want = mp.e ** mp.mpf(float(x))
+        ulp = mp.mpf(2) ** (mp.floor(mp.log(want, 2)) - 52)
+        worst = max(worst, float(abs(got - want) / ulp))
+    assert worst < 1.0, worst
+    assert oracle.orc_logistic_exp(0.0) == 1.0
