@@ -1212,6 +1212,18 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
   ctx->run_pending = false;
   double *img = nullptr;
   if (hipMalloc((void **)&img, sizeof(double) * memory) != hipSuccess) return fail(GRLX_ERR_OOM, "no device memory for a %zu-weight policy image", memory);
+  // (a target network with tau != 0: one new dense vector per replica, allocated before anything is touched -- a failure leaves the context as it was)
+  std::vector<double *> fresh((size_t)n_replicas, nullptr);
+  if (target_images)
+    for (int k = 0; k < n_replicas; ++k)
+      if (hipMalloc((void **)&fresh[(size_t)k], sizeof(double) * memory) != hipSuccess)
+      {
+        (void)hipGetLastError();
+        for (double *t : fresh)
+          if (t) (void)hipFree(t);
+        (void)hipFree(img);
+        return fail(GRLX_ERR_OOM, "no device memory for the target vector of replica %d", first_replica + k);
+      }
   ctx->images.push_back(img);
   {
     std::vector<int> &of = ctx->image_of[table];
@@ -1225,19 +1237,15 @@ int grlx_load_weights(grlx_ctx *ctx, int table, int first_replica, int n_replica
     if (ctx->target_images.empty()) ctx->target_images.assign((size_t)N, nullptr);
     std::vector<ReplicaState> hs((size_t)n_replicas);
     HIP_TRY(hipMemcpy(hs.data(), ctx->states + first_replica, sizeof(ReplicaState) * (size_t)n_replicas, hipMemcpyDeviceToHost));
+    if (target_images)
+      for (int k = 0; k < n_replicas; ++k) HIP_TRY(launch_target_after_load(ctx->P, first_replica + k, img, fresh[(size_t)k], nullptr));
+    HIP_TRY(hipDeviceSynchronize());          // (the kernels read the vectors of an earlier load for the last time)
     for (int k = 0; k < n_replicas; ++k)
     {
       const int r = first_replica + k;
-      double *timg = nullptr;
-      if (target_images)
-      {
-        if (hipMalloc((void **)&timg, sizeof(double) * memory) != hipSuccess) return fail(GRLX_ERR_OOM, "no device memory for the target vector of replica %d", r);
-        HIP_TRY(launch_target_after_load(ctx->P, r, img, timg, nullptr));
-      }
-      HIP_TRY(hipDeviceSynchronize());
-      if (ctx->target_images[(size_t)r]) (void)hipFree(ctx->target_images[(size_t)r]);      // (read by the kernel above for the last time)
-      ctx->target_images[(size_t)r] = timg;
-      hs[(size_t)k].target_base = timg;
+      if (ctx->target_images[(size_t)r]) (void)hipFree(ctx->target_images[(size_t)r]);
+      ctx->target_images[(size_t)r] = fresh[(size_t)k];
+      hs[(size_t)k].target_base = fresh[(size_t)k];
       hs[(size_t)k].syncs += 1;                     // the load's synchronize() (count_ = 0, representation.h:284-296)
       hs[(size_t)k].syncs_base = hs[(size_t)k].syncs;
       hs[(size_t)k].sync_count = 0;
