@@ -4,6 +4,7 @@
 // -g N: one process per GPU (rank r on the r-th visible device, started before anything touches HIP), every rank running -r replicas
 // (clones r * replicas ..., seeds and "@i" identities counted over the whole job), the learning curves reduced with one RCCL all-reduce
 // per run (multi_gpu.h); rank 0 prints the rows and writes <output>-<run>-mean.txt.  The model is experiment/multi (multi.cpp:44-75).
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -71,12 +72,20 @@ int main(int argc, char **argv)
         kids.push_back(pid);
       }
       if (rank < 0)
-      { // the parent: wait for the ranks, fail if any of them failed
+      { // the parent: wait for the ranks in whatever order they end; the first failure ends the others (a rank that waits for a dead peer
+        // inside the communicator's rendezvous would wait for ever)
         int bad = 0;
-        for (pid_t k : kids)
+        for (size_t left = kids.size(); left > 0; --left)
         {
           int st = 0;
-          if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad++;
+          const pid_t done = waitpid(-1, &st, 0);
+          if (done < 0) { bad++; break; }
+          if (!WIFEXITED(st) || WEXITSTATUS(st) != 0)
+          {
+            if (bad++ == 0)
+              for (pid_t k : kids)
+                if (k != done) kill(k, SIGTERM);
+          }
         }
         unlink(id_file.c_str());
         if (bad) log(0, std::to_string(bad) + " of " + std::to_string(gpus) + " ranks failed");
